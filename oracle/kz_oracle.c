@@ -1,0 +1,686 @@
+/*
+ * kz_oracle.c — CPU restatement of the kZero self-play NN-eval path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load this library, and only as the checker /
+ * reported CPU baseline.  The product path (kzero_amd/csrc) never links or calls it.
+ *
+ * Parity status: the arithmetic of this path lives in the un-vendored crates.io
+ * dependency kn-graph 0.7.3 (rust/Cargo.toml:47-51; call site
+ * rust/kz-core/src/network/cpu.rs:50 `cpu_eval_graph_exec`) and no reference test pins a
+ * numeric network output.  This oracle is therefore pinned against
+ * golden vectors produced HERE by the reference's own PyTorch network definition
+ * (python/lib/model/post_act.py, the module the ONNX is exported from) with the
+ * committed generator oracle/gen_golden.py — see tests/test_oracle_golden.py — plus the
+ * BitBuffer known answers of rust/kz-core/src/mapping/bit_buffer.rs:112-164.
+ *
+ * Every function cites the reference lines it restates.  Layout is NCHW f32 and the
+ * convolution is the direct 7-loop form, like the reference CPU executor.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define KZO_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* KZMODEL1 container (format: kzero_amd/model_file.py)                       */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    char name[96];
+    int dtype; /* 0 f32, 1 i64 */
+    int ndim;
+    uint64_t dims[6];
+    const void *data;
+    uint64_t count;
+} kzo_tensor;
+
+typedef struct {
+    char key[64];
+    int kind; /* 0 int, 1 float, 2 string */
+    int64_t i;
+    double f;
+    char s[64];
+} kzo_meta;
+
+typedef struct kzo_net {
+    uint8_t *blob;
+    int n_meta;
+    kzo_meta *meta;
+    int n_tensors;
+    kzo_tensor *tensors;
+
+    int h, w, n_scalar, n_bool, c_in;
+    int depth, channels, final_affine;
+    int sh_channels, sh_size;
+    int policy_len;
+    int policy_kind; /* 0 ataxx_conv, 1 conv, 2 attention, 3 dense */
+    int policy_conv_channels, policy_extra_moves, policy_query_channels;
+    int dense_hidden_channels, dense_hidden_size;
+    float bn_eps;
+} kzo_net;
+
+static __thread char kzo_err[256];
+
+KZO_EXPORT const char *kzo_last_error(void) { return kzo_err; }
+
+static int fail(const char *msg) {
+    snprintf(kzo_err, sizeof kzo_err, "%s", msg);
+    return -1;
+}
+
+typedef struct {
+    const uint8_t *p;
+    size_t left;
+    int bad;
+} reader;
+
+static void rd(reader *r, void *dst, size_t n) {
+    if (r->left < n) {
+        r->bad = 1;
+        memset(dst, 0, n);
+        return;
+    }
+    memcpy(dst, r->p, n);
+    r->p += n;
+    r->left -= n;
+}
+
+static const kzo_meta *find_meta(const kzo_net *net, const char *key) {
+    for (int i = 0; i < net->n_meta; i++)
+        if (!strcmp(net->meta[i].key, key)) return &net->meta[i];
+    return NULL;
+}
+
+static int64_t meta_int(const kzo_net *net, const char *key, int64_t dflt) {
+    const kzo_meta *m = find_meta(net, key);
+    if (!m) return dflt;
+    return m->kind == 1 ? (int64_t)m->f : m->i;
+}
+
+static const kzo_tensor *find_tensor(const kzo_net *net, const char *name) {
+    for (int i = 0; i < net->n_tensors; i++)
+        if (!strcmp(net->tensors[i].name, name)) return &net->tensors[i];
+    return NULL;
+}
+
+static const float *tensor_f32(const kzo_net *net, const char *name, uint64_t expect) {
+    const kzo_tensor *t = find_tensor(net, name);
+    if (!t || t->dtype != 0 || t->count != expect) {
+        snprintf(kzo_err, sizeof kzo_err, "missing or mis-shaped tensor '%s' (want %llu values)", name,
+                 (unsigned long long)expect);
+        return NULL;
+    }
+    return (const float *)t->data;
+}
+
+KZO_EXPORT void kzo_free(kzo_net *net) {
+    if (!net) return;
+    free(net->blob);
+    free(net->meta);
+    free(net->tensors);
+    free(net);
+}
+
+KZO_EXPORT int kzo_load(const void *blob, size_t len, kzo_net **out) {
+    kzo_net *net = calloc(1, sizeof *net);
+    net->blob = malloc(len);
+    memcpy(net->blob, blob, len);
+    reader r = {net->blob, len, 0};
+
+    char magic[8];
+    rd(&r, magic, 8);
+    if (r.bad || memcmp(magic, "KZMODEL1", 8)) {
+        kzo_free(net);
+        return fail("not a KZMODEL1 container");
+    }
+    uint32_t n_meta;
+    rd(&r, &n_meta, 4);
+    net->n_meta = (int)n_meta;
+    net->meta = calloc(n_meta ? n_meta : 1, sizeof(kzo_meta));
+    for (uint32_t i = 0; i < n_meta && !r.bad; i++) {
+        kzo_meta *m = &net->meta[i];
+        uint16_t klen;
+        rd(&r, &klen, 2);
+        if (klen >= sizeof m->key) { r.bad = 1; break; }
+        rd(&r, m->key, klen);
+        uint8_t kind;
+        rd(&r, &kind, 1);
+        m->kind = kind;
+        if (kind == 0) rd(&r, &m->i, 8);
+        else if (kind == 1) rd(&r, &m->f, 8);
+        else if (kind == 2) {
+            uint32_t vlen;
+            rd(&r, &vlen, 4);
+            if (vlen >= sizeof m->s) { r.bad = 1; break; }
+            rd(&r, m->s, vlen);
+        } else r.bad = 1;
+    }
+    uint32_t n_tensors;
+    rd(&r, &n_tensors, 4);
+    net->n_tensors = (int)n_tensors;
+    net->tensors = calloc(n_tensors ? n_tensors : 1, sizeof(kzo_tensor));
+    uint64_t *offsets = calloc(n_tensors ? n_tensors : 1, sizeof(uint64_t));
+    uint64_t *nbytes = calloc(n_tensors ? n_tensors : 1, sizeof(uint64_t));
+    for (uint32_t i = 0; i < n_tensors && !r.bad; i++) {
+        kzo_tensor *t = &net->tensors[i];
+        uint16_t nlen;
+        rd(&r, &nlen, 2);
+        if (nlen >= sizeof t->name) { r.bad = 1; break; }
+        rd(&r, t->name, nlen);
+        uint8_t dtype;
+        uint32_t ndim;
+        rd(&r, &dtype, 1);
+        rd(&r, &ndim, 4);
+        if (ndim > 6) { r.bad = 1; break; }
+        t->dtype = dtype;
+        t->ndim = (int)ndim;
+        t->count = 1;
+        for (uint32_t d = 0; d < ndim; d++) {
+            rd(&r, &t->dims[d], 8);
+            t->count *= t->dims[d];
+        }
+        rd(&r, &offsets[i], 8);
+        rd(&r, &nbytes[i], 8);
+    }
+    uint64_t data_len;
+    rd(&r, &data_len, 8);
+    if (r.bad || r.left < data_len) {
+        free(offsets);
+        free(nbytes);
+        kzo_free(net);
+        return fail("truncated KZMODEL1 container");
+    }
+    for (uint32_t i = 0; i < n_tensors; i++) {
+        kzo_tensor *t = &net->tensors[i];
+        uint64_t esz = t->dtype == 0 ? 4 : 8;
+        if (offsets[i] + nbytes[i] > data_len || nbytes[i] != t->count * esz) {
+            free(offsets);
+            free(nbytes);
+            kzo_free(net);
+            return fail("tensor table out of range");
+        }
+        t->data = r.p + offsets[i];
+    }
+    free(offsets);
+    free(nbytes);
+
+    net->h = (int)meta_int(net, "board_h", 0);
+    net->w = (int)meta_int(net, "board_w", 0);
+    net->n_scalar = (int)meta_int(net, "input_scalar_channels", 0);
+    net->n_bool = (int)meta_int(net, "input_bool_channels", 0);
+    net->c_in = net->n_scalar + net->n_bool;
+    net->depth = (int)meta_int(net, "tower_depth", -1);
+    net->channels = (int)meta_int(net, "tower_channels", 0);
+    net->final_affine = (int)meta_int(net, "tower_final_affine", 1);
+    net->sh_channels = (int)meta_int(net, "scalar_hidden_channels", 4);
+    net->sh_size = (int)meta_int(net, "scalar_hidden_size", 32);
+    net->policy_len = (int)meta_int(net, "policy_len", 0);
+    net->policy_conv_channels = (int)meta_int(net, "policy_conv_channels", 0);
+    net->policy_extra_moves = (int)meta_int(net, "policy_extra_moves", 0);
+    net->policy_query_channels = (int)meta_int(net, "policy_query_channels", 0);
+    net->dense_hidden_channels = (int)meta_int(net, "policy_dense_hidden_channels", 0);
+    net->dense_hidden_size = (int)meta_int(net, "policy_dense_hidden_size", 0);
+    const kzo_meta *eps = find_meta(net, "bn_eps");
+    net->bn_eps = eps ? (float)(eps->kind == 1 ? eps->f : (double)eps->i) : 1e-5f;
+    const kzo_meta *kind = find_meta(net, "policy_kind");
+    if (!kind || kind->kind != 2) {
+        kzo_free(net);
+        return fail("missing policy_kind");
+    }
+    if (!strcmp(kind->s, "ataxx_conv")) net->policy_kind = 0;
+    else if (!strcmp(kind->s, "conv")) net->policy_kind = 1;
+    else if (!strcmp(kind->s, "attention")) net->policy_kind = 2;
+    else if (!strcmp(kind->s, "dense")) net->policy_kind = 3;
+    else {
+        kzo_free(net);
+        return fail("unknown policy_kind");
+    }
+    if (net->h <= 0 || net->w <= 0 || net->c_in <= 0 || net->depth < 0 || net->channels <= 0 ||
+        net->policy_len <= 0) {
+        kzo_free(net);
+        return fail("bad architecture descriptor");
+    }
+    *out = net;
+    return 0;
+}
+
+/* out[0..6] = c_in, h, w, n_scalar, n_bool, policy_len, depth, channels */
+KZO_EXPORT int kzo_info(const kzo_net *net, int *out8) {
+    out8[0] = net->c_in; out8[1] = net->h; out8[2] = net->w; out8[3] = net->n_scalar;
+    out8[4] = net->n_bool; out8[5] = net->policy_len; out8[6] = net->depth; out8[7] = net->channels;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* BitBuffer — rust/kz-core/src/mapping/bit_buffer.rs:4-96                     */
+/* ------------------------------------------------------------------------- */
+
+/* bit_buffer.rs:19-36 `push`: bit i lives in byte i/8 at position i%8 (LSB first). */
+KZO_EXPORT int kzo_bits_push(uint8_t *storage, size_t capacity, size_t *len, int b) {
+    if (*len >= capacity) return fail("BitBuffer: not enough space left");
+    size_t index = *len / 8, bit = *len % 8;
+    *len += 1;
+    if (b) storage[index] |= (uint8_t)(1u << bit);
+    else storage[index] &= (uint8_t)~(1u << bit);
+    return 0;
+}
+
+/* bit_buffer.rs:38-57 `push_block`: 64 bits as 8 little-endian bytes, byte aligned only. */
+KZO_EXPORT int kzo_bits_push_block(uint8_t *storage, size_t capacity, size_t *len, uint64_t block) {
+    if (*len + 64 > capacity) return fail("BitBuffer: not enough space left for block");
+    if (*len % 8 != 0) return fail("BitBuffer: can only push aligned blocks");
+    size_t index = *len / 8;
+    for (int i = 0; i < 8; i++) storage[index + i] = (uint8_t)(block >> (8 * i));
+    *len += 64;
+    return 0;
+}
+
+/* bit_buffer.rs:80-90 `index`. */
+KZO_EXPORT int kzo_bits_get(const uint8_t *storage, size_t i) { return (storage[i / 8] >> (i % 8)) & 1; }
+
+/* bit_buffer.rs:8-14: storage bytes for a capacity. */
+KZO_EXPORT size_t kzo_bits_storage_len(size_t capacity) { return (capacity - 1) / 8 + 1; }
+
+/* ------------------------------------------------------------------------- */
+/* encode_input_full — rust/kz-core/src/mapping/mod.rs:40-63                   */
+/* scalar planes first (each scalar broadcast over H*W, :54-56), then the     */
+/* bool planes as 0.0/1.0 (:57-59); bool index = c*H*W + y*W + x.             */
+/* ------------------------------------------------------------------------- */
+KZO_EXPORT void kzo_encode_input_full(const uint8_t *bits, size_t bits_stride, const float *scalars, int batch,
+                                      int n_scalar, int n_bool, int h, int w, float *out) {
+    size_t hw = (size_t)h * w;
+    size_t bool_count = (size_t)n_bool * hw;
+    size_t full = (n_scalar + n_bool) * hw;
+    for (int b = 0; b < batch; b++) {
+        float *dst = out + (size_t)b * full;
+        for (int s = 0; s < n_scalar; s++)
+            for (size_t i = 0; i < hw; i++) *dst++ = scalars[(size_t)b * n_scalar + s];
+        const uint8_t *bb = bits + (size_t)b * bits_stride;
+        for (size_t i = 0; i < bool_count; i++) *dst++ = (float)kzo_bits_get(bb, i);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Network arithmetic — python/lib/model/post_act.py                           */
+/* ------------------------------------------------------------------------- */
+
+/* conv2d(): post_act.py:231-239 — nn.Conv2d, square odd kernel k, padding k/2, bias. x [cin,h,w] -> y [cout,h,w] */
+static void conv2d(const float *x, int cin, int h, int w, const float *wt, const float *bias, int cout, int k,
+                   float *y) {
+    int pad = k / 2;
+    for (int oc = 0; oc < cout; oc++) {
+        float *yo = y + (size_t)oc * h * w;
+        for (int i = 0; i < h * w; i++) yo[i] = bias[oc];
+        for (int ic = 0; ic < cin; ic++) {
+            const float *xi = x + (size_t)ic * h * w;
+            const float *wk = wt + ((size_t)oc * cin + ic) * k * k;
+            for (int ky = 0; ky < k; ky++) {
+                for (int kx = 0; kx < k; kx++) {
+                    float wv = wk[ky * k + kx];
+                    int dy = ky - pad, dx = kx - pad;
+                    int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? h - dy : h;
+                    int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? w - dx : w;
+                    for (int yy = y0; yy < y1; yy++) {
+                        const float *xr = xi + (size_t)(yy + dy) * w + dx;
+                        float *yr = yo + (size_t)yy * w;
+                        for (int xx = x0; xx < x1; xx++) yr[xx] += wv * xr[xx];
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* nn.BatchNorm2d in eval mode (network.eval(), python/lib/save_onnx.py:82): running stats, eps 1e-5. In place. */
+static void batchnorm_eval(float *x, int c, int hw, const float *weight, const float *bias, const float *mean,
+                           const float *var, float eps) {
+    for (int ch = 0; ch < c; ch++) {
+        float inv = 1.0f / sqrtf(var[ch] + eps);
+        float g = weight ? weight[ch] : 1.0f, b = bias ? bias[ch] : 0.0f;
+        float *p = x + (size_t)ch * hw;
+        for (int i = 0; i < hw; i++) p[i] = (p[i] - mean[ch]) * inv * g + b;
+    }
+}
+
+static void relu(float *x, size_t n) {
+    for (size_t i = 0; i < n; i++) x[i] = x[i] > 0.0f ? x[i] : 0.0f;
+}
+
+/* nn.Linear: y = W x + b, W [out, in] */
+static void linear(const float *x, int in, const float *wt, const float *bias, int out, float *y) {
+    for (int o = 0; o < out; o++) {
+        float acc = bias[o];
+        const float *wr = wt + (size_t)o * in;
+        for (int i = 0; i < in; i++) acc += wr[i] * x[i];
+        y[o] = acc;
+    }
+}
+
+typedef void (*kzo_trace_fn)(const char *name, const float *data, int count, int board, void *user);
+
+typedef struct {
+    const float *w, *b;
+} convp;
+
+typedef struct {
+    const float *weight, *bias, *mean, *var;
+} bnp;
+
+static int get_conv(const kzo_net *net, const char *prefix, int cout, int cin, int k, convp *c) {
+    char name[128];
+    snprintf(name, sizeof name, "%s.weight", prefix);
+    c->w = tensor_f32(net, name, (uint64_t)cout * cin * k * k);
+    snprintf(name, sizeof name, "%s.bias", prefix);
+    c->b = c->w ? tensor_f32(net, name, (uint64_t)cout) : NULL;
+    return (c->w && c->b) ? 0 : -1;
+}
+
+static int get_bn(const kzo_net *net, const char *prefix, int c, int affine, bnp *bn) {
+    char name[128];
+    bn->weight = bn->bias = NULL;
+    if (affine) {
+        snprintf(name, sizeof name, "%s.weight", prefix);
+        bn->weight = tensor_f32(net, name, (uint64_t)c);
+        snprintf(name, sizeof name, "%s.bias", prefix);
+        bn->bias = tensor_f32(net, name, (uint64_t)c);
+        if (!bn->weight || !bn->bias) return -1;
+    }
+    snprintf(name, sizeof name, "%s.running_mean", prefix);
+    bn->mean = tensor_f32(net, name, (uint64_t)c);
+    snprintf(name, sizeof name, "%s.running_var", prefix);
+    bn->var = tensor_f32(net, name, (uint64_t)c);
+    return (bn->mean && bn->var) ? 0 : -1;
+}
+
+/* One board through PredictionHeads.forward (post_act.py:194-198). Returns 0 or -1. */
+static int forward_board(const kzo_net *net, const float *input, float *scalars_out, float *policy_out, int board,
+                         kzo_trace_fn trace, void *user) {
+    const int h = net->h, w = net->w, hw = h * w, C = net->channels;
+    char name[128];
+    int rc = -1;
+    float *x = malloc(sizeof(float) * (size_t)C * hw);
+    float *t0 = malloc(sizeof(float) * (size_t)C * hw);
+    float *t1 = malloc(sizeof(float) * (size_t)C * hw);
+    float *head = NULL;
+
+    /* ResTower (post_act.py:201-211): stem conv with no BN and no ReLU (:205) */
+    convp stem;
+    if (get_conv(net, "common.tower.0", C, net->c_in, 3, &stem)) goto done;
+    conv2d(input, net->c_in, h, w, stem.w, stem.b, C, 3, x);
+    if (trace) trace("tower.0", x, C * hw, board, user);
+
+    /* ResBlock (post_act.py:214-228): input + relu(bn(conv(relu(bn(conv(input)))))) */
+    for (int i = 1; i <= net->depth; i++) {
+        convp ca, cb;
+        bnp ba, bb;
+        snprintf(name, sizeof name, "common.tower.%d.seq.0", i);
+        if (get_conv(net, name, C, C, 3, &ca)) goto done;
+        snprintf(name, sizeof name, "common.tower.%d.seq.1", i);
+        if (get_bn(net, name, C, 1, &ba)) goto done;
+        snprintf(name, sizeof name, "common.tower.%d.seq.3", i);
+        if (get_conv(net, name, C, C, 3, &cb)) goto done;
+        snprintf(name, sizeof name, "common.tower.%d.seq.4", i);
+        if (get_bn(net, name, C, 1, &bb)) goto done;
+
+        conv2d(x, C, h, w, ca.w, ca.b, C, 3, t0);
+        batchnorm_eval(t0, C, hw, ba.weight, ba.bias, ba.mean, ba.var, net->bn_eps);
+        relu(t0, (size_t)C * hw);
+        if (trace) {
+            snprintf(name, sizeof name, "tower.%d.mid", i);
+            trace(name, t0, C * hw, board, user);
+        }
+        conv2d(t0, C, h, w, cb.w, cb.b, C, 3, t1);
+        batchnorm_eval(t1, C, hw, bb.weight, bb.bias, bb.mean, bb.var, net->bn_eps);
+        relu(t1, (size_t)C * hw);
+        for (int j = 0; j < C * hw; j++) x[j] = x[j] + t1[j]; /* residual AFTER the ReLU (:227-228) */
+        if (trace) {
+            snprintf(name, sizeof name, "tower.%d", i);
+            trace(name, x, C * hw, board, user);
+        }
+    }
+
+    /* final BatchNorm2d(channels, affine=final_affine) (post_act.py:207) */
+    {
+        bnp bf;
+        snprintf(name, sizeof name, "common.tower.%d", net->depth + 1);
+        if (get_bn(net, name, C, net->final_affine, &bf)) goto done;
+        batchnorm_eval(x, C, hw, bf.weight, bf.bias, bf.mean, bf.var, net->bn_eps);
+        if (trace) {
+            snprintf(name, sizeof name, "tower.%d", net->depth + 1);
+            trace(name, x, C * hw, board, user);
+        }
+    }
+
+    /* ScalarHead (post_act.py:10-23): conv1x1 -> ReLU -> Flatten (channel-major) -> Linear -> ReLU -> Linear(5) */
+    {
+        const int hc = net->sh_channels, hs = net->sh_size;
+        convp c0;
+        if (get_conv(net, "scalar_head.seq.0", hc, C, 1, &c0)) goto done;
+        const float *w3 = tensor_f32(net, "scalar_head.seq.3.weight", (uint64_t)hs * hc * hw);
+        const float *b3 = tensor_f32(net, "scalar_head.seq.3.bias", (uint64_t)hs);
+        const float *w5 = tensor_f32(net, "scalar_head.seq.5.weight", (uint64_t)5 * hs);
+        const float *b5 = tensor_f32(net, "scalar_head.seq.5.bias", 5);
+        if (!w3 || !b3 || !w5 || !b5) goto done;
+        float *a = malloc(sizeof(float) * (size_t)hc * hw);
+        float *hid = malloc(sizeof(float) * (size_t)hs);
+        conv2d(x, C, h, w, c0.w, c0.b, hc, 1, a);
+        relu(a, (size_t)hc * hw);
+        if (trace) trace("scalar_head.conv_relu", a, hc * hw, board, user);
+        linear(a, hc * hw, w3, b3, hs, hid);
+        relu(hid, (size_t)hs);
+        if (trace) trace("scalar_head.fc0_relu", hid, hs, board, user);
+        linear(hid, hs, w5, b5, 5, scalars_out);
+        free(a);
+        free(hid);
+    }
+
+    /* policy heads */
+    if (net->policy_kind == 0) {
+        /* AtaxxConvPolicyHead (post_act.py:91-112): conv1x1 C->C, ReLU, conv1x1 C->17; flatten(1) ‖ one zero column */
+        const int pc = net->policy_conv_channels;
+        convp c0, c2;
+        if (pc * hw + 1 != net->policy_len) { fail("ataxx head: policy_len mismatch"); goto done; }
+        if (get_conv(net, "policy_head.seq.0", C, C, 1, &c0)) goto done;
+        if (get_conv(net, "policy_head.seq.2", pc, C, 1, &c2)) goto done;
+        conv2d(x, C, h, w, c0.w, c0.b, C, 1, t0);
+        relu(t0, (size_t)C * hw);
+        conv2d(t0, C, h, w, c2.w, c2.b, pc, 1, policy_out);
+        policy_out[pc * hw] = 0.0f;
+    } else if (net->policy_kind == 1) {
+        /* ConvPolicyHead (post_act.py:54-88), non-chess branch: concat([seq(common).flatten(1), seq_extra(common)]) */
+        const int pc = net->policy_conv_channels, extra = net->policy_extra_moves;
+        convp c0, c2;
+        if (pc * hw + extra != net->policy_len) { fail("conv head: policy_len mismatch"); goto done; }
+        if (get_conv(net, "policy_head.seq.0", C, C, 1, &c0)) goto done;
+        if (get_conv(net, "policy_head.seq.2", pc, C, 1, &c2)) goto done;
+        conv2d(x, C, h, w, c0.w, c0.b, C, 1, t0);
+        relu(t0, (size_t)C * hw);
+        conv2d(t0, C, h, w, c2.w, c2.b, pc, 1, policy_out);
+        if (extra != 0) {
+            convp ce;
+            if (get_conv(net, "policy_head.seq_extra.0", 1, C, 1, &ce)) goto done;
+            const float *we = tensor_f32(net, "policy_head.seq_extra.2.weight", (uint64_t)extra * hw);
+            const float *be = tensor_f32(net, "policy_head.seq_extra.2.bias", (uint64_t)extra);
+            if (!we || !be) goto done;
+            conv2d(x, C, h, w, ce.w, ce.b, 1, 1, t1);
+            linear(t1, hw, we, be, extra, policy_out + pc * hw);
+        }
+    } else if (net->policy_kind == 2) {
+        /* AttentionPolicyHead (post_act.py:115-141) */
+        const int Q = net->policy_query_channels;
+        if (h != 8 || w != 8) { fail("attention head needs an 8x8 board"); goto done; }
+        convp cbulk, cunder;
+        if (get_conv(net, "policy_head.conv_bulk", 2 * Q, C, 1, &cbulk)) goto done;
+        if (get_conv(net, "policy_head.conv_under", 3 * Q, C, 1, &cunder)) goto done;
+        const kzo_tensor *tab = find_tensor(net, "policy_head.FLAT_TO_ATT");
+        if (!tab || tab->dtype != 1 || (int)tab->count != net->policy_len) { fail("missing FLAT_TO_ATT"); goto done; }
+        const int64_t *flat_to_att = tab->data;
+        head = malloc(sizeof(float) * ((size_t)2 * Q * 64 + (size_t)3 * Q * 8 + (size_t)C * 8 + (size_t)Q * 88 + 64 * 88));
+        float *bulk = head;                 /* [2Q, 8, 8] */
+        float *under = bulk + 2 * Q * 64;   /* [3Q, 1, 8] */
+        float *row7 = under + 3 * Q * 8;    /* common[:, :, 7, None, :] -> [C, 1, 8] */
+        float *q_to = row7 + C * 8;         /* [Q, 88] */
+        float *att = q_to + Q * 88;         /* [64, 88] */
+        conv2d(x, C, 8, 8, cbulk.w, cbulk.b, 2 * Q, 1, bulk);
+        for (int c = 0; c < C; c++)
+            for (int xx = 0; xx < 8; xx++) row7[c * 8 + xx] = x[(size_t)c * 64 + 7 * 8 + xx];
+        conv2d(row7, C, 1, 8, cunder.w, cunder.b, 3 * Q, 1, under);
+        /* q_from = bulk[:, :Q].flatten(2) [Q,64]; q_to = cat(bulk[:, Q:].flatten(2) [Q,64], under.reshape(Q, 24)) */
+        const float *q_from = bulk;
+        for (int q = 0; q < Q; q++) {
+            for (int i = 0; i < 64; i++) q_to[q * 88 + i] = bulk[(size_t)(Q + q) * 64 + i];
+            /* under is [3Q,1,8] contiguous; reshape(-1, Q, 24): row q takes flat elements q*24 .. q*24+23 */
+            for (int i = 0; i < 24; i++) q_to[q * 88 + 64 + i] = under[(size_t)q * 24 + i];
+        }
+        /* policy = bmm(q_from^T [64,Q], q_to [Q,88]) / sqrt(Q) */
+        float scale = (float)pow((double)Q, 0.5);
+        for (int i = 0; i < 64; i++)
+            for (int j = 0; j < 88; j++) {
+                float acc = 0.0f;
+                for (int q = 0; q < Q; q++) acc += q_from[q * 64 + i] * q_to[q * 88 + j];
+                att[i * 88 + j] = acc / scale;
+            }
+        for (int i = 0; i < net->policy_len; i++) policy_out[i] = att[flat_to_att[i]];
+    } else {
+        /* DensePolicyHead (post_act.py:26-51): [conv1x1 + ReLU] -> Flatten -> [Linear + ReLU] -> Linear(policy_size) */
+        const int hc = net->dense_hidden_channels, hs = net->dense_hidden_size;
+        const float *cur = x;
+        int cur_c = C, idx = 0;
+        if (hc) {
+            convp c0;
+            if (get_conv(net, "policy_head.seq.0", hc, C, 1, &c0)) goto done;
+            conv2d(x, C, h, w, c0.w, c0.b, hc, 1, t0);
+            relu(t0, (size_t)hc * hw);
+            cur = t0;
+            cur_c = hc;
+            idx = 2; /* conv, relu */
+        }
+        idx += 1; /* flatten */
+        int size = cur_c * hw;
+        if (hs) {
+            snprintf(name, sizeof name, "policy_head.seq.%d.weight", idx);
+            const float *w0 = tensor_f32(net, name, (uint64_t)hs * size);
+            snprintf(name, sizeof name, "policy_head.seq.%d.bias", idx);
+            const float *b0 = tensor_f32(net, name, (uint64_t)hs);
+            if (!w0 || !b0) goto done;
+            linear(cur, size, w0, b0, hs, t1);
+            relu(t1, (size_t)hs);
+            cur = t1;
+            size = hs;
+            idx += 2;
+        }
+        snprintf(name, sizeof name, "policy_head.seq.%d.weight", idx);
+        const float *w1 = tensor_f32(net, name, (uint64_t)net->policy_len * size);
+        snprintf(name, sizeof name, "policy_head.seq.%d.bias", idx);
+        const float *b1 = tensor_f32(net, name, (uint64_t)net->policy_len);
+        if (!w1 || !b1) goto done;
+        linear(cur, size, w1, b1, net->policy_len, policy_out);
+    }
+    rc = 0;
+done:
+    free(x);
+    free(t0);
+    free(t1);
+    free(head);
+    return rc;
+}
+
+/*
+ * The CPU path: restates CPUNetwork::evaluate_batch_exec's call
+ * cpu_eval_graph_exec(&graph, batch, &[input], keep_all) (rust/kz-core/src/network/cpu.rs:33-51)
+ * for the PredictionHeads graph.  input NCHW f32 [batch, c_in, h, w]; scalars [batch,5]; policy [batch,P].
+ * threads <= 1: serial; otherwise OpenMP over boards (the boards are independent in eval mode).
+ */
+KZO_EXPORT int kzo_forward(const kzo_net *net, const float *input, int batch, float *scalars, float *policy,
+                           int threads) {
+    size_t in_stride = (size_t)net->c_in * net->h * net->w;
+    int bad = 0;
+#ifdef _OPENMP
+    int nt = threads > 1 ? threads : 1;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+#endif
+    for (int b = 0; b < batch; b++) {
+        if (forward_board(net, input + b * in_stride, scalars + (size_t)b * 5, policy + (size_t)b * net->policy_len, b,
+                          NULL, NULL))
+            bad = 1;
+    }
+    (void)threads;
+    return bad ? -1 : 0;
+}
+
+KZO_EXPORT int kzo_forward_trace(const kzo_net *net, const float *input, int batch, float *scalars, float *policy,
+                                 kzo_trace_fn trace, void *user) {
+    size_t in_stride = (size_t)net->c_in * net->h * net->w;
+    for (int b = 0; b < batch; b++)
+        if (forward_board(net, input + b * in_stride, scalars + (size_t)b * 5, policy + (size_t)b * net->policy_len, b,
+                          trace, user))
+            return -1;
+    return 0;
+}
+
+KZO_EXPORT int kzo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* decode_output — rust/kz-core/src/network/common.rs:16-114                    */
+/* ------------------------------------------------------------------------- */
+
+/* softmax_in_place (common.rs:102-114). Returns -1 where the reference asserts (sum must be > 0). */
+KZO_EXPORT int kzo_softmax_in_place(float *v, int n) {
+    float max = -INFINITY;
+    for (int i = 0; i < n; i++) max = v[i] > max ? v[i] : max; /* fold(NEG_INFINITY, max) */
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++) {
+        v[i] = expf(v[i] - max);
+        sum += v[i];
+    }
+    if (!(sum > 0.0f)) return fail("Softmax input sum must be strictly positive");
+    for (int i = 0; i < n; i++) v[i] /= sum;
+    return 0;
+}
+
+/*
+ * decode_output for the 2-output form (common.rs:31-42, :52-98): per board value = tanh(s0) (:60),
+ * wdl = softmax(s1..s3) (:64-69), moves_left = s4 (:61); policy = softmax over the logits gathered at
+ * move_to_index(mv) for each available move, in available_moves() order (:77-86).  The caller supplies the
+ * per-board index lists (CSR: move_offsets[batch+1], move_indices) because move generation lives in the ext
+ * board-game crate.  A board with no available moves yields an empty policy (`map_or(vec![], ..)`, :77).
+ * values_out [batch,5] = value, win, draw, loss, moves_left; policy_out parallel to move_indices.
+ */
+KZO_EXPORT int kzo_decode_output(const float *scalars, const float *policy_logits, int batch, int policy_len,
+                                 const int64_t *move_offsets, const int32_t *move_indices, float *values_out,
+                                 float *policy_out) {
+    for (int b = 0; b < batch; b++) {
+        const float *s = scalars + (size_t)b * 5;
+        float wdl[3] = {s[1], s[2], s[3]};
+        if (kzo_softmax_in_place(wdl, 3)) return -1;
+        float *vo = values_out + (size_t)b * 5;
+        vo[0] = tanhf(s[0]);
+        vo[1] = wdl[0];
+        vo[2] = wdl[1];
+        vo[3] = wdl[2];
+        vo[4] = s[4];
+        int64_t lo = move_offsets[b], hi = move_offsets[b + 1];
+        if (hi == lo) continue;
+        for (int64_t i = lo; i < hi; i++) {
+            int32_t idx = move_indices[i];
+            if (idx < 0 || idx >= policy_len) return fail("policy index out of range");
+            policy_out[i] = policy_logits[(size_t)b * policy_len + idx];
+        }
+        if (kzo_softmax_in_place(policy_out + lo, (int)(hi - lo))) return -1;
+    }
+    return 0;
+}

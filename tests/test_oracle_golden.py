@@ -1,0 +1,117 @@
+"""Pins the CPU oracle (oracle/kz_oracle.c) to the golden vectors generated from the reference's own PyTorch
+network definition (oracle/gen_golden.py) and to the reference's in-tree known answers."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from kzero_amd.model_file import read_model
+from tests import oracle_lib as O
+
+# f32 direct convolution vs PyTorch/oneDNN: different summation order only
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", O.GOLDEN_NETS)
+@pytest.mark.parametrize("kind", ["planes", "randn"])
+def test_forward_matches_reference_pytorch(name, kind):
+    net = O.OracleNet(O.load_blob(name))
+    x, scalars_ref, policy_ref = O.read_io(name, kind, net.c_in, net.h, net.w, net.policy_len)
+    scalars, policy = net.forward(x)
+    np.testing.assert_allclose(scalars, scalars_ref, **TOL)
+    np.testing.assert_allclose(policy, policy_ref, **TOL)
+
+
+def test_forward_threads_identical():
+    net = O.OracleNet(O.load_blob("ataxx7_2x16"))
+    x, _, _ = O.read_io("ataxx7_2x16", "planes", net.c_in, net.h, net.w, net.policy_len)
+    s1, p1 = net.forward(x, threads=1)
+    s4, p4 = net.forward(x, threads=4)
+    assert np.array_equal(s1, s4) and np.array_equal(p1, p4)
+
+
+def test_per_layer_activations():
+    name = "ataxx7_2x16"
+    net = O.OracleNet(O.load_blob(name))
+    x, _, _ = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    _, _, acts = net.forward_trace(x)
+    _, ref = read_model(open(os.path.join(O.GOLDEN, f"{name}.layers.kzm"), "rb").read())
+    assert set(ref) == set(acts)
+    for k, v in ref.items():
+        np.testing.assert_allclose(acts[k].reshape(v.shape), v, err_msg=k, **TOL)
+
+
+@pytest.mark.parametrize("name", O.GOLDEN_NETS)
+def test_encode_input_full_matches_planes(name):
+    """bits+scalars -> dense planes: scalar planes first, then bools (mapping/mod.rs:40-63); the packed fixture is
+    np.packbits(bitorder='little'), the inverse of the reference reader (python/lib/data/position.py:95-97)."""
+    net = O.OracleNet(O.load_blob(name))
+    x, _, _ = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    bits, scalars = O.read_packed(name, net.n_bool, net.n_scalar, net.h, net.w)
+    dense = O.encode_input_full(bits, scalars, net.n_scalar, net.n_bool, net.h, net.w)
+    assert np.array_equal(dense, x)
+
+
+def _bitbuffer(capacity):
+    n = O.lib().kzo_bits_storage_len(capacity)
+    return np.zeros(n, np.uint8), C.c_size_t(0)
+
+
+def test_bitbuffer_known_answers():
+    """rust/kz-core/src/mapping/bit_buffer.rs:112-164"""
+    L = O.lib()
+    # short (:117-124)
+    buf, n = _bitbuffer(8)
+    for b in (1, 0, 1):
+        assert L.kzo_bits_push(buf.ctypes.data, 8, C.byref(n), b) == 0
+    assert buf.tolist() == [0b101]
+    # edge_length (:127-135)
+    buf, n = _bitbuffer(8)
+    for _ in range(8):
+        L.kzo_bits_push(buf.ctypes.data, 8, C.byref(n), 1)
+    assert buf.tolist() == [0xFF]
+    buf, n = _bitbuffer(9)
+    for _ in range(9):
+        L.kzo_bits_push(buf.ctypes.data, 9, C.byref(n), 1)
+    assert buf.tolist() == [0xFF, 0b1]
+    # longer (:138-144)
+    buf, n = _bitbuffer(16)
+    for i in range(16):
+        L.kzo_bits_push(buf.ctypes.data, 16, C.byref(n), int(i in (1, 5, 12)))
+    assert buf.tolist() == [0b0010_0010, 0b1_0000]
+    # overflow (:147-153)
+    buf, n = _bitbuffer(32)
+    for _ in range(32):
+        assert L.kzo_bits_push(buf.ctypes.data, 32, C.byref(n), 0) == 0
+    assert L.kzo_bits_push(buf.ctypes.data, 32, C.byref(n), 0) != 0
+    # block (:156-163)
+    buf, n = _bitbuffer(64)
+    assert L.kzo_bits_push_block(buf.ctypes.data, 64, C.byref(n), 0b1_0000_0001) == 0
+    assert buf.tolist() == [1, 1, 0, 0, 0, 0, 0, 0] and n.value == 64
+    # unaligned block is rejected (:45-51)
+    buf, n = _bitbuffer(128)
+    L.kzo_bits_push(buf.ctypes.data, 128, C.byref(n), 1)
+    assert L.kzo_bits_push_block(buf.ctypes.data, 128, C.byref(n), 1) != 0
+
+
+def test_decode_output_known_answers():
+    """tanh / softmax-of-gathered-logits (network/common.rs:60-86) vs torch-computed answers."""
+    meta, t = read_model(open(os.path.join(O.GOLDEN, "decode_kat.kzm"), "rb").read())
+    b = meta["batch"]
+    moves = [t[f"indices.{i}"].astype(np.int32) for i in range(b)]
+    values, pols = O.decode_output(t["scalars"], t["logits"], moves)
+    np.testing.assert_allclose(values[:, 0], t["value"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(values[:, 1:4], t["wdl"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(values[:, 4], t["moves_left"])
+    for i in range(b):
+        assert len(pols[i]) == len(moves[i])
+        np.testing.assert_allclose(pols[i], t[f"policy.{i}"], rtol=1e-5, atol=1e-7)
+        if len(moves[i]):
+            assert abs(pols[i].sum() - 1) < 1e-5
+
+
+def test_softmax_rejects_non_positive_sum():
+    """common.rs:110: assert!(sum > 0.0) — NaN logits trip it."""
+    v = np.array([np.nan, 1.0], np.float32)
+    assert O.lib().kzo_softmax_in_place(v.ctypes.data, 2) != 0
