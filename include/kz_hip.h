@@ -1,0 +1,129 @@
+/*
+ * kz_hip.h — C ABI of the MI355X-native self-play NN executor for kZero.
+ *
+ * This is the drop-in boundary: the entry points a Rust `HipNetwork<B, M>: Network<B>` binds over FFI in place
+ * of the kn-cuda-eval `CudaExecutor` used by `CudaNetwork` (rust/kz-core/src/network/cudnn.rs:18-88).  Plain
+ * pointers and sizes only.  Every function returns 0 on success and non-zero on error; `kz_last_error()` gives
+ * the message (the reference panics on every error: `unwrap()` cudnn.rs:70,78, `assert!` :58 — the Rust shim
+ * turns a non-zero return into a panic to keep that behaviour).
+ *
+ * Threading contract (mirrors the reference): `kz_model` is immutable and may be shared by any number of threads
+ * and devices (it is the `Arc<Graph>` sent to every executor, rust/kz-selfplay/src/server/commander.rs:36-45).
+ * `kz_engine` is NOT thread-safe: one per executor thread (`evaluate_batch(&mut self)`, kz-core/src/network/mod.rs:56),
+ * created on that thread like `CudaNetwork::new` in `handle_new_graph` (kz-selfplay/src/server/executor.rs:320-342).
+ * Engines of one model on one device share a single uploaded copy of the weights.
+ */
+#ifndef KZ_HIP_H
+#define KZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZ_DTYPE_F32 0 /* f32 storage, exact-f32 MFMA: the <=1e-4 parity path (the reference is f32 only, cudnn.rs:73) */
+#define KZ_DTYPE_F16 1 /* f16 storage, f32 accumulate: the throughput path */
+
+#define KZ_POLICY_ATAXX_CONV 0 /* AtaxxConvPolicyHead, python/lib/model/post_act.py:91-112 */
+#define KZ_POLICY_CONV 1       /* ConvPolicyHead,      post_act.py:54-88 */
+#define KZ_POLICY_ATTENTION 2  /* AttentionPolicyHead, post_act.py:115-141 */
+#define KZ_POLICY_DENSE 3      /* DensePolicyHead,     post_act.py:26-51 */
+
+typedef struct kz_model kz_model;
+typedef struct kz_engine kz_engine;
+
+/* What `check_graph_shapes` compares against the mapper (rust/kz-core/src/network/common.rs:165-198):
+ * input [BATCH, input_channels, board_h, board_w] with input_channels = scalar + bool planes (scalars first,
+ * kz-core/src/mapping/mod.rs:40-63); outputs [BATCH, 5] and [BATCH, policy_len]. */
+typedef struct kz_model_info {
+    int32_t input_channels;
+    int32_t board_h;
+    int32_t board_w;
+    int32_t input_scalar_channels;
+    int32_t input_bool_channels;
+    int32_t policy_len;
+    int32_t tower_depth;
+    int32_t tower_channels;
+    int32_t policy_kind;
+    int32_t bits_bytes;     /* ceil(input_bool_channels * h * w / 8): BitBuffer storage per board (bit_buffer.rs:8-14) */
+    int64_t param_count;
+    double flops_per_eval;  /* direct-convolution FLOPs (2 per MAC), heads included: the roofline numerator */
+} kz_model_info;
+
+/* Thread-local message of the last failing call on this thread. */
+const char *kz_last_error(void);
+
+/* Replaces CudaDevice::all() (rust/kz-selfplay/src/server/server.rs:48-52). */
+int kz_device_count(int *count);
+
+/* ---- model: replaces load_graph_from_onnx_path + optimize_graph (server_alphazero.rs:126-128) ----
+ * Accepts the KZMODEL1 container (kzero_amd/model_file.py); Conv+BN folding happens here. */
+int kz_model_load(const char *path, kz_model **out);
+int kz_model_load_memory(const void *blob, size_t len, kz_model **out);
+void kz_model_free(kz_model *model);
+int kz_model_get_info(const kz_model *model, kz_model_info *out);
+
+/* ---- engine: replaces CudaNetwork::new(mapper, &graph, max_batch_size, device) (cudnn.rs:29-43) ---- */
+int kz_engine_create(const kz_model *model, int device, int max_batch, int dtype, kz_engine **out);
+void kz_engine_destroy(kz_engine *engine);
+int kz_engine_max_batch(const kz_engine *engine); /* Network::max_batch_size, network/mod.rs:53 */
+
+/* ---- synchronous evaluation: replaces CudaNetwork::evaluate_batch's encode + executor.evaluate (cudnn.rs:55-82) ----
+ * Only `batch` rows are computed and written (the reference NaN-pads to max_batch and discards, cudnn.rs:65,75-82).
+ * batch must be in [0, max_batch]; batch == 0 is a no-op.  Caller owns all buffers; nothing is retained. */
+
+/* Bit-compatible with CudaExecutor::evaluate: dense f32 NCHW [batch, C, H, W] as built by encode_input_full. */
+int kz_engine_eval_dense(kz_engine *engine, const float *input_nchw, int batch, float *scalars_out /* [batch,5] */,
+                         float *policy_out /* [batch,policy_len] */);
+
+/* Packed input, the GPU does encode_input_full: `bits` = BitBuffer storage per board (LSB-first,
+ * bit_buffer.rs:73-75), bits_stride bytes apart; `scalars_in` [batch, input_scalar_channels] as appended by
+ * InputMapper::encode_input (mapping/mod.rs:37). */
+int kz_engine_eval_packed(kz_engine *engine, const uint8_t *bits, size_t bits_stride, const float *scalars_in,
+                          int batch, float *scalars_out, float *policy_out);
+
+/* ---- asynchronous pair: >= 2 batches in flight per executor thread (replaces gpu_threads_per_device blocking
+ * threads, rust/Readme.md:51).  slot in [0, KZ_ENGINE_SLOTS).  Inputs are copied to pinned staging before submit
+ * returns; outputs are written to the caller's buffers by kz_engine_wait. */
+#define KZ_ENGINE_SLOTS 2
+int kz_engine_submit_packed(kz_engine *engine, int slot, const uint8_t *bits, size_t bits_stride,
+                            const float *scalars_in, int batch);
+int kz_engine_wait(kz_engine *engine, int slot, float *scalars_out, float *policy_out);
+
+/* ---- device-resident evaluation (inputs and outputs already in HBM; used by bench.py and the parity tests) ----
+ * Pointers are device pointers on the engine's device (kz_device_malloc).  Enqueues on the engine's stream and
+ * returns; kz_engine_synchronize waits. */
+int kz_engine_enqueue_packed_device(kz_engine *engine, const void *d_bits, size_t bits_stride,
+                                    const void *d_scalars_in, int batch, void *d_scalars_out, void *d_policy_out);
+int kz_engine_enqueue_dense_device(kz_engine *engine, const void *d_input_nchw, int batch, void *d_scalars_out,
+                                   void *d_policy_out);
+int kz_engine_synchronize(kz_engine *engine);
+
+/* ---- device memory helpers (plain hipMalloc/hipMemcpy on `device`) ---- */
+int kz_device_malloc(int device, size_t bytes, void **out);
+int kz_device_free(int device, void *ptr);
+int kz_memcpy_h2d(int device, void *dst, const void *src, size_t bytes);
+int kz_memcpy_d2h(int device, void *dst, const void *src, size_t bytes);
+int kz_device_synchronize(int device);
+
+/* ---- measurement ----
+ * With profiling on, every kernel launch of the forward pass is bracketed by HIP events on the engine's stream.
+ * kz_engine_kernel_time sums the elapsed time of the launches whose kernel name starts with `prefix` since
+ * profiling was last enabled (it synchronizes the stream first). */
+int kz_engine_set_profiling(kz_engine *engine, int enable);
+int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_ms, int64_t *launches);
+/* Name of the path the engine chose for the tower ("tower_resident_f16", "conv_igemm_f16", "conv_igemm_f32"). */
+const char *kz_engine_tower_path(const kz_engine *engine);
+
+/* ---- debugging / parity: copy an intermediate activation of the last evaluation to the host as f32 NCHW.
+ * name: "tower.<i>" as in python/lib/model/post_act.py's nn.Sequential indices (0 = stem, 1..d = blocks,
+ * d+1 = final BN).  Only available when the engine was created with the generic per-layer path
+ * (set KZ_FORCE_GENERIC=1 in the environment before kz_engine_create). */
+int kz_engine_read_activation(kz_engine *engine, const char *name, int batch, float *out_nchw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KZ_HIP_H */

@@ -1,0 +1,841 @@
+// kz_engine.hip — the executor behind the C ABI of include/kz_hip.h.
+//
+// One kz_engine = one `CudaNetwork` of the reference (rust/kz-core/src/network/cudnn.rs:18-88): a private HIP stream,
+// private activation buffers sized for max_batch, pinned staging for the host-pointer entry points, and a shared,
+// reference-counted copy of the device weights per (model, device, dtype).
+// Forward schedule per batch: encode (F0) -> tower (one board-resident launch, or stem + 2*depth fused conv launches
+// on the generic path) -> ScalarHead -> policy head.  Only `batch` rows are ever touched.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/kz_hip.h"
+#include "kz_kernels.hpp"
+#include "kz_model.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                        std::to_string(__LINE__) + ")");                                               \
+    } while (0)
+
+using kz::Conv;
+using kz::Linear;
+using kz::Model;
+using kz::round_up;
+
+uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;  // round-to-nearest-even, same conversion the device uses
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device weights, shared by all engines of one (model, device, dtype)
+// ------------------------------------------------------------------------------------------------
+struct DevConv {  // packed for kz_conv_igemm: [k*k][cout_p][cin_p] in T, bias f32 [cout_p]
+    void *w = nullptr;
+    float *b = nullptr;
+    int cin_p = 0, cout_p = 0, cout = 0, k = 1;
+};
+
+struct DeviceWeights {
+    int device = 0, dtype = 0;
+    std::vector<void *> allocs;
+
+    std::vector<DevConv> tower;  // generic path
+    float *post_scale = nullptr, *post_shift = nullptr;
+
+    // resident tower
+    bool resident = false;
+    void *res_w_stem = nullptr, *res_w_tower = nullptr;
+    float *res_bias = nullptr;
+
+    // scalar head
+    float *sh_w0 = nullptr, *sh_b0 = nullptr, *sh_w1 = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
+    // policy
+    DevConv p_conv0;                                   // conv / ataxx_conv / dense hidden conv
+    float *p_w1 = nullptr, *p_b1 = nullptr;            // last 1x1 conv of the conv heads
+    float *pe_wc = nullptr, *pe_bc = nullptr, *pe_wl = nullptr, *pe_bl = nullptr;  // seq_extra
+    DevConv p_bulk, p_under;
+    int32_t *flat_to_att = nullptr;
+    DevConv p_fc0, p_fc1;
+
+    ~DeviceWeights() {
+        (void)hipSetDevice(device);
+        for (void *p : allocs) (void)hipFree(p);
+    }
+
+    int upload(const void *src, size_t bytes, void **dst) {
+        HIP_TRY(hipMalloc(dst, bytes ? bytes : 16));
+        allocs.push_back(*dst);
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    }
+    int upload_f32(const std::vector<float> &v, float **dst) { return upload(v.data(), v.size() * 4, (void **)dst); }
+
+    // values [rows][cols] f32 -> T [rows_p][cols_p], zero padded
+    int upload_matrix(const std::vector<float> &v, int rows, int cols, int rows_p, int cols_p, void **dst) {
+        if (dtype == KZ_DTYPE_F32) {
+            std::vector<float> p((size_t)rows_p * cols_p, 0.0f);
+            for (int r = 0; r < rows; r++)
+                for (int c = 0; c < cols; c++) p[(size_t)r * cols_p + c] = v[(size_t)r * cols + c];
+            return upload(p.data(), p.size() * 4, dst);
+        }
+        std::vector<uint16_t> p((size_t)rows_p * cols_p, 0);
+        for (int r = 0; r < rows; r++)
+            for (int c = 0; c < cols; c++) p[(size_t)r * cols_p + c] = f32_to_f16_bits(v[(size_t)r * cols + c]);
+        return upload(p.data(), p.size() * 2, dst);
+    }
+
+    // OIHW conv -> [tap][cout_p][cin_p]; tap = ky*k + kx
+    int upload_conv(const Conv &cv, DevConv &d) {
+        d.k = cv.k;
+        d.cout = cv.cout;
+        d.cin_p = round_up(cv.cin, 32);
+        d.cout_p = round_up(cv.cout, 32);
+        const int taps = cv.k * cv.k;
+        std::vector<float> flat((size_t)taps * d.cout_p * d.cin_p, 0.0f);
+        for (int o = 0; o < cv.cout; o++)
+            for (int i = 0; i < cv.cin; i++)
+                for (int t = 0; t < taps; t++)
+                    flat[((size_t)t * d.cout_p + o) * d.cin_p + i] = cv.w[((size_t)o * cv.cin + i) * taps + t];
+        if (upload_matrix(flat, taps * d.cout_p, d.cin_p, taps * d.cout_p, d.cin_p, &d.w)) return 1;
+        std::vector<float> b(d.cout_p, 0.0f);
+        for (int o = 0; o < cv.cout; o++) b[o] = cv.b[o];
+        return upload_f32(b, &d.b);
+    }
+
+    // nn.Linear over a channel-major flatten of [ch][hw] (index c*hw + p) applied to NHWC rows [hw][ch_p]:
+    // re-index the input dimension to p*ch_p + c and run it as a 1x1 "convolution" over one row per board.
+    int upload_flat_linear(const Linear &l, int ch, int hw, int ch_p, DevConv &d) {
+        d.k = 1;
+        d.cout = l.out;
+        d.cout_p = round_up(l.out, 32);
+        d.cin_p = hw * ch_p;
+        std::vector<float> flat((size_t)d.cout_p * d.cin_p, 0.0f);
+        for (int o = 0; o < l.out; o++)
+            for (int c = 0; c < ch; c++)
+                for (int p = 0; p < hw; p++)
+                    flat[(size_t)o * d.cin_p + (size_t)p * ch_p + c] = l.w[(size_t)o * l.in + (size_t)c * hw + p];
+        if (upload_matrix(flat, d.cout_p, d.cin_p, d.cout_p, d.cin_p, &d.w)) return 1;
+        std::vector<float> b(d.cout_p, 0.0f);
+        for (int o = 0; o < l.out; o++) b[o] = l.b[o];
+        return upload_f32(b, &d.b);
+    }
+
+    int upload_linear(const Linear &l, DevConv &d) {
+        d.k = 1;
+        d.cout = l.out;
+        d.cout_p = round_up(l.out, 32);
+        d.cin_p = round_up(l.in, 32);
+        std::vector<float> flat((size_t)d.cout_p * d.cin_p, 0.0f);
+        for (int o = 0; o < l.out; o++)
+            for (int i = 0; i < l.in; i++) flat[(size_t)o * d.cin_p + i] = l.w[(size_t)o * l.in + i];
+        if (upload_matrix(flat, d.cout_p, d.cin_p, d.cout_p, d.cin_p, &d.w)) return 1;
+        std::vector<float> b(d.cout_p, 0.0f);
+        for (int o = 0; o < l.out; o++) b[o] = l.b[o];
+        return upload_f32(b, &d.b);
+    }
+
+    int build(const Model &m, bool want_resident) {
+        const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
+        HIP_TRY(hipSetDevice(device));
+        resident = want_resident;
+
+        std::vector<float> ps(cp, 1.0f), pt(cp, 0.0f);
+        for (int i = 0; i < C; i++) {
+            ps[i] = m.final_scale[i];
+            pt[i] = m.final_shift[i];
+        }
+        if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
+
+        if (resident) {
+            const int cin_p = round_up(m.c_in, 32);
+            const size_t stem_elems = (size_t)9 * 256 * cin_p, layer_elems = (size_t)9 * 256 * 256;
+            std::vector<uint16_t> stem(stem_elems), rest(layer_elems * 2 * m.depth);
+            kz::tower_pack_weights(m.tower[0].w.data(), C, m.c_in, cin_p, stem.data());
+            for (int l = 0; l < 2 * m.depth; l++)
+                kz::tower_pack_weights(m.tower[1 + l].w.data(), C, C, 256, rest.data() + layer_elems * l);
+            if (upload(stem.data(), stem.size() * 2, &res_w_stem)) return 1;
+            if (upload(rest.data(), rest.size() * 2, &res_w_tower)) return 1;
+            std::vector<float> bias((size_t)(1 + 2 * m.depth) * 256);
+            for (int l = 0; l < 1 + 2 * m.depth; l++)
+                for (int o = 0; o < 256; o++) bias[(size_t)l * 256 + o] = m.tower[l].b[o];
+            if (upload_f32(bias, &res_bias)) return 1;
+        } else {
+            tower.resize(m.tower.size());
+            for (size_t i = 0; i < m.tower.size(); i++)
+                if (upload_conv(m.tower[i], tower[i])) return 1;
+        }
+
+        // scalar head: w0 [hc][C] is the OIHW 1x1 conv as is; w1 keeps the channel-major flatten order
+        if (upload_f32(m.sh_conv.w, &sh_w0) || upload_f32(m.sh_conv.b, &sh_b0) || upload_f32(m.sh_fc0.w, &sh_w1) ||
+            upload_f32(m.sh_fc0.b, &sh_b1) || upload_f32(m.sh_fc1.w, &sh_w2) || upload_f32(m.sh_fc1.b, &sh_b2))
+            return 1;
+
+        switch (m.policy_kind) {
+            case kz::POLICY_ATAXX_CONV:
+            case kz::POLICY_CONV:
+                if (upload_conv(m.p_conv0, p_conv0)) return 1;
+                if (upload_f32(m.p_conv1.w, &p_w1) || upload_f32(m.p_conv1.b, &p_b1)) return 1;
+                if (m.policy_extra_moves) {
+                    if (upload_f32(m.p_extra_conv.w, &pe_wc) || upload_f32(m.p_extra_conv.b, &pe_bc) ||
+                        upload_f32(m.p_extra_fc.w, &pe_wl) || upload_f32(m.p_extra_fc.b, &pe_bl))
+                        return 1;
+                }
+                break;
+            case kz::POLICY_ATTENTION:
+                if (upload_conv(m.p_bulk, p_bulk) || upload_conv(m.p_under, p_under)) return 1;
+                if (upload(m.flat_to_att.data(), m.flat_to_att.size() * 4, (void **)&flat_to_att)) return 1;
+                break;
+            case kz::POLICY_DENSE: {
+                int ch = C, ch_p = cp;
+                if (m.dense_hidden_channels) {
+                    if (upload_conv(m.p_conv0, p_conv0)) return 1;
+                    ch = m.dense_hidden_channels;
+                    ch_p = p_conv0.cout_p;
+                }
+                if (m.dense_hidden_size) {
+                    if (upload_flat_linear(m.p_fc0, ch, hw, ch_p, p_fc0)) return 1;
+                    if (upload_linear(m.p_fc1, p_fc1)) return 1;
+                } else {
+                    if (upload_flat_linear(m.p_fc1, ch, hw, ch_p, p_fc1)) return 1;
+                }
+                break;
+            }
+        }
+        return 0;
+    }
+};
+
+std::mutex g_cache_mutex;
+std::map<std::tuple<const Model *, int, int, bool>, std::weak_ptr<DeviceWeights>> g_cache;
+
+struct Prof {
+    struct Rec {
+        std::string name;
+        hipEvent_t a, b;
+    };
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    void clear() {
+        for (auto &r : recs) pool.push_back({r.a, r.b});
+        recs.clear();
+    }
+    void destroy() {
+        clear();
+        for (auto &p : pool) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        pool.clear();
+    }
+    void begin(const char *name, hipStream_t s) {
+        if (!on) return;
+        Rec r;
+        r.name = name;
+        if (!pool.empty()) {
+            r.a = pool.back().first;
+            r.b = pool.back().second;
+            pool.pop_back();
+        } else {
+            (void)hipEventCreate(&r.a);
+            (void)hipEventCreate(&r.b);
+        }
+        (void)hipEventRecord(r.a, s);
+        recs.push_back(r);
+    }
+    void end(hipStream_t s) {
+        if (!on) return;
+        (void)hipEventRecord(recs.back().b, s);
+    }
+};
+
+}  // namespace
+
+struct kz_model {
+    std::shared_ptr<Model> m;
+};
+
+struct kz_engine {
+    std::shared_ptr<Model> model;
+    std::shared_ptr<DeviceWeights> wts;
+    int device = 0, dtype = 0, max_batch = 0;
+    size_t esz = 4;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs, pinned;
+    bool resident = false;
+    std::string path;
+
+    // activations
+    int cin_p = 0, cp = 0;
+    void *x_in = nullptr;
+    void *act[3] = {nullptr, nullptr, nullptr};
+    void *head0 = nullptr, *head1 = nullptr;  // head temporaries
+    int tower_out = 0;
+
+    // host-pointer entry points: per-slot device io + pinned staging
+    struct Slot {
+        uint8_t *d_bits = nullptr, *h_bits = nullptr;
+        float *d_sin = nullptr, *h_sin = nullptr;
+        float *d_sout = nullptr, *h_sout = nullptr;
+        float *d_pol = nullptr, *h_pol = nullptr;
+        hipEvent_t done = nullptr;
+        int batch = -1;
+    } slots[KZ_ENGINE_SLOTS];
+    float *d_dense = nullptr, *h_dense = nullptr;
+
+    // debugging
+    bool keep = false;
+    std::map<std::string, void *> kept;
+
+    Prof prof;
+
+    int dmalloc(void **p, size_t bytes) {
+        HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+        allocs.push_back(*p);
+        return 0;
+    }
+    int hmalloc(void **p, size_t bytes) {
+        HIP_TRY(hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault));
+        pinned.push_back(*p);
+        return 0;
+    }
+
+    int stash(const std::string &name, const void *src, int batch) {
+        if (!keep) return 0;
+        const size_t bytes = (size_t)batch * model->h * model->w * cp * esz;
+        auto it = kept.find(name);
+        if (it == kept.end()) {
+            void *p = nullptr;
+            if (dmalloc(&p, (size_t)max_batch * model->h * model->w * cp * esz)) return 1;
+            it = kept.emplace(name, p).first;
+        }
+        HIP_TRY(hipMemcpyAsync(it->second, src, bytes, hipMemcpyDeviceToDevice, stream));
+        return 0;
+    }
+
+    int conv(const DevConv &w, const void *x, int ldx, void *y, int ldy, int M, int relu, const void *res, bool post,
+             int h, int wd, int group, int src_group, int src_off, float *y32 = nullptr, int ldy32 = 0) {
+        kz::ConvArgs a{};
+        a.x = x; a.ldx = ldx; a.w = w.w; a.bias = w.b; a.res = res; a.ldres = ldy;
+        a.post_scale = post ? wts->post_scale : nullptr;
+        a.post_shift = post ? wts->post_shift : nullptr;
+        a.y = y; a.y32 = y32; a.ldy = ldy; a.ldy32 = ldy32;
+        a.M = M; a.h = h; a.w_ = wd; a.group = group; a.src_group = src_group; a.src_off = src_off;
+        a.cin_p = w.cin_p; a.cout_p = w.cout_p; a.cout = w.cout; a.k = w.k; a.relu = relu;
+        prof.begin(kz::conv_kernel_name(dtype), stream);
+        kz::launch_conv(dtype, a, stream);
+        prof.end(stream);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
+    int run_tower(int batch) {
+        const Model &m = *model;
+        const int hw = m.h * m.w, M = batch * hw;
+        if (resident) {
+            kz::TowerArgs t{};
+            t.x0 = x_in; t.cin_p = cin_p; t.w_stem = wts->res_w_stem; t.w_tower = wts->res_w_tower;
+            t.bias = wts->res_bias; t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
+            t.y = act[0]; t.batch = batch; t.h = m.h; t.w = m.w; t.depth = m.depth;
+            prof.begin("kz_tower_resident_f16", stream);
+            kz::launch_tower_resident(t, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            tower_out = 0;
+            return 0;
+        }
+        // stem: conv + bias, no activation (post_act.py:205)
+        if (conv(wts->tower[0], x_in, cin_p, act[0], cp, M, 0, nullptr, m.depth == 0, m.h, m.w, hw, hw, 0)) return 1;
+        if (stash(m.depth == 0 ? "tower.1" : "tower.0", act[0], batch)) return 1;
+        int cur = 0;
+        for (int i = 1; i <= m.depth; i++) {
+            const int mid = (cur + 1) % 3, nxt = (cur + 2) % 3;
+            const bool last = i == m.depth;
+            if (conv(wts->tower[2 * i - 1], act[cur], cp, act[mid], cp, M, 1, nullptr, false, m.h, m.w, hw, hw, 0))
+                return 1;
+            if (stash("tower." + std::to_string(i) + ".mid", act[mid], batch)) return 1;
+            // x + relu(bn(conv(mid))) (post_act.py:227-228); the tower's final BN rides on the last block
+            if (conv(wts->tower[2 * i], act[mid], cp, act[nxt], cp, M, 1, act[cur], last, m.h, m.w, hw, hw, 0))
+                return 1;
+            if (stash("tower." + std::to_string(last ? i + 1 : i), act[nxt], batch)) return 1;
+            cur = nxt;
+        }
+        tower_out = cur;
+        return 0;
+    }
+
+    int run_heads(int batch, float *d_scalars, float *d_policy) {
+        const Model &m = *model;
+        const int hw = m.h * m.w, M = batch * hw;
+        const void *x = act[tower_out];
+        {
+            kz::ScalarHeadArgs a{x, cp, batch, hw, m.channels, m.sh_conv.cout, m.sh_fc0.out,
+                                 wts->sh_w0, wts->sh_b0, wts->sh_w1, wts->sh_b1, wts->sh_w2, wts->sh_b2, d_scalars};
+            prof.begin("kz_scalar_head", stream);
+            kz::launch_scalar_head(dtype, a, stream);
+            prof.end(stream);
+        }
+        switch (m.policy_kind) {
+            case kz::POLICY_ATAXX_CONV:
+            case kz::POLICY_CONV: {
+                if (conv(wts->p_conv0, x, cp, head0, wts->p_conv0.cout_p, M, 1, nullptr, false, m.h, m.w, hw, hw, 0))
+                    return 1;
+                const int pc = m.policy_conv_channels;
+                kz::PolicyConvArgs a{head0, wts->p_conv0.cout_p, batch, hw, m.channels, pc, wts->p_w1, wts->p_b1,
+                                     d_policy, m.policy_len, m.policy_kind == kz::POLICY_ATAXX_CONV ? 1 : 0};
+                prof.begin("kz_policy_conv", stream);
+                kz::launch_policy_conv(dtype, a, stream);
+                prof.end(stream);
+                if (m.policy_kind == kz::POLICY_CONV && m.policy_extra_moves) {
+                    kz::PolicyExtraArgs e{x, cp, batch, hw, m.channels, m.policy_extra_moves, wts->pe_wc, wts->pe_bc,
+                                          wts->pe_wl, wts->pe_bl, d_policy, m.policy_len, pc * hw};
+                    prof.begin("kz_policy_extra", stream);
+                    kz::launch_policy_extra(dtype, e, stream);
+                    prof.end(stream);
+                }
+                break;
+            }
+            case kz::POLICY_ATTENTION: {
+                // bulk = conv_bulk(common) on all 64 squares; under = conv_under(common[:, :, 7, None, :]) on the
+                // 8 squares of rank index 7 (post_act.py:128-129): source rows 56..63 of each board
+                if (conv(wts->p_bulk, x, cp, head0, wts->p_bulk.cout_p, M, 0, nullptr, false, m.h, m.w, hw, hw, 0))
+                    return 1;
+                if (conv(wts->p_under, x, cp, head1, wts->p_under.cout_p, batch * 8, 0, nullptr, false, 1, 8, 8, hw, 56))
+                    return 1;
+                kz::AttentionArgs a{head0, head1, wts->p_bulk.cout_p, wts->p_under.cout_p, batch,
+                                    m.policy_query_channels, wts->flat_to_att, d_policy, m.policy_len};
+                prof.begin("kz_attention_gather", stream);
+                kz::launch_attention(dtype, a, stream);
+                prof.end(stream);
+                break;
+            }
+            case kz::POLICY_DENSE: {
+                const void *flat = x;
+                int flat_ld = hw * cp;
+                if (m.dense_hidden_channels) {
+                    if (conv(wts->p_conv0, x, cp, head0, wts->p_conv0.cout_p, M, 1, nullptr, false, m.h, m.w, hw, hw, 0))
+                        return 1;
+                    flat = head0;
+                    flat_ld = hw * wts->p_conv0.cout_p;
+                }
+                // Flatten + Linear: one GEMM row per board
+                if (m.dense_hidden_size) {
+                    if (conv(wts->p_fc0, flat, flat_ld, head1, wts->p_fc0.cout_p, batch, 1, nullptr, false, 1, 1, 1, 1, 0))
+                        return 1;
+                    if (conv(wts->p_fc1, head1, wts->p_fc0.cout_p, nullptr, 0, batch, 0, nullptr, false, 1, 1, 1, 1, 0,
+                             d_policy, m.policy_len))
+                        return 1;
+                } else {
+                    if (conv(wts->p_fc1, flat, flat_ld, nullptr, 0, batch, 0, nullptr, false, 1, 1, 1, 1, 0, d_policy,
+                             m.policy_len))
+                        return 1;
+                }
+                break;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
+    int forward_packed(const void *d_bits, size_t stride, const void *d_sin, int batch, void *d_sout, void *d_pol) {
+        const Model &m = *model;
+        prof.begin("kz_encode_packed", stream);
+        kz::launch_encode_packed(dtype, (const uint8_t *)d_bits, stride, (const float *)d_sin, batch, m.n_scalar,
+                                 m.n_bool, m.h * m.w, x_in, cin_p, stream);
+        prof.end(stream);
+        HIP_TRY(hipGetLastError());
+        if (run_tower(batch)) return 1;
+        return run_heads(batch, (float *)d_sout, (float *)d_pol);
+    }
+
+    int forward_dense(const void *d_nchw, int batch, void *d_sout, void *d_pol) {
+        const Model &m = *model;
+        prof.begin("kz_encode_dense", stream);
+        kz::launch_encode_dense(dtype, (const float *)d_nchw, batch, m.c_in, m.h * m.w, x_in, cin_p, stream);
+        prof.end(stream);
+        HIP_TRY(hipGetLastError());
+        if (run_tower(batch)) return 1;
+        return run_heads(batch, (float *)d_sout, (float *)d_pol);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+#define KZ_API __attribute__((visibility("default")))
+
+KZ_API const char *kz_last_error(void) { return g_err.c_str(); }
+
+KZ_API int kz_device_count(int *count) {
+    if (!count) return fail("kz_device_count: null argument");
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+KZ_API int kz_model_load_memory(const void *blob, size_t len, kz_model **out) {
+    if (!blob || !out) return fail("kz_model_load_memory: null argument");
+    std::string err;
+    Model *m = kz::parse_model(blob, len, err);
+    if (!m) return fail("kz_model_load: " + err);
+    *out = new kz_model{std::shared_ptr<Model>(m)};
+    return 0;
+}
+
+KZ_API int kz_model_load(const char *path, kz_model **out) {
+    if (!path || !out) return fail("kz_model_load: null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(std::string("kz_model_load: cannot open '") + path + "'");
+    std::vector<uint8_t> buf;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    return kz_model_load_memory(buf.data(), buf.size(), out);
+}
+
+KZ_API void kz_model_free(kz_model *model) { delete model; }
+
+KZ_API int kz_model_get_info(const kz_model *model, kz_model_info *out) {
+    if (!model || !out) return fail("kz_model_get_info: null argument");
+    const Model &m = *model->m;
+    out->input_channels = m.c_in;
+    out->board_h = m.h;
+    out->board_w = m.w;
+    out->input_scalar_channels = m.n_scalar;
+    out->input_bool_channels = m.n_bool;
+    out->policy_len = m.policy_len;
+    out->tower_depth = m.depth;
+    out->tower_channels = m.channels;
+    out->policy_kind = (int)m.policy_kind;
+    out->bits_bytes = (m.n_bool * m.h * m.w + 7) / 8;
+    out->param_count = m.param_count;
+    out->flops_per_eval = m.flops_per_eval;
+    return 0;
+}
+
+KZ_API void kz_engine_destroy(kz_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->prof.destroy();
+    for (auto &s : e->slots)
+        if (s.done) (void)hipEventDestroy(s.done);
+    for (void *p : e->allocs) (void)hipFree(p);
+    for (void *p : e->pinned) (void)hipHostFree(p);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    e->wts.reset();
+    delete e;
+}
+
+KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, int dtype, kz_engine **out) {
+    if (!model || !out) return fail("kz_engine_create: null argument");
+    if (max_batch <= 0) return fail("kz_engine_create: max_batch must be positive");
+    if (dtype != KZ_DTYPE_F32 && dtype != KZ_DTYPE_F16) return fail("kz_engine_create: unknown dtype");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail("kz_engine_create: device " + std::to_string(device) + " out of range (" + std::to_string(ndev) +
+                    " visible)");
+    HIP_TRY(hipSetDevice(device));
+
+    const Model &m = *model->m;
+    std::unique_ptr<kz_engine, void (*)(kz_engine *)> e(new kz_engine(), kz_engine_destroy);
+    e->model = model->m;
+    e->device = device;
+    e->dtype = dtype;
+    e->max_batch = max_batch;
+    e->esz = dtype == KZ_DTYPE_F32 ? 4 : 2;
+    e->cin_p = round_up(m.c_in, 32);
+    e->cp = round_up(m.channels, 32);
+    const char *force = getenv("KZ_FORCE_GENERIC");
+    e->resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth) && !(force && force[0] == '1');
+    const char *keep = getenv("KZ_KEEP_ACTIVATIONS");
+    e->keep = keep && keep[0] == '1' && !e->resident;
+    e->path = e->resident ? "tower_resident_f16" : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
+
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) e->wts = it->second.lock();
+        if (!e->wts) {
+            auto w = std::make_shared<DeviceWeights>();
+            w->device = device;
+            w->dtype = dtype;
+            if (w->build(m, e->resident)) return 1;
+            g_cache[key] = w;
+            e->wts = w;
+        }
+    }
+
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
+    if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
+    const int nact = e->resident ? 1 : 3;
+    for (int i = 0; i < nact; i++)
+        if (e->dmalloc(&e->act[i], rows * e->cp * e->esz)) return 1;
+    // head temporaries
+    size_t h0 = 0, h1 = 0;
+    const DeviceWeights &w = *e->wts;
+    switch (m.policy_kind) {
+        case kz::POLICY_ATAXX_CONV:
+        case kz::POLICY_CONV: h0 = rows * w.p_conv0.cout_p; break;
+        case kz::POLICY_ATTENTION:
+            h0 = rows * w.p_bulk.cout_p;
+            h1 = (size_t)max_batch * 8 * w.p_under.cout_p;
+            break;
+        case kz::POLICY_DENSE:
+            if (m.dense_hidden_channels) h0 = rows * w.p_conv0.cout_p;
+            if (m.dense_hidden_size) h1 = (size_t)max_batch * w.p_fc0.cout_p;
+            break;
+    }
+    if (e->dmalloc(&e->head0, h0 * e->esz) || e->dmalloc(&e->head1, h1 * e->esz)) return 1;
+
+    const size_t bits_bytes = (size_t)(m.n_bool * hw + 7) / 8;
+    for (auto &s : e->slots) {
+        if (e->dmalloc((void **)&s.d_bits, max_batch * bits_bytes) ||
+            e->dmalloc((void **)&s.d_sin, (size_t)max_batch * m.n_scalar * 4) ||
+            e->dmalloc((void **)&s.d_sout, (size_t)max_batch * 5 * 4) ||
+            e->dmalloc((void **)&s.d_pol, (size_t)max_batch * m.policy_len * 4))
+            return 1;
+        if (e->hmalloc((void **)&s.h_bits, max_batch * bits_bytes) ||
+            e->hmalloc((void **)&s.h_sin, (size_t)max_batch * m.n_scalar * 4) ||
+            e->hmalloc((void **)&s.h_sout, (size_t)max_batch * 5 * 4) ||
+            e->hmalloc((void **)&s.h_pol, (size_t)max_batch * m.policy_len * 4))
+            return 1;
+        HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    *out = e.release();
+    return 0;
+}
+
+KZ_API int kz_engine_max_batch(const kz_engine *e) { return e ? e->max_batch : 0; }
+
+KZ_API const char *kz_engine_tower_path(const kz_engine *e) { return e ? e->path.c_str() : ""; }
+
+static int check_batch(const kz_engine *e, int batch, const char *fn) {
+    if (!e) return fail(std::string(fn) + ": null engine");
+    if (batch < 0 || batch > e->max_batch)  // assert!(batch_size <= max_batch_size), cudnn.rs:58
+        return fail(std::string(fn) + ": batch " + std::to_string(batch) + " exceeds max_batch " +
+                    std::to_string(e->max_batch));
+    return 0;
+}
+
+KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, size_t bits_stride,
+                                   const float *scalars_in, int batch) {
+    if (check_batch(e, batch, "kz_engine_submit_packed")) return 1;
+    if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail("kz_engine_submit_packed: bad slot");
+    kz_engine::Slot &s = e->slots[slot];
+    if (s.batch >= 0) return fail("kz_engine_submit_packed: slot still in flight (call kz_engine_wait first)");
+    const Model &m = *e->model;
+    const size_t bits_bytes = (size_t)(m.n_bool * m.h * m.w + 7) / 8;
+    if (batch > 0 && (!bits || (m.n_scalar && !scalars_in))) return fail("kz_engine_submit_packed: null input");
+    if (batch > 0 && bits_stride < bits_bytes) return fail("kz_engine_submit_packed: bits_stride too small");
+    HIP_TRY(hipSetDevice(e->device));
+    s.batch = batch;
+    if (batch == 0) return 0;
+    for (int b = 0; b < batch; b++) memcpy(s.h_bits + b * bits_bytes, bits + b * bits_stride, bits_bytes);
+    memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
+    HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
+    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout, s.d_pol)) return 1;
+    HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, (size_t)batch * 5 * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.h_pol, s.d_pol, (size_t)batch * m.policy_len * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipEventRecord(s.done, e->stream));
+    return 0;
+}
+
+KZ_API int kz_engine_wait(kz_engine *e, int slot, float *scalars_out, float *policy_out) {
+    if (!e) return fail("kz_engine_wait: null engine");
+    if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail("kz_engine_wait: bad slot");
+    kz_engine::Slot &s = e->slots[slot];
+    if (s.batch < 0) return fail("kz_engine_wait: nothing submitted on this slot");
+    const int batch = s.batch;
+    s.batch = -1;
+    if (batch == 0) return 0;
+    if (!scalars_out || !policy_out) return fail("kz_engine_wait: null output");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(s.done));
+    memcpy(scalars_out, s.h_sout, (size_t)batch * 5 * 4);
+    memcpy(policy_out, s.h_pol, (size_t)batch * e->model->policy_len * 4);
+    return 0;
+}
+
+KZ_API int kz_engine_eval_packed(kz_engine *e, const uint8_t *bits, size_t bits_stride, const float *scalars_in,
+                                 int batch, float *scalars_out, float *policy_out) {
+    if (kz_engine_submit_packed(e, 0, bits, bits_stride, scalars_in, batch)) return 1;
+    return kz_engine_wait(e, 0, scalars_out, policy_out);
+}
+
+KZ_API int kz_engine_eval_dense(kz_engine *e, const float *input_nchw, int batch, float *scalars_out,
+                                float *policy_out) {
+    if (check_batch(e, batch, "kz_engine_eval_dense")) return 1;
+    if (batch == 0) return 0;
+    if (!input_nchw || !scalars_out || !policy_out) return fail("kz_engine_eval_dense: null argument");
+    kz_engine::Slot &s = e->slots[0];
+    if (s.batch >= 0) return fail("kz_engine_eval_dense: slot 0 still in flight");
+    const Model &m = *e->model;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t per = (size_t)m.c_in * m.h * m.w * 4;
+    if (!e->d_dense) {
+        if (e->dmalloc((void **)&e->d_dense, e->max_batch * per) || e->hmalloc((void **)&e->h_dense, e->max_batch * per))
+            return 1;
+    }
+    memcpy(e->h_dense, input_nchw, batch * per);
+    HIP_TRY(hipMemcpyAsync(e->d_dense, e->h_dense, batch * per, hipMemcpyHostToDevice, e->stream));
+    if (e->forward_dense(e->d_dense, batch, s.d_sout, s.d_pol)) return 1;
+    HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, (size_t)batch * 5 * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.h_pol, s.d_pol, (size_t)batch * m.policy_len * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(scalars_out, s.h_sout, (size_t)batch * 5 * 4);
+    memcpy(policy_out, s.h_pol, (size_t)batch * m.policy_len * 4);
+    return 0;
+}
+
+KZ_API int kz_engine_enqueue_packed_device(kz_engine *e, const void *d_bits, size_t bits_stride,
+                                           const void *d_scalars_in, int batch, void *d_scalars_out,
+                                           void *d_policy_out) {
+    if (check_batch(e, batch, "kz_engine_enqueue_packed_device")) return 1;
+    if (batch == 0) return 0;
+    if (!d_bits || !d_scalars_out || !d_policy_out) return fail("kz_engine_enqueue_packed_device: null argument");
+    const Model &m = *e->model;
+    if (bits_stride < (size_t)(m.n_bool * m.h * m.w + 7) / 8)
+        return fail("kz_engine_enqueue_packed_device: bits_stride too small");
+    HIP_TRY(hipSetDevice(e->device));
+    return e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
+}
+
+KZ_API int kz_engine_enqueue_dense_device(kz_engine *e, const void *d_input_nchw, int batch, void *d_scalars_out,
+                                          void *d_policy_out) {
+    if (check_batch(e, batch, "kz_engine_enqueue_dense_device")) return 1;
+    if (batch == 0) return 0;
+    if (!d_input_nchw || !d_scalars_out || !d_policy_out) return fail("kz_engine_enqueue_dense_device: null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return e->forward_dense(d_input_nchw, batch, d_scalars_out, d_policy_out);
+}
+
+KZ_API int kz_engine_synchronize(kz_engine *e) {
+    if (!e) return fail("kz_engine_synchronize: null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+KZ_API int kz_device_malloc(int device, size_t bytes, void **out) {
+    if (!out) return fail("kz_device_malloc: null argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    return 0;
+}
+
+KZ_API int kz_device_free(int device, void *ptr) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(ptr));
+    return 0;
+}
+
+KZ_API int kz_memcpy_h2d(int device, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+KZ_API int kz_memcpy_d2h(int device, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+KZ_API int kz_device_synchronize(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+KZ_API int kz_engine_set_profiling(kz_engine *e, int enable) {
+    if (!e) return fail("kz_engine_set_profiling: null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->prof.clear();
+    e->prof.on = enable != 0;
+    return 0;
+}
+
+KZ_API int kz_engine_kernel_time(kz_engine *e, const char *prefix, double *total_ms, int64_t *launches) {
+    if (!e || !prefix || !total_ms || !launches) return fail("kz_engine_kernel_time: null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double total = 0;
+    int64_t n = 0;
+    const size_t plen = strlen(prefix);
+    for (auto &r : e->prof.recs) {
+        if (r.name.compare(0, plen, prefix) != 0) continue;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        total += ms;
+        n++;
+    }
+    *total_ms = total;
+    *launches = n;
+    return 0;
+}
+
+KZ_API int kz_engine_read_activation(kz_engine *e, const char *name, int batch, float *out_nchw) {
+    if (!e || !name || !out_nchw) return fail("kz_engine_read_activation: null argument");
+    if (!e->keep)
+        return fail("kz_engine_read_activation: engine keeps no activations (create it with KZ_FORCE_GENERIC=1 and "
+                    "KZ_KEEP_ACTIVATIONS=1)");
+    auto it = e->kept.find(name);
+    if (it == e->kept.end()) return fail(std::string("kz_engine_read_activation: no activation named '") + name + "'");
+    if (check_batch(e, batch, "kz_engine_read_activation")) return 1;
+    const Model &m = *e->model;
+    const int hw = m.h * m.w, C = m.channels, cp = e->cp;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<uint8_t> raw((size_t)batch * hw * cp * e->esz);
+    HIP_TRY(hipMemcpy(raw.data(), it->second, raw.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; b++)
+        for (int c = 0; c < C; c++)
+            for (int p = 0; p < hw; p++) {
+                const size_t src = ((size_t)b * hw + p) * cp + c;
+                float v;
+                if (e->dtype == KZ_DTYPE_F32) {
+                    memcpy(&v, raw.data() + src * 4, 4);
+                } else {
+                    _Float16 h;
+                    memcpy(&h, raw.data() + src * 2, 2);
+                    v = (float)h;
+                }
+                out_nchw[((size_t)b * C + c) * hw + p] = v;
+            }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// kz_kernels.hpp — launch interface of the gfx950 kernels (definitions: kz_kernels.hip, kz_tower.hip).
+// All activations are NHWC with the channel dimension padded to a multiple of 32 ("Cp"): row = one board
+// square (pixel), columns = channels.  T is float (KZ_DTYPE_F32) or _Float16 (KZ_DTYPE_F16).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace kz {
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// F0 — board encode (rust/kz-core/src/mapping/mod.rs:40-63) on the GPU.
+// packed: bits [batch][bits_stride] u8 (BitBuffer layout) + scalars [batch][n_scalar] f32 -> x [batch*hw][ldx]
+void launch_encode_packed(int dtype, const uint8_t *bits, size_t bits_stride, const float *scalars, int batch,
+                          int n_scalar, int n_bool, int hw, void *x, int ldx, hipStream_t stream);
+// dense: NCHW f32 [batch][c][hw] -> x [batch*hw][ldx] (channels >= c zero-filled)
+void launch_encode_dense(int dtype, const float *nchw, int batch, int c, int hw, void *x, int ldx,
+                         hipStream_t stream);
+
+// Implicit-GEMM convolution, kernel k in {1,3}, pad k/2, fused epilogue:
+//   v = acc + bias[oc];  if (relu) v = max(v, 0);  if (res) v += res[row][oc];
+//   if (post_scale) v = v * post_scale[oc] + post_shift[oc];  y[row][oc] = v
+// (conv A of a ResBlock: relu; conv B: relu then residual add — post_act.py:227-228 adds AFTER the ReLU;
+//  the tower's final BatchNorm rides on the last conv as post_scale/post_shift.)
+struct ConvArgs {
+    const void *x;       // [rows_src][ldx]
+    int ldx;
+    const void *w;       // packed [k*k][cout_p][cin_p]
+    const float *bias;   // [cout_p]
+    const void *res;     // optional [M][ldres]
+    int ldres;
+    const float *post_scale, *post_shift;  // optional [cout_p]
+    void *y;             // [M][ldy] in T, or nullptr
+    float *y32;          // optional f32 output [M][ldy32], columns < cout only
+    int ldy, ldy32;
+    int M;               // output rows
+    int h, w_;           // board dims (tap validity); rows of one board are contiguous: row = b*group + y*w + x
+    int group;           // rows per board in M space (h*w)
+    int src_group;       // rows per board in the source buffer
+    int src_off;         // first source row of the group inside its board
+    int cin_p, cout_p, cout;
+    int k;
+    int relu;
+};
+void launch_conv(int dtype, const ConvArgs &a, hipStream_t stream);
+const char *conv_kernel_name(int dtype);
+
+// ScalarHead (post_act.py:10-23) from the tower output x [batch*hw][ldx] -> scalars [batch][5] f32
+struct ScalarHeadArgs {
+    const void *x;
+    int ldx, batch, hw, c, hc, hs;
+    const float *w0, *b0;  // [hc][c], [hc]
+    const float *w1, *b1;  // [hs][hc*hw] (channel-major flatten index c*hw + p), [hs]
+    const float *w2, *b2;  // [5][hs], [5]
+    float *out;
+};
+void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream);
+
+// Last 1x1 conv of the conv policy heads: y [batch*hw][ldy] (after conv1x1+ReLU) -> policy[b][oc*hw + p]
+// (channel-major flatten, post_act.py:83,108) and optional trailing columns:
+//   zero_tail columns of 0.0 (AtaxxConvPolicyHead's pass logit, post_act.py:106-110)
+struct PolicyConvArgs {
+    const void *y;
+    int ldy, batch, hw, c, pc;
+    const float *w, *b;  // [pc][c], [pc]
+    float *policy;
+    int policy_len, zero_tail;
+};
+void launch_policy_conv(int dtype, const PolicyConvArgs &a, hipStream_t stream);
+
+// ConvPolicyHead.seq_extra (post_act.py:64-68): conv1x1 C->1, Flatten, Linear(hw -> extra) -> policy[b][offset + j]
+struct PolicyExtraArgs {
+    const void *x;
+    int ldx, batch, hw, c, extra;
+    const float *wc, *bc;  // [c], [1]
+    const float *wl, *bl;  // [extra][hw], [extra]
+    float *policy;
+    int policy_len, offset;
+};
+void launch_policy_extra(int dtype, const PolicyExtraArgs &a, hipStream_t stream);
+
+// AttentionPolicyHead tail (post_act.py:127-141): bulk [batch*64][ld_bulk] (2Q channels), under [batch*8][ld_under]
+// (3Q channels) -> policy[b][k] = (q_from^T q_to)[flat_to_att[k]] / sqrt(Q)
+struct AttentionArgs {
+    const void *bulk, *under;
+    int ld_bulk, ld_under, batch, q;
+    const int32_t *flat_to_att;
+    float *policy;
+    int policy_len;
+};
+void launch_attention(int dtype, const AttentionArgs &a, hipStream_t stream);
+
+// ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----
+// Requirements: f16, h*w <= 64, channels == 256 (cp), any depth >= 1.
+struct TowerArgs {
+    const void *x0;       // encoded input [batch*hw][cin_p] f16
+    int cin_p;            // 32
+    const void *w_stem;   // fragment-packed stem weights
+    const void *w_tower;  // fragment-packed weights of the 2*depth 3x3 convs
+    const float *bias;    // [1 + 2*depth][256]
+    const float *post_scale, *post_shift;  // final BN [256]
+    void *y;              // tower output [batch*hw][256] f16
+    int batch, h, w, depth;
+};
+bool tower_resident_supported(int dtype, int h, int w, int channels, int depth);
+size_t tower_packed_weight_elems(int cin_p, int depth);
+// host-side packing: OIHW f32 (BN folded) -> MFMA A-fragment order f16; dst index for conv layer l (0 = stem)
+void tower_pack_weights(const float *oihw, int cout, int cin, int cin_p, uint16_t *dst);
+void launch_tower_resident(const TowerArgs &a, hipStream_t stream);
+
+}  // namespace kz

@@ -1,0 +1,60 @@
+// kz_model.hpp — host-side model: KZMODEL1 parse + Conv/BN folding.
+// Replaces `load_graph_from_onnx_path` + `optimize_graph` (rust/kz-selfplay/src/server/server_alphazero.rs:126-128)
+// for the PredictionHeads(ResTower, ScalarHead, <policy head>) family of python/lib/model/post_act.py.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace kz {
+
+struct Conv {  // nn.Conv2d with square kernel k, weights OIHW, BN (if any) already folded in
+    int cout = 0, cin = 0, k = 1;
+    std::vector<float> w, b;
+};
+
+struct Linear {  // nn.Linear, weights [out][in]
+    int out = 0, in = 0;
+    std::vector<float> w, b;
+};
+
+enum PolicyKind { POLICY_ATAXX_CONV = 0, POLICY_CONV = 1, POLICY_ATTENTION = 2, POLICY_DENSE = 3 };
+
+struct Model {
+    // architecture descriptor
+    std::string game;
+    int h = 0, w = 0, n_scalar = 0, n_bool = 0, c_in = 0;
+    int depth = 0, channels = 0;
+    int policy_len = 0;
+    PolicyKind policy_kind = POLICY_CONV;
+    int policy_conv_channels = 0, policy_extra_moves = 0, policy_query_channels = 0;
+    int dense_hidden_channels = 0, dense_hidden_size = 0;
+
+    // ResTower (post_act.py:201-211): tower[0] = stem; tower[2i-1], tower[2i] = block i conv A / conv B,
+    // each with its BatchNorm folded (W' = s*W, b' = s*b + t).  The tower's final BatchNorm stays a per-channel
+    // affine (final_scale, final_shift): it is applied after the last residual add, so it cannot be folded
+    // backwards; the executor fuses it into the last conv's epilogue.
+    std::vector<Conv> tower;
+    std::vector<float> final_scale, final_shift;
+
+    // ScalarHead (post_act.py:10-23)
+    Conv sh_conv;
+    Linear sh_fc0, sh_fc1;
+
+    // policy heads
+    Conv p_conv0, p_conv1;       // ataxx_conv / conv: seq.0, seq.2     dense: seq.0 (optional)
+    Conv p_extra_conv;           // conv: seq_extra.0
+    Linear p_extra_fc;           // conv: seq_extra.2
+    Conv p_bulk, p_under;        // attention
+    std::vector<int32_t> flat_to_att;
+    Linear p_fc0, p_fc1;         // dense: optional hidden Linear, final Linear
+
+    int64_t param_count = 0;
+    double flops_per_eval = 0;
+};
+
+// Returns nullptr and sets `err` on failure.
+Model *parse_model(const void *blob, size_t len, std::string &err);
+
+}  // namespace kz

@@ -1,0 +1,125 @@
+"""Synthetic models and boards (no network for checkpoints or datasets).
+
+`random_model` builds a KZMODEL1 container with the tensor names and shapes of the reference's
+`PredictionHeads(ResTower(d, C_in, C), ScalarHead(S, C, 4, 32), <policy head>)` state_dict
+(python/lib/model/post_act.py:187-211), initialised like PyTorch's defaults
+(U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for conv/linear weights and biases) with mildly non-trivial BatchNorm
+statistics so that Conv+BN folding is exercised.
+
+`random_boards` builds packed boards: BitBuffer-layout bool planes (LSB-first, rust/kz-core/src/mapping/
+bit_buffer.rs:73-75) plus the per-board scalars, with densities that resemble real positions.
+"""
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .model_file import read_model, write_model
+
+GAMES = {
+    # name: (board, scalar planes, bool planes, policy_len fn)
+    "chess": dict(size=8, n_scalar=8, n_bool=13, policy_len=1880, p_bool=0.04),      # chess.rs:125-171
+    "ataxx-7": dict(size=7, n_scalar=1, n_bool=3, policy_len=17 * 49 + 1, p_bool=0.3),  # ataxx.rs:93-116
+    "go-19": dict(size=19, n_scalar=6, n_bool=7, policy_len=1 + 361, p_bool=0.25),   # go.rs:46-113 (territory on)
+    "go-9": dict(size=9, n_scalar=6, n_bool=7, policy_len=1 + 81, p_bool=0.25),
+}
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def chess_flat_to_att() -> np.ndarray:
+    """The 1880-entry gather table of AttentionPolicyHead (a data table of the reference,
+    python/lib/mapping/chess_flat_to_att.txt), taken from the committed golden chess model."""
+    _, tensors = read_model(open(os.path.join(_GOLDEN, "chess_2x32_att.kzm"), "rb").read())
+    return tensors["policy_head.FLAT_TO_ATT"].astype(np.int64)
+
+
+def _uniform(rng, shape, fan_in):
+    bound = 1.0 / np.sqrt(fan_in)
+    return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def _conv(rng, t, prefix, cout, cin, k):
+    t[prefix + ".weight"] = _uniform(rng, (cout, cin, k, k), cin * k * k)
+    t[prefix + ".bias"] = _uniform(rng, (cout,), cin * k * k)
+
+
+def _linear(rng, t, prefix, out, inp):
+    t[prefix + ".weight"] = _uniform(rng, (out, inp), inp)
+    t[prefix + ".bias"] = _uniform(rng, (out,), inp)
+
+
+def _bn(rng, t, prefix, c):
+    t[prefix + ".weight"] = rng.uniform(0.8, 1.2, size=c).astype(np.float32)
+    t[prefix + ".bias"] = rng.normal(0.0, 0.1, size=c).astype(np.float32)
+    t[prefix + ".running_mean"] = rng.normal(0.0, 0.1, size=c).astype(np.float32)
+    t[prefix + ".running_var"] = rng.uniform(0.8, 1.25, size=c).astype(np.float32)
+
+
+def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0, query_channels: int = None,
+                 n_bool: int = None) -> bytes:
+    g = GAMES[game]
+    size, n_scalar = g["size"], g["n_scalar"]
+    n_bool = g["n_bool"] if n_bool is None else n_bool
+    hw, C = size * size, channels
+    rng = np.random.default_rng(seed)
+    t: Dict[str, np.ndarray] = {}
+    meta = {
+        "game": game, "board_h": size, "board_w": size,
+        "input_scalar_channels": n_scalar, "input_bool_channels": n_bool,
+        "tower_depth": depth, "tower_channels": C, "tower_final_affine": 1,
+        "scalar_hidden_channels": 4, "scalar_hidden_size": 32,
+        "policy_kind": head, "policy_len": g["policy_len"], "bn_eps": 1e-5,
+    }
+    _conv(rng, t, "common.tower.0", C, n_scalar + n_bool, 3)
+    for i in range(1, depth + 1):
+        _conv(rng, t, f"common.tower.{i}.seq.0", C, C, 3)
+        _bn(rng, t, f"common.tower.{i}.seq.1", C)
+        _conv(rng, t, f"common.tower.{i}.seq.3", C, C, 3)
+        _bn(rng, t, f"common.tower.{i}.seq.4", C)
+    _bn(rng, t, f"common.tower.{depth + 1}", C)
+    _conv(rng, t, "scalar_head.seq.0", 4, C, 1)
+    _linear(rng, t, "scalar_head.seq.3", 32, 4 * hw)
+    _linear(rng, t, "scalar_head.seq.5", 5, 32)
+    if head == "ataxx_conv":
+        meta["policy_conv_channels"] = 17
+        _conv(rng, t, "policy_head.seq.0", C, C, 1)
+        _conv(rng, t, "policy_head.seq.2", 17, C, 1)
+    elif head == "conv":
+        meta["policy_conv_channels"] = 1
+        meta["policy_extra_moves"] = 1
+        _conv(rng, t, "policy_head.seq.0", C, C, 1)
+        _conv(rng, t, "policy_head.seq.2", 1, C, 1)
+        _conv(rng, t, "policy_head.seq_extra.0", 1, C, 1)
+        _linear(rng, t, "policy_head.seq_extra.2", 1, hw)
+    elif head == "attention":
+        q = query_channels or C  # supervised_main_alpha.py:76: AttentionPolicyHead(game, channels, channels)
+        meta["policy_query_channels"] = q
+        _conv(rng, t, "policy_head.conv_bulk", 2 * q, C, 1)
+        _conv(rng, t, "policy_head.conv_under", 3 * q, C, 1)
+        t["policy_head.FLAT_TO_ATT"] = chess_flat_to_att()
+    else:
+        raise ValueError(f"unsupported synthetic head '{head}'")
+    return write_model(meta, t)
+
+
+def random_boards(game: str, batch: int, seed: int = 0, n_bool: int = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Returns (bits [batch, ceil(n_bool*hw/8)] u8, scalars [batch, n_scalar] f32)."""
+    g = GAMES[game]
+    size, n_scalar = g["size"], g["n_scalar"]
+    n_bool = g["n_bool"] if n_bool is None else n_bool
+    rng = np.random.default_rng(seed)
+    bools = rng.uniform(size=(batch, n_bool * size * size)) < g["p_bool"]
+    bits = np.packbits(bools.astype(np.uint8), axis=1, bitorder="little")
+    if game == "chess":
+        # [pov==White, pov==Black, K/Q castle us, K/Q castle them, repetitions, 50-move counter] (chess.rs:136-155)
+        white = rng.integers(0, 2, size=batch)
+        scalars = np.stack([white, 1 - white, *(rng.integers(0, 2, size=batch) for _ in range(4)),
+                            rng.integers(0, 3, size=batch), rng.integers(0, 100, size=batch)], axis=1)
+    elif game.startswith("ataxx"):
+        scalars = rng.uniform(0, 1, size=(batch, 1))  # moves_since_last_copy / MAX (ataxx.rs:107-109)
+    else:
+        black = rng.integers(0, 2, size=batch)
+        scalars = np.stack([black, 1 - black, np.zeros(batch), np.zeros(batch), np.full(batch, 7.5 / 15.0),
+                            np.zeros(batch)], axis=1)  # go.rs:105-112
+    return np.ascontiguousarray(bits), np.ascontiguousarray(scalars.astype(np.float32))

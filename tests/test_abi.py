@@ -1,0 +1,105 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/kz_hip.h declares,
+parses models on the host, and fails loudly (no fallback) where a GPU is needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kzero_amd import capi, synth
+from kzero_amd.model_file import read_model, write_model
+from tests import oracle_lib as O
+
+HEADER = os.path.join(O.REPO, "include", "kz_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(capi.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in kz_hip.h but not exported"
+    assert set(names) == set(capi.SIGNATURES), "capi.py binding out of sync with kz_hip.h"
+
+
+@pytest.mark.parametrize("name", O.GOLDEN_NETS)
+def test_model_info_matches_oracle(name):
+    blob = O.load_blob(name)
+    model = capi.Model(blob=blob)
+    net = O.OracleNet(blob)
+    i = model.info
+    assert (i.input_channels, i.board_h, i.board_w) == (net.c_in, net.h, net.w)
+    assert (i.input_scalar_channels, i.input_bool_channels) == (net.n_scalar, net.n_bool)
+    assert (i.policy_len, i.tower_depth, i.tower_channels) == (net.policy_len, net.depth, net.channels)
+    assert i.bits_bytes == (net.n_bool * net.h * net.w + 7) // 8
+    _, tensors = read_model(blob)
+    assert i.param_count == sum(t.size for k, t in tensors.items() if t.dtype == np.float32)
+
+
+def test_flops_match_baseline_md():
+    """FLOP/eval counted by hooking the reference modules."""
+    chess = capi.Model(blob=synth.random_model("chess", 20, 256, "attention"))
+    assert abs(chess.info.flops_per_eval / 3.049e9 - 1) < 2e-3
+    ataxx = capi.Model(blob=synth.random_model("ataxx-7", 8, 128, "ataxx_conv"))
+    assert abs(ataxx.info.flops_per_eval / 233.5e6 - 1) < 2e-3
+    a0 = capi.Model(blob=synth.random_model("ataxx-7", 4, 64, "ataxx_conv"))
+    assert abs(a0.info.flops_per_eval / 29.67e6 - 1) < 2e-3
+    go = capi.Model(blob=synth.random_model("go-19", 40, 256, "conv"))
+    assert abs(go.info.flops_per_eval / 34.13e9 - 1) < 3e-3
+
+
+def test_model_load_from_path(tmp_path):
+    p = tmp_path / "m.kzm"
+    p.write_bytes(O.load_blob("ataxx7_2x16"))
+    assert capi.Model(path=str(p)).info.policy_len == 834
+    with pytest.raises(capi.KzError, match="cannot open"):
+        capi.Model(path=str(tmp_path / "missing.kzm"))
+
+
+def test_bad_models_are_rejected_with_a_message():
+    with pytest.raises(capi.KzError, match="KZMODEL1"):
+        capi.Model(blob=b"not a model at all")
+    blob = O.load_blob("ataxx7_2x16")
+    with pytest.raises(capi.KzError, match="truncated"):
+        capi.Model(blob=blob[:len(blob) // 2])
+    meta, tensors = read_model(blob)
+    tensors = dict(tensors)
+    del tensors["common.tower.1.seq.1.running_var"]
+    with pytest.raises(capi.KzError, match="running_var"):
+        capi.Model(blob=write_model(meta, tensors))
+    meta2 = dict(meta)
+    meta2["policy_len"] = 100
+    with pytest.raises(capi.KzError, match="policy_len"):
+        capi.Model(blob=write_model(meta2, dict(read_model(blob)[1])))
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """The product path must fail when it cannot run on a GPU; it never computes on the CPU."""
+    try:
+        n = capi.device_count()
+    except capi.KzError:
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is visible")
+    model = capi.Model(blob=O.load_blob("ataxx7_2x16"))
+    with pytest.raises(capi.KzError):
+        capi.Engine(model, 0, 4, capi.KZ_DTYPE_F32)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under kzero_amd/ may import, link or load it."""
+    pkg = os.path.join(O.REPO, "kzero_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", ".sh")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert "kzoracle" not in text and "oracle_lib" not in text and "kz_oracle" not in text, f
+    out = os.popen(f"readelf -d {capi.LIB_PATH}").read()
+    assert "oracle" not in out

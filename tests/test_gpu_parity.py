@@ -1,0 +1,266 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the golden vectors.
+
+Tolerances:
+  f32 path: max |delta| <= 1e-4 on policy logits and the 5 scalars (BASELINE.json north_star / BASELINE.md §4).
+  f16 path: 1e-4 is not attainable by construction (f16 storage of weights and activations, f32 accumulate);
+            the stated tolerance is |delta| <= F16_ATOL + F16_RTOL*|ref| with the values below, and the post-softmax
+            policy within 2e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from kzero_amd import capi, synth
+from kzero_amd.model_file import read_model
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+F32_ATOL = 1e-4
+F16_ATOL, F16_RTOL = 3e-2, 2e-2
+
+
+def assert_f32(actual, ref, what):
+    err = np.abs(actual - ref).max() if actual.size else 0.0
+    assert err <= F32_ATOL, f"{what}: max |delta| = {err:.3e} > 1e-4"
+
+
+def assert_f16(actual, ref, what):
+    bad = np.abs(actual - ref) > F16_ATOL + F16_RTOL * np.abs(ref)
+    assert not bad.any(), f"{what}: {bad.sum()} values off, max |delta| = {np.abs(actual - ref).max():.3e}"
+
+
+def softmax(x):
+    e = np.exp(x - x.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert capi.device_count() >= 1
+    return 0
+
+
+@pytest.mark.parametrize("name", O.GOLDEN_NETS)
+@pytest.mark.parametrize("kind", ["planes", "randn"])
+def test_f32_dense_matches_golden_and_oracle(dev, name, kind):
+    blob = O.load_blob(name)
+    net = O.OracleNet(blob)
+    x, s_gold, p_gold = O.read_io(name, kind, net.c_in, net.h, net.w, net.policy_len)
+    s_or, p_or = net.forward(x)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 8, capi.KZ_DTYPE_F32)
+    s, p = eng.eval_dense(x)
+    assert_f32(s, s_gold, "scalars vs golden")
+    assert_f32(p, p_gold, "policy vs golden")
+    assert_f32(s, s_or, "scalars vs oracle")
+    assert_f32(p, p_or, "policy vs oracle")
+
+
+@pytest.mark.parametrize("name", O.GOLDEN_NETS)
+@pytest.mark.parametrize("dtype", [capi.KZ_DTYPE_F32, capi.KZ_DTYPE_F16])
+def test_packed_input(dev, name, dtype):
+    """bits + scalars in, the GPU does encode_input_full (F0)."""
+    blob = O.load_blob(name)
+    net = O.OracleNet(blob)
+    _, s_gold, p_gold = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    bits, scalars_in = O.read_packed(name, net.n_bool, net.n_scalar, net.h, net.w)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 4, dtype)
+    s, p = eng.eval_packed(bits, scalars_in)
+    if dtype == capi.KZ_DTYPE_F32:
+        assert_f32(s, s_gold, "scalars")
+        assert_f32(p, p_gold, "policy")
+    else:
+        assert_f16(s, s_gold, "scalars")
+        assert_f16(p, p_gold, "policy")
+        assert np.abs(softmax(p) - softmax(p_gold)).max() < 2e-3
+
+
+def test_per_layer_activations_f32(dev, monkeypatch):
+    monkeypatch.setenv("KZ_FORCE_GENERIC", "1")
+    monkeypatch.setenv("KZ_KEEP_ACTIVATIONS", "1")
+    name = "ataxx7_2x16"
+    blob = O.load_blob(name)
+    net = O.OracleNet(blob)
+    x, _, _ = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    _, ref = read_model(open(os.path.join(O.GOLDEN, f"{name}.layers.kzm"), "rb").read())
+    eng = capi.Engine(capi.Model(blob=blob), dev, 4, capi.KZ_DTYPE_F32)
+    eng.eval_dense(x)
+    # the last block's pre-BN output is never materialised: the final BN is fused into its epilogue
+    for key in ["tower.0", "tower.1.mid", "tower.1", "tower.2.mid", "tower.3"]:
+        assert_f32(eng.read_activation(key, x.shape[0]), ref[key], key)
+
+
+def test_batch_edges(dev):
+    """empty, single, ragged and oversize batches; only `batch` rows are written (cudnn.rs:58,65,75-82)."""
+    name = "chess_2x32_att"
+    blob = O.load_blob(name)
+    net = O.OracleNet(blob)
+    x, s_gold, p_gold = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 3, capi.KZ_DTYPE_F32)
+    assert eng.max_batch == 3
+    s0, p0 = eng.eval_dense(x[:0])
+    assert s0.shape == (0, 5) and p0.shape == (0, net.policy_len)
+    s1, p1 = eng.eval_dense(x[:1])
+    assert_f32(s1, s_gold[:1], "single scalars")
+    assert_f32(p1, p_gold[:1], "single policy")
+    s3, p3 = eng.eval_dense(x)
+    # per-sample independence: a board's result does not depend on its batch (eval-mode BN)
+    assert np.array_equal(s3[:1], s1) and np.array_equal(p3[:1], p1)
+    with pytest.raises(capi.KzError, match="exceeds max_batch"):
+        eng.eval_dense(np.concatenate([x, x]))
+    # the engine is still usable after an error
+    s3b, _ = eng.eval_dense(x)
+    assert np.array_equal(s3, s3b)
+
+
+def test_async_slots_and_shared_weights(dev):
+    name = "ataxx7_4x64"
+    blob = O.load_blob(name)
+    net = O.OracleNet(blob)
+    _, s_gold, p_gold = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    bits, scalars_in = O.read_packed(name, net.n_bool, net.n_scalar, net.h, net.w)
+    model = capi.Model(blob=blob)
+    e1 = capi.Engine(model, dev, 2, capi.KZ_DTYPE_F32)
+    e2 = capi.Engine(model, dev, 2, capi.KZ_DTYPE_F32)  # shares the uploaded weights with e1
+    n0 = e1.submit_packed(0, bits, scalars_in)
+    n1 = e1.submit_packed(1, bits[::-1], scalars_in[::-1])
+    with pytest.raises(capi.KzError, match="in flight"):
+        e1.submit_packed(0, bits, scalars_in)
+    s_b, p_b = e1.wait(1, n1)
+    s_a, p_a = e1.wait(0, n0)
+    assert_f32(s_a, s_gold, "slot 0")
+    assert_f32(p_a, p_gold, "slot 0")
+    assert np.array_equal(s_b[::-1], s_a) and np.array_equal(p_b[::-1], p_a)
+    s_c, p_c = e2.eval_packed(bits, scalars_in)
+    assert np.array_equal(s_c, s_a) and np.array_equal(p_c, p_a)
+    with pytest.raises(capi.KzError, match="nothing submitted"):
+        e1.wait(0, n0)
+    e1.close()
+    s_d, _ = e2.eval_packed(bits, scalars_in)  # weights stay alive while any engine uses them
+    assert np.array_equal(s_d, s_a)
+
+
+def test_device_resident_entry_points(dev):
+    name = "go9_2x16_conv_terr"
+    blob = O.load_blob(name)
+    net = O.OracleNet(blob)
+    x, s_gold, p_gold = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    bits, scalars_in = O.read_packed(name, net.n_bool, net.n_scalar, net.h, net.w)
+    b = x.shape[0]
+    eng = capi.Engine(capi.Model(blob=blob), dev, b, capi.KZ_DTYPE_F32)
+    d_s = capi.DeviceBuffer(dev, b * 5 * 4)
+    d_p = capi.DeviceBuffer(dev, b * net.policy_len * 4)
+    eng.enqueue_packed_device(capi.DeviceBuffer.from_host(dev, bits), bits.shape[1],
+                              capi.DeviceBuffer.from_host(dev, scalars_in), b, d_s, d_p)
+    eng.synchronize()
+    assert_f32(d_s.to_host(np.float32, (b, 5)), s_gold, "packed device scalars")
+    assert_f32(d_p.to_host(np.float32, (b, net.policy_len)), p_gold, "packed device policy")
+    eng.enqueue_dense_device(capi.DeviceBuffer.from_host(dev, x), b, d_s, d_p)
+    eng.synchronize()
+    assert_f32(d_p.to_host(np.float32, (b, net.policy_len)), p_gold, "dense device policy")
+
+
+def test_config_a1_ataxx_8x128_f32_batch256(dev):
+    """BASELINE.json configs[1]: Ataxx 7x7, 8-block x 128ch ResNet fp32, executor batch 256 — vs the oracle."""
+    blob = synth.random_model("ataxx-7", 8, 128, "ataxx_conv", seed=11)
+    bits, scalars_in = synth.random_boards("ataxx-7", 256, seed=12)
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F32)
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert_f32(s, s_ref, "scalars")
+    assert_f32(p, p_ref, "policy")
+    # the same through f16, with the stated f16 tolerance
+    eng16 = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F16)
+    s16, p16 = eng16.eval_packed(bits, scalars_in)
+    assert_f16(s16, s_ref, "f16 scalars")
+    assert_f16(p16, p_ref, "f16 policy")
+
+
+@pytest.fixture(scope="module")
+def chess_full():
+    blob = synth.random_model("chess", 20, 256, "attention", seed=21)
+    bits, scalars_in = synth.random_boards("chess", 256, seed=22)
+    return blob, bits, scalars_in
+
+
+def test_config_c1_chess_20x256_f16_vs_oracle_sample(dev, chess_full):
+    """BASELINE.json configs[2] at full size; the oracle checks a sample of boards (it needs ~1 s per board)."""
+    blob, bits, scalars_in = chess_full
+    net = O.OracleNet(blob)
+    pick = np.array([0, 1, 63, 64, 127, 128, 200, 255])
+    dense = O.encode_input_full(bits[pick], scalars_in[pick], net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F16)
+    s, p = eng.eval_packed(bits, scalars_in)
+    print("tower path:", eng.tower_path, "max |dlogit|", np.abs(p[pick] - p_ref).max(), "max |dscalar|",
+          np.abs(s[pick] - s_ref).max())
+    assert_f16(s[pick], s_ref, "scalars")
+    assert_f16(p[pick], p_ref, "policy")
+    assert np.abs(softmax(p[pick]) - softmax(p_ref)).max() < 2e-3
+
+
+def test_config_c1_f32_vs_oracle_sample(dev, chess_full):
+    blob, bits, scalars_in = chess_full
+    net = O.OracleNet(blob)
+    pick = np.array([3, 100, 254])
+    dense = O.encode_input_full(bits[pick], scalars_in[pick], net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F32)
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert_f32(s[pick], s_ref, "scalars")
+    assert_f32(p[pick], p_ref, "policy")
+
+
+def test_full_size_properties(dev, chess_full):
+    """Size-independent properties at the full configuration: permutation equivariance over the batch,
+    batch-size invariance, determinism, and agreement of the board-resident tower with the generic per-layer path."""
+    blob, bits, scalars_in = chess_full
+    model = capi.Model(blob=blob)
+    eng = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert np.isfinite(s).all() and np.isfinite(p).all()
+    s2, p2 = eng.eval_packed(bits, scalars_in)
+    assert np.array_equal(s, s2) and np.array_equal(p, p2), "not deterministic"
+    perm = np.random.default_rng(5).permutation(256)
+    sp, pp = eng.eval_packed(bits[perm], scalars_in[perm])
+    assert np.array_equal(sp, s[perm]) and np.array_equal(pp, p[perm]), "not permutation equivariant"
+    s7, p7 = eng.eval_packed(bits[:7], scalars_in[:7])
+    assert np.array_equal(s7, s[:7]) and np.array_equal(p7, p[:7]), "result depends on the batch size"
+    if eng.tower_path == "tower_resident_f16":
+        os.environ["KZ_FORCE_GENERIC"] = "1"
+        try:
+            gen = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+        finally:
+            del os.environ["KZ_FORCE_GENERIC"]
+        assert gen.tower_path == "conv_igemm_f16"
+        sg, pg = gen.eval_packed(bits, scalars_in)
+        # both are f16-storage/f32-accumulate; they differ only in summation order
+        assert np.abs(sg - s).max() < 2e-2 and np.abs(pg - p).max() < 2e-2
+
+
+def test_go19_generic_path_vs_oracle(dev):
+    """Large board (19x19, 13 input planes, conv head + pass move): the per-layer implicit-GEMM path."""
+    blob = synth.random_model("go-19", 3, 64, "conv", seed=31)
+    bits, scalars_in = synth.random_boards("go-19", 5, seed=32)
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 8, capi.KZ_DTYPE_F32)
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert_f32(s, s_ref, "scalars")
+    assert_f32(p, p_ref, "policy")
+
+
+def test_profiling_reports_kernel_time(dev):
+    blob = O.load_blob("ataxx7_4x64")
+    net = O.OracleNet(blob)
+    bits, scalars_in = O.read_packed("ataxx7_4x64", net.n_bool, net.n_scalar, net.h, net.w)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 2, capi.KZ_DTYPE_F32)
+    eng.set_profiling(True)
+    eng.eval_packed(bits, scalars_in)
+    total, n = eng.kernel_time("kz_conv_igemm")
+    assert n == 1 + 2 * 4 + 1 and total > 0  # stem + 2 per block + the policy head's 1x1
+    eng.set_profiling(False)
