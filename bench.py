@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — self-play NN evals/sec, Chess 20x256 ResNet, executor batch 256 (BASELINE.json metric).
+
+A "step" is one executor batch (256 synthetic packed boards, already resident in HBM) through the whole hot path:
+board encode -> ResNet tower -> scalar + attention-policy heads, outputs left in HBM.  evals/s = sum of batch lengths of
+completed evaluations / wall time — the reference's own `real` counter (rust/kz-selfplay/src/server/
+server_alphazero.rs:113-115, collector.rs:172-191).  Steps are issued round-robin over `--engines` executor engines per
+GPU (the reference's gpu_threads_per_device, rust/Readme.md:51), each with its own HIP stream.
+
+Multi-GPU: the path shards by game -> device with no collective (each device has its own job channel, server.rs:325-331):
+one process per GPU, every rank runs K steps on its own boards ("weak" scaling), value = all ranks' evals / max time.
+torch.distributed is only the control plane (barrier + max of the elapsed time) and runs on gloo: there is no tensor
+to exchange, so RCCL/xGMI stay idle by design.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="executor batch (gpu_batch_size)")
+    ap.add_argument("--engines", type=int, default=2, help="executor engines (streams) per GPU")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--workload", default="chess-20x256", choices=["chess-20x256", "ataxx-8x128", "go19-40x256"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    "chess-20x256": dict(game="chess", depth=20, channels=256, head="attention"),
+    "ataxx-8x128": dict(game="ataxx-7", depth=8, channels=128, head="ataxx_conv"),
+    "go19-40x256": dict(game="go-19", depth=40, channels=256, head="conv"),
+}
+
+
+def cpu_baseline(blob, bits, scalars_in, target_seconds):
+    """The CPU restatement (oracle, kind 'port') timed on this box's host cores, on a bounded sample of the same
+    boards.  Reported beside the GPU number; never the thing measured as `value`."""
+    import numpy as np
+    from tests import oracle_lib as O
+    net = O.OracleNet(blob)
+    cores = os.cpu_count() or 1
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    t0 = time.perf_counter()
+    net.forward(dense[:1], threads=1)
+    one = time.perf_counter() - t0
+    n = int(max(cores, min(len(dense), cores * max(1.0, target_seconds / max(one, 1e-3)) // 1)))
+    n = max(cores, (n // cores) * cores)
+    n = min(n, len(dense))
+    t0 = time.perf_counter()
+    net.forward(dense[:n], threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{n} boards of the same synthetic batch, oracle/kz_oracle.c f32 NCHW direct conv, "
+                      f"OpenMP over boards on {cores} threads, {dt:.1f} s; single-thread {1.0 / one:.3f} evals/s"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+
+    torch = None
+    dist = None
+    if distributed:
+        import torch  # noqa: F811  (control plane only)
+        import torch.distributed as dist  # noqa: F811
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import numpy as np
+    from kzero_amd import capi, synth
+
+    ndev = capi.device_count()
+    device = local_rank % max(ndev, 1)
+    dtype = capi.KZ_DTYPE_F16 if args.dtype == "f16" else capi.KZ_DTYPE_F32
+    wl = WORKLOADS[args.workload]
+
+    blob = synth.random_model(wl["game"], wl["depth"], wl["channels"], wl["head"], seed=0)
+    model = capi.Model(blob=blob)
+    info = model.info
+    B = args.batch
+    bits, scalars_in = synth.random_boards(wl["game"], B, seed=1000 + rank)
+
+    engines = [capi.Engine(model, device, B, dtype) for _ in range(args.engines)]
+    d_bits = capi.DeviceBuffer.from_host(device, bits)
+    d_sin = capi.DeviceBuffer.from_host(device, scalars_in)
+    outs = [(capi.DeviceBuffer(device, B * 5 * 4), capi.DeviceBuffer(device, B * info.policy_len * 4))
+            for _ in engines]
+    stride = bits.shape[1]
+
+    def step(i):
+        e = i % len(engines)
+        engines[e].enqueue_packed_device(d_bits, stride, d_sin, B, outs[e][0], outs[e][1])
+
+    def sync_all():
+        for e in engines:
+            e.synchronize()
+        capi.check(capi.load().kz_device_synchronize(device))
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+
+    for e in engines:
+        e.set_profiling(True)
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel, timed with HIP events on the engines' own streams over the timed region
+    tower_path = engines[0].tower_path
+    kname = {"tower_resident_f16": "kz_tower_resident_f16", "conv_igemm_f16": "kz_conv_igemm_f16",
+             "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
+    k_ms, k_n = 0.0, 0
+    for e in engines:
+        ms, n = e.kernel_time(kname)
+        k_ms += ms
+        k_n += n
+        e.set_profiling(False)
+
+    # sanity: outputs are finite numbers
+    s_host = outs[0][0].to_host(np.float32, (B, 5))
+    assert np.isfinite(s_host).all(), "non-finite network output"
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_evals = args.steps * B * world
+    value = total_evals / elapsed
+    hw = info.board_h * info.board_w
+    C = info.tower_channels
+    tower_flops = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
+    if tower_path == "tower_resident_f16":
+        flops_per_launch = tower_flops * B  # one launch = the whole tower for one batch
+    else:
+        # per-layer launches (tower + the 1x1 head convolutions that share the kernel): average over the step
+        head_flops = info.flops_per_eval - tower_flops
+        launches_per_step = k_n / max(args.steps, 1)
+        flops_per_launch = (tower_flops + head_flops) * B / max(launches_per_step, 1)
+    peak = 2500.0 if args.dtype == "f16" else 157.3
+    avg_ms = k_ms / max(k_n, 1)
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if k_n else 0.0
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                "launches": k_n, "flop_per_launch": flops_per_launch,
+                "whole_path_frac": round(value / world * info.flops_per_eval / 1e12 / peak, 4)}
+
+    out = {
+        "metric": "self-play NN evals/sec (node), Chess 20x256 ResNet b=256, 1/2/4/8 GPU",
+        "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, packed boards resident in HBM",
+                   "engines_per_gpu": args.engines, "tower_path": tower_path, "parallelism": f"dp{world} (no collective)",
+                   "flop_per_eval": info.flops_per_eval},
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(blob, bits, scalars_in, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,11 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
         "policy_kind": head, "policy_len": g["policy_len"], "bn_eps": 1e-5,
     }
     _conv(rng, t, "common.tower.0", C, n_scalar + n_bool, 3)
+    if game == "chess":
+        # the mapper feeds raw counters (repetitions 0..2, 50-move counter 0..99; chess.rs:153-154); a trained stem
+        # scales them down, an untrained one would let them dominate every activation
+        t["common.tower.0.weight"][:, 6] *= 0.5
+        t["common.tower.0.weight"][:, 7] *= 0.01
     for i in range(1, depth + 1):
         _conv(rng, t, f"common.tower.{i}.seq.0", C, C, 3)
         _bn(rng, t, f"common.tower.{i}.seq.1", C)
