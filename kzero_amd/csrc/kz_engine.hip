@@ -575,7 +575,8 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->cin_p = round_up(m.c_in, 32);
     e->cp = round_up(m.channels, 32);
     const char *force = getenv("KZ_FORCE_GENERIC");
-    e->resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth) && !(force && force[0] == '1');
+    e->resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth) && e->cin_p == 32 &&
+                  !(force && force[0] == '1');
     const char *keep = getenv("KZ_KEEP_ACTIVATIONS");
     e->keep = keep && keep[0] == '1' && !e->resident;
     e->path = e->resident ? "tower_resident_f16" : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
