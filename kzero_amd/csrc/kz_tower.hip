@@ -13,8 +13,11 @@
 //  * GEMM orientation D[oc][pixel] = W[oc][k] * X[k][pixel]: weights are the MFMA A operand, activations the B
 //    operand, so a lane ends up with 4 consecutive channels of one pixel and writes them to the NHWC LDS image with one
 //    ds_write_b64.  im2col exists only as LDS addressing: a tap outside the board reads a shared all-zero row.
-//  * LDS image: row = pixel (512 B = 256 f16), 16-byte chunk c of row p stored at chunk position c ^ (p & 15), which
-//    makes the ds_read_b128 fragment reads of 16 different pixels conflict-free.
+//  * LDS image: row = pixel, 512 B of channels + 16 B pad (row stride 528 B): the 16 pixel rows of a ds_read_b128
+//    fragment read land on 16 different 16-byte slots of the 256-byte bank row, and the k-step's channel chunk is a
+//    plain immediate offset.
+#include <type_traits>
+
 #include "kz_kernels.hpp"
 
 namespace kz {
@@ -27,7 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int C = 256;        // tower channels
-constexpr int ROW = C * 2;    // bytes per pixel row in LDS
+constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row: 512 B of channels + 16 B pad, so that the 16 rows of a
+                              // fragment read fall on 16 different 16-byte slots of the 256-byte bank row
 constexpr int KSTEPS = 72;    // 9 taps x 8 chunks of 32 channels
 constexpr int PF = 4;         // weight prefetch distance in k-steps (register stages)
 
@@ -44,14 +48,14 @@ struct Layout {
     static constexpr int M = NB * 64;
     static constexpr int MT = M / 16;
     static constexpr int X_OFF = 0;
-    static constexpr int Y_OFF = M * ROW;
-    static constexpr int Z_OFF = 2 * M * ROW;       // 512 zero bytes
-    static constexpr int S_OFF = Z_OFF + ROW;       // stem input, rows of 64 B (32 channels)
+    static constexpr int Y_OFF = M * RS;
+    static constexpr int Z_OFF = 2 * M * RS;        // 512 zero bytes (+ pad)
+    static constexpr int S_OFF = Z_OFF + RS;        // stem input, rows of 64 B (32 channels)
     static constexpr int BYTES = S_OFF + M * 64;
 };
 
-// LDS byte offset of 16-byte chunk c16 of pixel row p
-__device__ __forceinline__ int lds_chunk(int p, int c16) { return p * ROW + ((c16 ^ (p & 15)) << 4); }
+// LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
+constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
 template <int NB>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     }
 
     // ---- zero row and stem input ----
-    if (tid < 32) *reinterpret_cast<uint4 *>(lds + L::Z_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    if (tid < 33) *reinterpret_cast<uint4 *>(lds + L::Z_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
     for (int id = tid; id < M * 4; id += 256) {
         const int row = id >> 2, c = id & 3;
         const int board = board0 + (row >> 6);
@@ -89,47 +93,76 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     }
     __syncthreads();
 
+    // accumulators start at the bias: D = bias + W*X, so the epilogue has no add.  The bias of layer l+1 is fetched
+    // while layer l computes: a load that is consumed right away would make the compiler wait for vmcnt(0) and drain
+    // the weight prefetch ring once per layer.
     f32x4 acc[4][MT];
-    auto zero_acc = [&]() {
+    f32x4 bias_next[4];
+    auto fetch_bias = [&](int layer) {
+        const int l = layer <= layers ? layer : layers;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+            bias_next[nt] = *reinterpret_cast<const f32x4 *>(a.bias + l * C + wave * 64 + nt * 16 + kq * 4);
+    };
+    auto init_acc = [&]() {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int mt = 0; mt < MT; mt++) acc[nt][mt] = bias_next[nt];
+    };
+    f32x4 post_s[4], post_t[4];  // final BN, fetched at the start of the last layer
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+        post_s[nt] = f32x4{1.f, 1.f, 1.f, 1.f};
+        post_t[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ReLU on the bit pattern: negative floats are negative integers (no canonicalising v_max inserted)
+    auto relu4 = [](f32x4 v) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 b = __builtin_bit_cast(i32x4, v);
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = b[j] > 0 ? b[j] : 0;
+        return __builtin_bit_cast(f32x4, b);
     };
 
-    // epilogue: v = acc + bias; [relu]; [+ residual X]; [final BN]; -> f16 -> LDS image at dst_off
-    auto epilogue = [&](int layer, int dst_off, bool relu, bool residual, bool post) {
+    // this lane's slice of the LDS image: pixel row fr of tile 0, channels [64*wave + 4*kq, +4) of oc-tile 0
+    const int epi_base = fr * RS + (wave * 64 + kq * 4) * 2;
+    // epilogue: [relu]; [+ residual X]; [final BN]; -> f16 -> LDS image at dst_off.  Flags are compile-time.
+    auto epilogue = [&](int dst_off, auto relu, auto residual, auto post) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
-            const int oc = wave * 64 + nt * 16 + kq * 4;
-            const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias + layer * C + oc);
-            f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (post) {
-                ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-                pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
+            h16x4 rx[MT];
+            if constexpr (decltype(residual)::value) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    rx[mt] = *reinterpret_cast<const h16x4 *>(lds + L::X_OFF + epi_base + mt * 16 * RS + nt * 32);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                const int p = mt * 16 + fr;
-                const int off = lds_chunk(p, oc >> 3) + (kq & 1) * 8;
-                f32x4 v = acc[nt][mt] + bias;
-                if (relu) {
+                const int off = epi_base + mt * 16 * RS + nt * 32;
+                f32x4 v = acc[nt][mt];
+                if constexpr (decltype(relu)::value) v = relu4(v);
+                if constexpr (decltype(residual)::value) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j], 0.0f);
+                    for (int j = 0; j < 4; j++) v[j] += (float)rx[mt][j];
                 }
-                if (residual) {
-                    const h16x4 rx = *reinterpret_cast<const h16x4 *>(lds + L::X_OFF + off);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] += (float)rx[j];
-                }
-                if (post) v = v * ps + pt;
+                if constexpr (decltype(post)::value) v = v * post_s[nt] + post_t[nt];
                 *reinterpret_cast<h16x4 *>(lds + dst_off + off) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
             }
         }
     };
+    constexpr std::true_type YES{};
+    constexpr std::false_type NO{};
+
+    // tap validity per lane: the pixel of tile row fr is (y = 2*(mt&3) + (fr>>3), x = fr&7); these four lane masks
+    // combined with the (wave-uniform) tap give the invalid lanes without any per-lane arithmetic
+    const bool x_is0 = (lane & 7) == 0, x_is7 = (lane & 7) == 7, yo_is0 = (lane & 8) == 0, yo_is1 = !yo_is0;
 
     // ---- stem: 9 k-steps over the 32 (padded) input channels; conv + bias, no activation (post_act.py:205) ----
-    zero_acc();
+    fetch_bias(0);
+    init_acc();
+    fetch_bias(1);
     for (int tap = 0; tap < 9; tap++) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         h16x8 af[4];
@@ -138,11 +171,12 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
             const uint4 t = a.w_stem[((tap * 4 + wave) * 4 + nt) * 64 + lane];
             af[nt] = *reinterpret_cast<const h16x8 *>(&t);
         }
+        const bool kill_x = (dx < 0 && x_is0) || (dx > 0 && x_is7);
+        const bool kill_top = dy < 0 && yo_is0, kill_bot = dy > 0 && yo_is1;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
+            const bool ok = !(kill_x || ((mt & 3) == 0 && kill_top) || ((mt & 3) == 3 && kill_bot));
             const int p = mt * 16 + fr;
-            const int yy = ((p >> 3) & 7) + dy, xx = (p & 7) + dx;
-            const bool ok = (unsigned)yy < 8u && (unsigned)xx < 8u;
             const int off = ok ? L::S_OFF + (p + dy * 8 + dx) * 64 + kq * 16 : L::Z_OFF + kq * 16;
             const h16x8 bf = *reinterpret_cast<const h16x8 *>(lds + off);
 #pragma unroll
@@ -150,22 +184,22 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf, acc[nt][mt], 0, 0, 0);
         }
     }
-    epilogue(0, L::X_OFF, false, false, a.depth == 0);
+    epilogue(L::X_OFF, NO, NO, NO);
     __syncthreads();
 
     // ---- the 2*depth 3x3 convolutions ----
-    // per pixel-tile LDS address of this lane's fragment row for one tap; chunk bits are XORed in per k-step:
-    // chunk position (ch*4 + kq) ^ (q & 15) = ((ch ^ (q>>2 & 3)) << 2) | (kq ^ (q & 3))
+    // T[mt] = LDS address of this lane's fragment row (pixel shifted by the tap, 8 channels at kq) or of the zero row;
+    // the k-step's 32-channel chunk is an immediate offset (ch * 64 bytes)
+    const int frag_base = fr * RS + kq * 16;
     auto tap_rows = [&](int tap, int src_off, int (&T)[MT]) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const bool kill_x = (dx < 0 && x_is0) || (dx > 0 && x_is7);
+        const bool kill_top = dy < 0 && yo_is0, kill_bot = dy > 0 && yo_is1;
+        const int shifted = frag_base + src_off + (dy * 8 + dx) * RS;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const int p = mt * 16 + fr;
-            const int yy = ((p >> 3) & 7) + dy, xx = (p & 7) + dx;
-            const bool ok = (unsigned)yy < 8u && (unsigned)xx < 8u;
-            const int q = p + dy * 8 + dx;
-            const int t_ok = src_off + q * ROW + (((q >> 2) & 3) << 6) + ((kq ^ (q & 3)) << 4);
-            T[mt] = ok ? t_ok : L::Z_OFF + (kq << 4);
+            const bool ok = !(kill_x || ((mt & 3) == 0 && kill_top) || ((mt & 3) == 3 && kill_bot));
+            T[mt] = ok ? shifted + mt * 16 * RS : L::Z_OFF + (kq << 4);
         }
     };
 
@@ -173,7 +207,16 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     for (int layer = 1; layer <= layers; layer++) {
         const bool is_b = (layer & 1) == 0;  // conv A: X -> Y; conv B: Y -> X (+ residual)
         const int src_off = is_b ? L::Y_OFF : L::X_OFF;
-        zero_acc();
+        init_acc();
+        fetch_bias(layer + 1);
+        if (layer == layers) {
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const int oc = wave * 64 + nt * 16 + kq * 4;
+                post_s[nt] = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
+                post_t[nt] = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
+            }
+        }
         int T[MT], Tn[MT];
         h16x8 bf[2][MT];  // activation fragments, double buffered one k-step ahead
         tap_rows(0, src_off, T);
@@ -184,17 +227,14 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #pragma unroll
             for (int ch = 0; ch < 8; ch++) {
                 const int stage = ch & (PF - 1), cur = ch & 1, nxt = cur ^ 1;
-                // (1) next k-step's activation fragments: LDS -> registers
-                if (ch < 7) {
+                // next k-step's activation fragments: LDS -> registers (after the last tap this re-reads tap 8,
+                // harmless and branch-free)
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++)
-                        bf[nxt][mt] = *reinterpret_cast<const h16x8 *>(lds + (T[mt] ^ ((ch + 1) << 6)));
-                } else if (tap < 8) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++) bf[nxt][mt] = *reinterpret_cast<const h16x8 *>(lds + Tn[mt]);
-                }
-                // (2) this k-step's weight fragments were loaded PF k-steps ago; refill the stage with k-step g + PF
-                //     (clamped at the end of the stream; the surplus loads are never used)
+                for (int mt = 0; mt < MT; mt++)
+                    bf[nxt][mt] = ch < 7 ? *reinterpret_cast<const h16x8 *>(lds + T[mt] + (ch + 1) * 64)
+                                         : *reinterpret_cast<const h16x8 *>(lds + Tn[mt]);
+                // this k-step's weight fragments were loaded PF k-steps ago; refill the stage with k-step g + PF
+                // (clamped at the end of the stream; the surplus loads are never used)
                 h16x8 af[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
@@ -203,29 +243,43 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++) wreg[stage][nt] = wp[(size_t)gn * 1024 + nt * 64];
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                // (3) 4 x MT MFMAs on independent accumulators
+                // 4 x MT MFMAs on independent accumulators
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[cur][mt], acc[nt][mt], 0, 0, 0);
+                // issue order: the LDS reads and the weight loads ride in the shadow of the MFMAs
+                constexpr int PER = (4 * MT) / (MT + 4) >= 2 ? 2 : 1;  // MFMAs per memory instruction
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, PER, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, PER, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4 * MT - PER * (MT + 4), 0);
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) T[mt] = Tn[mt];
         }
-        epilogue(layer, is_b ? L::X_OFF : L::Y_OFF, true, is_b, layer == layers);
+        if (!is_b) epilogue(L::Y_OFF, YES, NO, NO);
+        else if (layer != layers) epilogue(L::X_OFF, YES, YES, NO);
+        else epilogue(L::X_OFF, YES, YES, YES);
         __syncthreads();
     }
 
-    // ---- write the tower output: un-swizzle, coalesced 16-byte stores ----
+    // ---- write the tower output: coalesced 16-byte stores ----
     for (int id = tid; id < M * 32; id += 256) {
         const int p = id >> 5, c16 = id & 31;
         const int board = board0 + (p >> 6);
         if (board < a.batch) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(lds + L::X_OFF + lds_chunk(p, c16));
+            const uint4 v = *reinterpret_cast<const uint4 *>(lds + L::X_OFF + p * RS + c16 * 16);
             *reinterpret_cast<uint4 *>(a.y + ((size_t)board0 * 64 + p) * C + c16 * 8) = v;
         }
     }
