@@ -49,8 +49,8 @@ struct Layout {
     static constexpr int MT = M / 16;
     static constexpr int X_OFF = 0;
     static constexpr int Y_OFF = M * RS;
-    static constexpr int Z_OFF = 2 * M * RS;        // 512 zero bytes (+ pad)
-    static constexpr int S_OFF = Z_OFF + RS;        // stem input, rows of 64 B (32 channels)
+    static constexpr int Z_OFF = 2 * M * RS;        // 16 all-zero rows (what a tap outside the board reads)
+    static constexpr int S_OFF = Z_OFF + 16 * RS;   // stem input, rows of 64 B (32 channels)
     static constexpr int BYTES = S_OFF + M * 64;
 };
 
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     }
 
     // ---- zero row and stem input ----
-    if (tid < 33) *reinterpret_cast<uint4 *>(lds + L::Z_OFF + tid * 16) = make_uint4(0, 0, 0, 0);
+    for (int id = tid; id < 16 * RS / 16; id += 256)
+        *reinterpret_cast<uint4 *>(lds + L::Z_OFF + id * 16) = make_uint4(0, 0, 0, 0);
     for (int id = tid; id < M * 4; id += 256) {
         const int row = id >> 2, c = id & 3;
         const int board = board0 + (row >> 6);
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         for (int mt = 0; mt < MT; mt++) {
             const bool ok = !(kill_x || ((mt & 3) == 0 && kill_top) || ((mt & 3) == 3 && kill_bot));
             const int p = mt * 16 + fr;
-            const int off = ok ? L::S_OFF + (p + dy * 8 + dx) * 64 + kq * 16 : L::Z_OFF + kq * 16;
+            const int off = ok ? L::S_OFF + (p + dy * 8 + dx) * 64 + kq * 16 : L::Z_OFF + kq * 16;  // stem: natural k
             const h16x8 bf = *reinterpret_cast<const h16x8 *>(lds + off);
 #pragma unroll
             for (int nt = 0; nt < 4; nt++)
@@ -188,18 +189,25 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     __syncthreads();
 
     // ---- the 2*depth 3x3 convolutions ----
-    // T[mt] = LDS address of this lane's fragment row (pixel shifted by the tap, 8 channels at kq) or of the zero row;
-    // the k-step's 32-channel chunk is an immediate offset (ch * 64 bytes)
-    const int frag_base = fr * RS + kq * 16;
+    // T[mt] = LDS address of this lane's fragment row (pixel shifted by the tap) or of a zero row.
+    // Channel assignment of a k-step: lane group kq reads the 16-byte chunk at 256*(kq&1) + 128*(kq>>1) + 16*ch of the
+    // row, i.e. k-step ch covers channels {8ch..8ch+7} + {0, 128, 64, 192}[kq].  The two kq groups that share a
+    // ds_read_b128 bank group are then exactly 256 B (one bank row) apart, and with the 16-byte row pad the 16 pixel
+    // rows of a fragment read hit 16 different slots: conflict-free for every tap.  (The k order of a sum is free as
+    // long as the weights are packed with the same assignment: tower_pack_weights.)  Lanes whose tap falls outside the
+    // board read zero row (q & 15), which keeps the same slot pattern.
+    const int kq_off = 256 * (kq & 1) + 128 * (kq >> 1);
+    const int frag_base = fr * RS + kq_off;
     auto tap_rows = [&](int tap, int src_off, int (&T)[MT]) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const bool kill_x = (dx < 0 && x_is0) || (dx > 0 && x_is7);
         const bool kill_top = dy < 0 && yo_is0, kill_bot = dy > 0 && yo_is1;
         const int shifted = frag_base + src_off + (dy * 8 + dx) * RS;
+        const int zrow = L::Z_OFF + ((fr + dy * 8 + dx) & 15) * RS + kq_off;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const bool ok = !(kill_x || ((mt & 3) == 0 && kill_top) || ((mt & 3) == 3 && kill_bot));
-            T[mt] = ok ? shifted + mt * 16 * RS : L::Z_OFF + (kq << 4);
+            T[mt] = ok ? shifted + mt * 16 * RS : zrow;
         }
     };
 
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 // harmless and branch-free)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
-                    bf[nxt][mt] = ch < 7 ? *reinterpret_cast<const h16x8 *>(lds + T[mt] + (ch + 1) * 64)
+                    bf[nxt][mt] = ch < 7 ? *reinterpret_cast<const h16x8 *>(lds + T[mt] + (ch + 1) * 16)
                                          : *reinterpret_cast<const h16x8 *>(lds + Tn[mt]);
                 // this k-step's weight fragments were loaded PF k-steps ago; refill the stage with k-step g + PF
                 // (clamped at the end of the stream; the surplus loads are never used)
@@ -305,9 +313,12 @@ size_t tower_packed_weight_elems(int cin_p, int depth) {
 }
 
 // OIHW f32 -> [tap 9][chunk cin_p/32][wave 4][nt 4][lane 64][8] f16: element j of lane (fr, kq) of (wave, nt) is
-// W[oc = 64*wave + 16*nt + fr][channel = 32*chunk + 8*kq + j][tap] — the A fragment of v_mfma_f32_16x16x32_f16.
+// W[oc = 64*wave + 16*nt + fr][channel][tap] — the A fragment of v_mfma_f32_16x16x32_f16 — where the k-step's channel
+// assignment is the kernel's: cin_p == 256: channel = 8*chunk + {0,128,64,192}[kq] + j (bank-conflict-free LDS reads);
+// stem (cin_p == 32): channel = 8*kq + j.
 void tower_pack_weights(const float *oihw, int cout, int cin, int cin_p, uint16_t *dst) {
     const int nchunk = cin_p / 32;
+    static const int kq_base[4] = {0, 128, 64, 192};
     for (int tap = 0; tap < 9; tap++)
         for (int chunk = 0; chunk < nchunk; chunk++)
             for (int wave = 0; wave < 4; wave++)
@@ -315,7 +326,8 @@ void tower_pack_weights(const float *oihw, int cout, int cin, int cin_p, uint16_
                     for (int lane = 0; lane < 64; lane++)
                         for (int j = 0; j < 8; j++) {
                             const int oc = 64 * wave + 16 * nt + (lane & 15);
-                            const int ch = 32 * chunk + 8 * (lane >> 4) + j;
+                            const int kq = lane >> 4;
+                            const int ch = cin_p == 256 ? 8 * chunk + kq_base[kq] + j : 32 * chunk + 8 * kq + j;
                             float v = 0.0f;
                             if (oc < cout && ch < cin) v = oihw[((size_t)oc * cin + ch) * 9 + tap];
                             const _Float16 hv = (_Float16)v;
