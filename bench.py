@@ -69,17 +69,12 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
 
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-
+    from kzero_amd import benchlib
+    rank, local_rank, world, distributed = benchlib.rank_info()
     torch = None
-    dist = None
     if distributed:
-        import torch  # noqa: F811  (control plane only)
-        import torch.distributed as dist  # noqa: F811
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import torch  # noqa: F811  (control plane only; imported before the HIP library on purpose)
+    dist = benchlib.init_control_plane()
 
     import numpy as np
     from kzero_amd import capi, synth
@@ -93,7 +88,7 @@ def main():
     model = capi.Model(blob=blob)
     info = model.info
     B = args.batch
-    bits, scalars_in = synth.random_boards(wl["game"], B, seed=1000 + rank)
+    bits, scalars_in = synth.random_boards(wl["game"], B, seed=benchlib.board_seed(rank))
 
     engines = [capi.Engine(model, device, B, dtype) for _ in range(args.engines)]
     d_bits = capi.DeviceBuffer.from_host(device, bits)
@@ -113,27 +108,11 @@ def main():
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    sync_all()
+    def start_profiling():
+        for e in engines:
+            e.set_profiling(True)
 
-    for e in engines:
-        e.set_profiling(True)
-    if dist is not None:
-        dist.barrier()
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = benchlib.run_timed(step, sync_all, args.steps, args.warmup, dist, on_timed_start=start_profiling)
 
     # dominant kernel, timed with HIP events on the engines' own streams over the timed region
     tower_path = engines[0].tower_path
@@ -155,8 +134,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_evals = args.steps * B * world
-    value = total_evals / elapsed
+    value = benchlib.whole_job_value(args.steps, B, world, elapsed)
     hw = info.board_h * info.board_w
     C = info.tower_channels
     tower_flops = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
