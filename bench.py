@@ -116,8 +116,8 @@ def main():
 
     # dominant kernel, timed with HIP events on the engines' own streams over the timed region
     tower_path = engines[0].tower_path
-    kname = {"tower_resident_f16": "kz_tower_resident_f16", "conv_igemm_f16": "kz_conv_igemm_f16",
-             "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
+    kname = {"tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
+             "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
     k_ms, k_n = 0.0, 0
     for e in engines:
         ms, n = e.kernel_time(kname)
@@ -138,7 +138,9 @@ def main():
     hw = info.board_h * info.board_w
     C = info.tower_channels
     tower_flops = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
-    if tower_path == "tower_resident_f16":
+    if tower_path == "tower_resident_f16+heads":
+        flops_per_launch = info.flops_per_eval * B  # one launch = tower + heads for one batch
+    elif tower_path == "tower_resident_f16":
         flops_per_launch = tower_flops * B  # one launch = the whole tower for one batch
     else:
         # per-layer launches (tower + the 1x1 head convolutions that share the kernel): average over the step

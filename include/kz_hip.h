@@ -114,7 +114,8 @@ int kz_device_synchronize(int device);
  * profiling was last enabled (it synchronizes the stream first). */
 int kz_engine_set_profiling(kz_engine *engine, int enable);
 int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_ms, int64_t *launches);
-/* Name of the path the engine chose for the tower ("tower_resident_f16", "conv_igemm_f16", "conv_igemm_f32"). */
+/* Name of the path the engine chose: "tower_resident_f16+heads" (whole network in one launch), "tower_resident_f16",
+ * "conv_igemm_f16" or "conv_igemm_f32" (per-layer launches). */
 const char *kz_engine_tower_path(const kz_engine *engine);
 
 /* ---- debugging / parity: copy an intermediate activation of the last evaluation to the host as f32 NCHW.

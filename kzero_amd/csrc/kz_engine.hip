@@ -68,9 +68,10 @@ struct DeviceWeights {
     float *post_scale = nullptr, *post_shift = nullptr;
 
     // resident tower
-    bool resident = false;
+    bool resident = false, fused_heads = false;
     void *res_w_stem = nullptr, *res_w_tower = nullptr;
     float *res_bias = nullptr;
+    int32_t *att_idx = nullptr;
 
     // scalar head
     float *sh_w0 = nullptr, *sh_b0 = nullptr, *sh_w1 = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
@@ -159,10 +160,11 @@ struct DeviceWeights {
         return upload_f32(b, &d.b);
     }
 
-    int build(const Model &m, bool want_resident) {
+    int build(const Model &m, bool want_resident, bool want_fused) {
         const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
         HIP_TRY(hipSetDevice(device));
         resident = want_resident;
+        fused_heads = want_resident && want_fused;
 
         std::vector<float> ps(cp, 1.0f), pt(cp, 0.0f);
         for (int i = 0; i < C; i++) {
@@ -174,15 +176,23 @@ struct DeviceWeights {
         if (resident) {
             const int cin_p = round_up(m.c_in, 32);
             const size_t stem_elems = (size_t)9 * 256 * cin_p, layer_elems = (size_t)9 * 256 * 256;
-            std::vector<uint16_t> stem(stem_elems), rest(layer_elems * 2 * m.depth);
+            const size_t head_elems = fused_heads ? kz::tower_heads_weight_elems() : 0;
+            std::vector<uint16_t> stem(stem_elems), rest(layer_elems * 2 * m.depth + head_elems);
             kz::tower_pack_weights(m.tower[0].w.data(), C, m.c_in, cin_p, stem.data());
             for (int l = 0; l < 2 * m.depth; l++)
                 kz::tower_pack_weights(m.tower[1 + l].w.data(), C, C, 256, rest.data() + layer_elems * l);
-            if (upload(stem.data(), stem.size() * 2, &res_w_stem)) return 1;
-            if (upload(rest.data(), rest.size() * 2, &res_w_tower)) return 1;
-            std::vector<float> bias((size_t)(1 + 2 * m.depth) * 256);
+            std::vector<float> bias((size_t)(1 + 2 * m.depth + (fused_heads ? 5 : 0)) * 256);
             for (int l = 0; l < 1 + 2 * m.depth; l++)
                 for (int o = 0; o < 256; o++) bias[(size_t)l * 256 + o] = m.tower[l].b[o];
+            if (fused_heads) {
+                kz::tower_pack_heads(m.p_bulk.w.data(), m.p_bulk.b.data(), m.p_under.w.data(), m.p_under.b.data(),
+                                     rest.data() + layer_elems * 2 * m.depth, bias.data() + (size_t)(1 + 2 * m.depth) * 256);
+                std::vector<int32_t> idx(m.flat_to_att.size());
+                for (size_t i = 0; i < idx.size(); i++) idx[i] = (m.flat_to_att[i] / 88) * 96 + m.flat_to_att[i] % 88;
+                if (upload(idx.data(), idx.size() * 4, (void **)&att_idx)) return 1;
+            }
+            if (upload(stem.data(), stem.size() * 2, &res_w_stem)) return 1;
+            if (upload(rest.data(), rest.size() * 2, &res_w_tower)) return 1;
             if (upload_f32(bias, &res_bias)) return 1;
         } else {
             tower.resize(m.tower.size());
@@ -195,6 +205,7 @@ struct DeviceWeights {
             upload_f32(m.sh_fc0.b, &sh_b1) || upload_f32(m.sh_fc1.w, &sh_w2) || upload_f32(m.sh_fc1.b, &sh_b2))
             return 1;
 
+        if (fused_heads) return 0;  // the policy head lives in the tower's weight stream
         switch (m.policy_kind) {
             case kz::POLICY_ATAXX_CONV:
             case kz::POLICY_CONV:
@@ -231,7 +242,7 @@ struct DeviceWeights {
 };
 
 std::mutex g_cache_mutex;
-std::map<std::tuple<const Model *, int, int, bool>, std::weak_ptr<DeviceWeights>> g_cache;
+std::map<std::tuple<const Model *, int, int, bool, bool>, std::weak_ptr<DeviceWeights>> g_cache;
 
 struct Prof {
     struct Rec {
@@ -287,7 +298,7 @@ struct kz_engine {
     size_t esz = 4;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs, pinned;
-    bool resident = false;
+    bool resident = false, fused_heads = false;
     std::string path;
 
     // activations
@@ -354,7 +365,7 @@ struct kz_engine {
         return 0;
     }
 
-    int run_tower(int batch) {
+    int run_tower(int batch, float *d_scalars, float *d_policy) {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         if (resident) {
@@ -362,6 +373,10 @@ struct kz_engine {
             t.x0 = x_in; t.cin_p = cin_p; t.w_stem = wts->res_w_stem; t.w_tower = wts->res_w_tower;
             t.bias = wts->res_bias; t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
             t.y = act[0]; t.batch = batch; t.h = m.h; t.w = m.w; t.depth = m.depth;
+            t.fused_heads = fused_heads;
+            t.sh_w0 = wts->sh_w0; t.sh_b0 = wts->sh_b0; t.sh_w1 = wts->sh_w1; t.sh_b1 = wts->sh_b1;
+            t.sh_w2 = wts->sh_w2; t.sh_b2 = wts->sh_b2; t.att_idx = wts->att_idx;
+            t.scalars = d_scalars; t.policy = d_policy;
             prof.begin("kz_tower_resident_f16", stream);
             kz::launch_tower_resident(t, stream);
             prof.end(stream);
@@ -390,6 +405,7 @@ struct kz_engine {
     }
 
     int run_heads(int batch, float *d_scalars, float *d_policy) {
+        if (fused_heads) return 0;  // written by the tower launch
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         const void *x = act[tower_out];
@@ -469,7 +485,7 @@ struct kz_engine {
                                  m.n_bool, m.h * m.w, x_in, cin_p, stream);
         prof.end(stream);
         HIP_TRY(hipGetLastError());
-        if (run_tower(batch)) return 1;
+        if (run_tower(batch, (float *)d_sout, (float *)d_pol)) return 1;
         return run_heads(batch, (float *)d_sout, (float *)d_pol);
     }
 
@@ -479,7 +495,7 @@ struct kz_engine {
         kz::launch_encode_dense(dtype, (const float *)d_nchw, batch, m.c_in, m.h * m.w, x_in, cin_p, stream);
         prof.end(stream);
         HIP_TRY(hipGetLastError());
-        if (run_tower(batch)) return 1;
+        if (run_tower(batch, (float *)d_sout, (float *)d_pol)) return 1;
         return run_heads(batch, (float *)d_sout, (float *)d_pol);
     }
 };
@@ -577,20 +593,28 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     const char *force = getenv("KZ_FORCE_GENERIC");
     e->resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth) && e->cin_p == 32 &&
                   !(force && force[0] == '1');
+    const char *nofuse = getenv("KZ_NO_FUSED_HEADS");
+    e->fused_heads = e->resident && !(nofuse && nofuse[0] == '1') &&
+                     kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,
+                                               m.sh_fc0.out);
     const char *keep = getenv("KZ_KEEP_ACTIVATIONS");
     e->keep = keep && keep[0] == '1' && !e->resident;
     e->path = e->resident ? "tower_resident_f16" : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
+    if (getenv("KZ_NO_FUSED_HEADS") == nullptr || getenv("KZ_NO_FUSED_HEADS")[0] != '1')
+        if (e->resident && kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len,
+                                                      m.sh_conv.cout, m.sh_fc0.out))
+            e->path = "tower_resident_f16+heads";
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident);
+        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident, e->fused_heads);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) e->wts = it->second.lock();
         if (!e->wts) {
             auto w = std::make_shared<DeviceWeights>();
             w->device = device;
             w->dtype = dtype;
-            if (w->build(m, e->resident)) return 1;
+            if (w->build(m, e->resident, e->fused_heads)) return 1;
             g_cache[key] = w;
             e->wts = w;
         }
@@ -605,7 +629,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     // head temporaries
     size_t h0 = 0, h1 = 0;
     const DeviceWeights &w = *e->wts;
-    switch (m.policy_kind) {
+    if (!e->fused_heads) switch (m.policy_kind) {
         case kz::POLICY_ATAXX_CONV:
         case kz::POLICY_CONV: h0 = rows * w.p_conv0.cout_p; break;
         case kz::POLICY_ATTENTION:

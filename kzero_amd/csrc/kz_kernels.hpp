@@ -100,11 +100,21 @@ struct TowerArgs {
     const void *w_tower;  // fragment-packed weights of the 2*depth 3x3 convs
     const float *bias;    // [1 + 2*depth][256]
     const float *post_scale, *post_shift;  // final BN [256]
-    void *y;              // tower output [batch*hw][256] f16
+    void *y;              // tower output [batch*hw][256] f16 (unused with fused heads)
     int batch, h, w, depth;
+    // fused chess heads (ScalarHead + AttentionPolicyHead): the launch writes scalars/policy instead of y
+    bool fused_heads;
+    const float *sh_w0, *sh_b0, *sh_w1, *sh_b1, *sh_w2, *sh_b2;
+    const int32_t *att_idx;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
+    float *scalars, *policy;
 };
 bool tower_resident_supported(int dtype, int h, int w, int channels, int depth);
+bool tower_heads_supported(int policy_kind, int query_channels, int policy_len, int sh_channels, int sh_size);
 size_t tower_packed_weight_elems(int cin_p, int depth);
+size_t tower_heads_weight_elems();
+// heads part of the weight stream (appended after the tower layers) and its 5 x 256 bias rows
+void tower_pack_heads(const float *w_bulk, const float *b_bulk, const float *w_under, const float *b_under,
+                      uint16_t *dst, float *bias5);
 // host-side packing: OIHW f32 (BN folded) -> MFMA A-fragment order f16; dst index for conv layer l (0 = stem)
 void tower_pack_weights(const float *oihw, int cout, int cin, int cin_p, uint16_t *dst);
 void launch_tower_resident(const TowerArgs &a, hipStream_t stream);

@@ -1,22 +1,27 @@
-// kz_tower.hip — board-resident ResTower: the whole tower (stem + 2*depth fused 3x3 convolutions + final BN) in ONE
-// launch.  Replaces the ~41 cuDNN `cudnnConvolutionBiasActivationForward` launches of the reference's GPU path
-// (docs/conv_bn_sm_flow.svg) for 8x8 boards with 256 channels in f16.
+// kz_tower.hip — board-resident ResTower (+ fused chess heads): the whole tower (stem + 2*depth fused 3x3
+// convolutions + final BN) and, for the attention-policy chess network, the ScalarHead and AttentionPolicyHead, in ONE
+// launch.  Replaces the ~45 cuDNN/NVRTC launches of the reference's GPU path (docs/conv_bn_sm_flow.svg; SURVEY.md
+// §2.2 F1-F6) for 8x8 boards with 256 channels in f16.
 //
-// Why this shape (MI355X-first, see DESIGN.md §Kernels):
+// Why this shape (MI355X-first, see DESIGN.md §5):
 //  * Boards are independent and an 8x8x256 f16 board is 32 KB, so a workgroup keeps NB boards' residual stream (X) and
 //    mid activation (Y) in LDS for the whole tower: activations never touch HBM between layers, there is no launch
 //    boundary between layers and no inter-workgroup communication at all.
 //  * The only stream is the weights (1.18 MB per layer).  They are read from L2 straight into MFMA A-fragment
 //    registers: the host packs them in fragment order, so a wave-instruction is one coalesced 1 KiB global_load_dwordx4
 //    and weights never pass through LDS.  Each wave owns 64 output channels (no weight byte is loaded twice per CU).
-//    Loads run PF k-steps ahead of the MFMAs, across layer boundaries.
+//    Loads run PF k-steps ahead of the MFMAs, across layer boundaries and into the heads.
 //  * GEMM orientation D[oc][pixel] = W[oc][k] * X[k][pixel]: weights are the MFMA A operand, activations the B
 //    operand, so a lane ends up with 4 consecutive channels of one pixel and writes them to the NHWC LDS image with one
-//    ds_write_b64.  im2col exists only as LDS addressing: a tap outside the board reads a shared all-zero row.
-//  * LDS image: row = pixel, 512 B of channels + 16 B pad (row stride 528 B): the 16 pixel rows of a ds_read_b128
-//    fragment read land on 16 different 16-byte slots of the 256-byte bank row, and the k-step's channel chunk is a
-//    plain immediate offset.
+//    ds_write_b64.  im2col exists only as LDS addressing: a tap outside the board reads an all-zero row.
+//  * LDS image: row = pixel, 512 B of channels + 16 B pad (row stride 528 B), and a k-step's channel assignment is
+//    permuted so that every ds_read_b128 fragment read is bank-conflict-free (see frag_base below).
+//  * Heads (post_act.py:10-23, 115-141) run on the LDS-resident tower output: conv_under and conv_bulk are more passes
+//    of the same weight stream, q_from^T q_to is MFMA on LDS operands, the 1880-entry gather and the scalar head write
+//    the only HBM output of the launch (7.5 KB per board).
+#include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "kz_kernels.hpp"
 
@@ -29,11 +34,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int C = 256;        // tower channels
+constexpr int C = 256;          // tower channels (= attention query channels in the fused-heads variant)
 constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row: 512 B of channels + 16 B pad, so that the 16 rows of a
-                              // fragment read fall on 16 different 16-byte slots of the 256-byte bank row
-constexpr int KSTEPS = 72;    // 9 taps x 8 chunks of 32 channels
-constexpr int PF = 4;         // weight prefetch distance in k-steps (register stages)
+                                // fragment read fall on 16 different 16-byte slots of the 256-byte bank row
+constexpr int URS = 3 * C * 2 + 16;  // row stride of the conv_under image (768 channels)
+constexpr int KSTEPS = 72;      // 9 taps x 8 chunks of 32 channels
+constexpr int HEAD_KSTEPS = 5 * 8;  // conv_under as 3 passes of 256 channels, conv_bulk as 2: 8 k-steps each
+constexpr int PF = 4;           // weight prefetch distance in k-steps (register stages)
+constexpr int POLICY = 1880, LOGIT_LD = 96;  // 64 x 88 attention logits, rows padded to 96
 
 struct TowerDev {
     const h16 *x0;
@@ -41,6 +49,10 @@ struct TowerDev {
     const float *bias, *post_scale, *post_shift;
     h16 *y;
     int cin_p, batch, depth;
+    // fused heads
+    const float *sh_w0, *sh_b0, *sh_w1, *sh_b1, *sh_w2, *sh_b2;
+    const int32_t *att_idx;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
+    float *scalars, *policy;
 };
 
 template <int NB>
@@ -51,13 +63,22 @@ struct Layout {
     static constexpr int Y_OFF = M * RS;
     static constexpr int Z_OFF = 2 * M * RS;        // 16 all-zero rows (what a tap outside the board reads)
     static constexpr int S_OFF = Z_OFF + 16 * RS;   // stem input, rows of 64 B (32 channels)
-    static constexpr int BYTES = S_OFF + M * 64;
+    static constexpr int TOWER_BYTES = S_OFF + M * 64;
+    // heads phase (the zero rows and the stem input are dead by then)
+    static constexpr int U_OFF = Z_OFF;             // conv_under image: 16 rows x URS
+    static constexpr int ACT_OFF = U_OFF + 16 * URS;  // scalar head: act [NB][256] f32, hid [NB][32] f32
+    static constexpr int HID_OFF = ACT_OFF + NB * 256 * 4;
+    static constexpr int HEADS_BYTES = HID_OFF + NB * 32 * 4;
+    static constexpr int LOG_OFF = Y_OFF;           // attention logits [NB][64][96] f32 (after q_from is consumed)
+    static constexpr int BYTES = TOWER_BYTES > HEADS_BYTES ? TOWER_BYTES : HEADS_BYTES;
+    static_assert(NB * 64 * LOGIT_LD * 4 <= M * RS, "logits fit the Y region");
+    static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 
 // LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
-template <int NB>
+template <int NB, bool HEADS>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     using L = Layout<NB>;
     constexpr int M = L::M, MT = L::MT;
@@ -69,7 +90,8 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     const int fr = lane & 15, kq = lane >> 4;
     const int board0 = blockIdx.x * NB;
     const int layers = 2 * a.depth;
-    const int total_ksteps = layers * KSTEPS;
+    const int total_ksteps = layers * KSTEPS + (HEADS ? HEAD_KSTEPS : 0);
+    const int bias_rows = layers + (HEADS ? 5 : 0);  // last valid row of the bias table
 
     // ---- weight stream: per k-step 16 KB = [wave 4][nt 4][lane 64] x 16 B; prime PF stages before anything else ----
     const uint4 *wp = a.w_tower + wave * 256 + lane;
@@ -80,8 +102,18 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) wreg[s][nt] = wp[(size_t)g * 1024 + nt * 64];
     }
+    int g = 0;  // global k-step index into the weight stream
+    // take this k-step's fragments out of ring stage `stage` and refill the stage with k-step g + PF (clamped at the
+    // end of the stream; the surplus loads are never used)
+    auto ring_take = [&](int stage, h16x8 (&af)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
+        const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wreg[stage][nt] = wp[(size_t)gn * 1024 + nt * 64];
+    };
 
-    // ---- zero row and stem input ----
+    // ---- zero rows and stem input ----
     for (int id = tid; id < 16 * RS / 16; id += 256)
         *reinterpret_cast<uint4 *>(lds + L::Z_OFF + id * 16) = make_uint4(0, 0, 0, 0);
     for (int id = tid; id < M * 4; id += 256) {
@@ -99,8 +131,8 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     // the weight prefetch ring once per layer.
     f32x4 acc[4][MT];
     f32x4 bias_next[4];
-    auto fetch_bias = [&](int layer) {
-        const int l = layer <= layers ? layer : layers;
+    auto fetch_bias = [&](int row) {
+        const int l = row <= bias_rows ? row : bias_rows;
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
             bias_next[nt] = *reinterpret_cast<const f32x4 *>(a.bias + l * C + wave * 64 + nt * 16 + kq * 4);
@@ -126,6 +158,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         for (int j = 0; j < 4; j++) b[j] = b[j] > 0 ? b[j] : 0;
         return __builtin_bit_cast(f32x4, b);
     };
+    auto to_h4 = [](f32x4 v) { return h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]}; };
 
     // this lane's slice of the LDS image: pixel row fr of tile 0, channels [64*wave + 4*kq, +4) of oc-tile 0
     const int epi_base = fr * RS + (wave * 64 + kq * 4) * 2;
@@ -149,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                     for (int j = 0; j < 4; j++) v[j] += (float)rx[mt][j];
                 }
                 if constexpr (decltype(post)::value) v = v * post_s[nt] + post_t[nt];
-                *reinterpret_cast<h16x4 *>(lds + dst_off + off) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4 *>(lds + dst_off + off) = to_h4(v);
             }
         }
     };
@@ -188,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     epilogue(L::X_OFF, NO, NO, NO);
     __syncthreads();
 
-    // ---- the 2*depth 3x3 convolutions ----
+    // ---- convolution passes over the LDS image ----
     // T[mt] = LDS address of this lane's fragment row (pixel shifted by the tap) or of a zero row.
     // Channel assignment of a k-step: lane group kq reads the 16-byte chunk at 256*(kq&1) + 128*(kq>>1) + 16*ch of the
     // row, i.e. k-step ch covers channels {8ch..8ch+7} + {0, 128, 64, 192}[kq].  The two kq groups that share a
@@ -211,46 +244,27 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         }
     };
 
-    int g = 0;  // global k-step index into the weight stream
-    for (int layer = 1; layer <= layers; layer++) {
-        const bool is_b = (layer & 1) == 0;  // conv A: X -> Y; conv B: Y -> X (+ residual)
-        const int src_off = is_b ? L::Y_OFF : L::X_OFF;
-        init_acc();
-        fetch_bias(layer + 1);
-        if (layer == layers) {
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                const int oc = wave * 64 + nt * 16 + kq * 4;
-                post_s[nt] = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-                post_t[nt] = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-            }
-        }
+    // acc += sum over taps [tap_lo, tap_hi) and all 256 input channels of W * image(src_off): 8 k-steps per tap
+    auto conv_pass = [&](int src_off, int tap_lo, int tap_hi) {
         int T[MT], Tn[MT];
         h16x8 bf[2][MT];  // activation fragments, double buffered one k-step ahead
-        tap_rows(0, src_off, T);
+        tap_rows(tap_lo, src_off, T);
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) bf[0][mt] = *reinterpret_cast<const h16x8 *>(lds + T[mt]);
-        for (int tap = 0; tap < 9; tap++) {
-            tap_rows(tap < 8 ? tap + 1 : 8, src_off, Tn);
+        for (int tap = tap_lo; tap < tap_hi; tap++) {
+            tap_rows(tap + 1 < tap_hi ? tap + 1 : tap, src_off, Tn);
 #pragma unroll
             for (int ch = 0; ch < 8; ch++) {
                 const int stage = ch & (PF - 1), cur = ch & 1, nxt = cur ^ 1;
-                // next k-step's activation fragments: LDS -> registers (after the last tap this re-reads tap 8,
+                // next k-step's activation fragments: LDS -> registers (after the last tap this re-reads that tap,
                 // harmless and branch-free)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
                     bf[nxt][mt] = ch < 7 ? *reinterpret_cast<const h16x8 *>(lds + T[mt] + (ch + 1) * 16)
                                          : *reinterpret_cast<const h16x8 *>(lds + Tn[mt]);
-                // this k-step's weight fragments were loaded PF k-steps ago; refill the stage with k-step g + PF
-                // (clamped at the end of the stream; the surplus loads are never used)
+                // this k-step's weight fragments were loaded PF k-steps ago
                 h16x8 af[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
-                {
-                    const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
-#pragma unroll
-                    for (int nt = 0; nt < 4; nt++) wreg[stage][nt] = wp[(size_t)gn * 1024 + nt * 64];
-                }
+                ring_take(stage, af);
                 // 4 x MT MFMAs on independent accumulators
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
@@ -276,19 +290,184 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) T[mt] = Tn[mt];
         }
+    };
+
+    // ---- the 2*depth 3x3 convolutions ----
+    for (int layer = 1; layer <= layers; layer++) {
+        const bool is_b = (layer & 1) == 0;  // conv A: X -> Y; conv B: Y -> X (+ residual)
+        init_acc();
+        fetch_bias(layer + 1);
+        if (layer == layers) {
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const int oc = wave * 64 + nt * 16 + kq * 4;
+                post_s[nt] = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
+                post_t[nt] = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
+            }
+        }
+        conv_pass(is_b ? L::Y_OFF : L::X_OFF, 0, 9);
         if (!is_b) epilogue(L::Y_OFF, YES, NO, NO);
         else if (layer != layers) epilogue(L::X_OFF, YES, YES, NO);
         else epilogue(L::X_OFF, YES, YES, YES);
         __syncthreads();
     }
 
-    // ---- write the tower output: coalesced 16-byte stores ----
-    for (int id = tid; id < M * 32; id += 256) {
-        const int p = id >> 5, c16 = id & 31;
-        const int board = board0 + (p >> 6);
-        if (board < a.batch) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(lds + L::X_OFF + p * RS + c16 * 16);
-            *reinterpret_cast<uint4 *>(a.y + ((size_t)board0 * 64 + p) * C + c16 * 8) = v;
+    if constexpr (!HEADS) {
+        // ---- write the tower output: coalesced 16-byte stores ----
+        for (int id = tid; id < M * 32; id += 256) {
+            const int p = id >> 5, c16 = id & 31;
+            const int board = board0 + (p >> 6);
+            if (board < a.batch) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(lds + L::X_OFF + p * RS + c16 * 16);
+                *reinterpret_cast<uint4 *>(a.y + ((size_t)board0 * 64 + p) * C + c16 * 8) = v;
+            }
+        }
+    } else {
+        // =====================================================================================================
+        // Heads on the LDS-resident tower output X (already through the final BN).
+        // =====================================================================================================
+        // ---- H1: ScalarHead conv1x1 C->4 + ReLU (post_act.py:14-15), channel-major flatten (:16) -> act[b][c*64+p]
+        {
+            float *act = reinterpret_cast<float *>(lds + L::ACT_OFF);
+            for (int o = tid; o < NB * 256; o += 256) {
+                const int b = o >> 8, c4 = (o >> 6) & 3, p = o & 63;
+                const unsigned char *row = lds + L::X_OFF + (b * 64 + p) * RS;
+                const float *w = a.sh_w0 + c4 * C;
+                float s = a.sh_b0[c4];
+#pragma unroll 4
+                for (int i = 0; i < C; i += 8) {
+                    const h16x8 xv = *reinterpret_cast<const h16x8 *>(row + i * 2);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + i), w1 = *reinterpret_cast<const f32x4 *>(w + i + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s += (float)xv[j] * w0[j] + (float)xv[4 + j] * w1[j];
+                }
+                act[o] = fmaxf(s, 0.0f);
+            }
+        }
+
+        // ---- H2: conv_under on the 8 squares of rank index 7 (post_act.py:129), as 3 passes of 256 output channels.
+        // The host permutes its output channels to s-major (oc' = 256*s + q for original channel 3q + s) so that
+        // under.reshape(Q, 24)[q][8s + x] (post_act.py:134) is contiguous in q: row (b*8+x), bytes [512 s, 512 s + 512).
+        {
+            const int urow = (NB == 2 ? (fr >> 3) * 64 : 0) + 56 + (fr & 7);
+            const int tb = L::X_OFF + urow * RS + kq_off;
+            for (int s = 0; s < 3; s++) {
+                f32x4 ua[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) ua[nt] = bias_next[nt];
+                fetch_bias(layers + 2 + s);
+#pragma unroll
+                for (int ch = 0; ch < 8; ch++) {
+                    const h16x8 bf = *reinterpret_cast<const h16x8 *>(lds + tb + ch * 16);
+                    h16x8 af[4];
+                    ring_take(ch & (PF - 1), af);
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++)
+                        ua[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf, ua[nt], 0, 0, 0);
+                    g++;
+                }
+                if (NB == 2 || fr < 8) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++)
+                        *reinterpret_cast<h16x4 *>(lds + L::U_OFF + fr * URS + (256 * s + wave * 64 + nt * 16 + kq * 4) * 2) =
+                            to_h4(ua[nt]);
+                }
+            }
+        }
+
+        // ---- H3: conv_bulk channels [0, Q) = q_from: X -> Y
+        init_acc();
+        fetch_bias(layers + 5);
+        conv_pass(L::X_OFF, 4, 5);
+        epilogue(L::Y_OFF, NO, NO, NO);
+
+        // ---- H4: conv_bulk channels [Q, 2Q) = the 64 board squares of q_to: X -> X in place (every wave reads all of X
+        // in its k-loop, so the writes wait for a barrier)
+        init_acc();
+        conv_pass(L::X_OFF, 4, 5);
+        __syncthreads();
+        epilogue(L::X_OFF, NO, NO, NO);
+        __syncthreads();
+
+        // ---- H5: ScalarHead Linear(256 -> 32) + ReLU (post_act.py:17-18): 4 lanes per output, 64 inputs each
+        {
+            const float *act = reinterpret_cast<const float *>(lds + L::ACT_OFF);
+            float *hid = reinterpret_cast<float *>(lds + L::HID_OFF);
+            if (tid < NB * 128) {
+                const int pair = tid >> 2, part = tid & 3, b = pair >> 5, j = pair & 31;
+                const float *w = a.sh_w1 + j * 256 + part * 64;
+                const float *x = act + b * 256 + part * 64;
+                float s = 0.0f;
+#pragma unroll 4
+                for (int i = 0; i < 64; i += 4) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + i), xv = *reinterpret_cast<const f32x4 *>(x + i);
+                    s += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+                }
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (part == 0) hid[b * 32 + j] = fmaxf(s + a.sh_b1[j], 0.0f);
+            }
+        }
+
+        // ---- H6: attention logits (post_act.py:138): L[i][j] = sum_q q_from[q][i] * q_to[q][j] / sqrt(Q).
+        // MFMA with q_to rows as the A operand and q_from rows as the B operand: a lane ends up with 4 consecutive j
+        // of one i.  q_to row j: j < 64 -> X row j (conv_bulk upper half); j = 64 + 8s + x -> under image row x, block s.
+        constexpr int IT = NB == 2 ? 2 : 1;  // i-tiles per wave
+        const int hb = NB == 2 ? wave >> 1 : 0;
+        const int it0 = NB == 2 ? (wave & 1) * 2 : wave;
+        f32x4 la[IT][6];
+        {
+            int ja[6], ia[IT];
+#pragma unroll
+            for (int jt = 0; jt < 4; jt++) ja[jt] = L::X_OFF + (hb * 64 + jt * 16 + fr) * RS + kq_off;
+            ja[4] = L::U_OFF + (hb * 8 + (fr & 7)) * URS + (fr >> 3) * 512 + kq_off;  // t = fr: s = fr>>3 in {0,1}
+            ja[5] = L::U_OFF + (hb * 8 + (fr & 7)) * URS + 2 * 512 + kq_off;          // t = 16 + fr: s = 2 (fr >= 8: pad)
+#pragma unroll
+            for (int ii = 0; ii < IT; ii++) ia[ii] = L::Y_OFF + (hb * 64 + (it0 + ii) * 16 + fr) * RS + kq_off;
+#pragma unroll
+            for (int ii = 0; ii < IT; ii++)
+#pragma unroll
+                for (int jt = 0; jt < 6; jt++) la[ii][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 8; ch++) {
+                h16x8 qa[6], qb[IT];
+#pragma unroll
+                for (int jt = 0; jt < 6; jt++) qa[jt] = *reinterpret_cast<const h16x8 *>(lds + ja[jt] + ch * 16);
+#pragma unroll
+                for (int ii = 0; ii < IT; ii++) qb[ii] = *reinterpret_cast<const h16x8 *>(lds + ia[ii] + ch * 16);
+#pragma unroll
+                for (int ii = 0; ii < IT; ii++)
+#pragma unroll
+                    for (int jt = 0; jt < 6; jt++)
+                        la[ii][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[jt], qb[ii], la[ii][jt], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave is done reading q_from (Y), q_to (X, U) and has written hid
+        {
+            const float inv = 1.0f / sqrtf((float)C);
+#pragma unroll
+            for (int ii = 0; ii < IT; ii++)
+#pragma unroll
+                for (int jt = 0; jt < 6; jt++) {
+                    const int i = (it0 + ii) * 16 + fr, j = jt * 16 + kq * 4;
+                    *reinterpret_cast<f32x4 *>(lds + L::LOG_OFF + ((hb * 64 + i) * LOGIT_LD + j) * 4) = la[ii][jt] * inv;
+                }
+        }
+        // ---- H7: ScalarHead Linear(32 -> 5) (post_act.py:19)
+        if (tid < NB * 5) {
+            const int b = tid / 5, k = tid % 5;
+            const float *hid = reinterpret_cast<const float *>(lds + L::HID_OFF) + b * 32;
+            float s = a.sh_b2[k];
+            for (int i = 0; i < 32; i++) s += a.sh_w2[k * 32 + i] * hid[i];
+            if (board0 + b < a.batch) a.scalars[(size_t)(board0 + b) * 5 + k] = s;
+        }
+        __syncthreads();
+        // ---- H8: policy.flatten(1)[:, FLAT_TO_ATT] (post_act.py:140): coalesced 1880-float rows
+        for (int b = 0; b < NB; b++) {
+            if (board0 + b >= a.batch) break;
+            const float *lg = reinterpret_cast<const float *>(lds + L::LOG_OFF) + b * 64 * LOGIT_LD;
+            float *pol = a.policy + (size_t)(board0 + b) * POLICY;
+            for (int k = tid; k < POLICY; k += 256) pol[k] = lg[a.att_idx[k]];
         }
     }
 }
@@ -302,15 +481,38 @@ int boards_per_wg() {
     return nb;
 }
 
+// [256 out][256 in] row-major f32 -> one 8-k-step pass of the weight stream (same layout as a tap of a 3x3 layer)
+void pack_1x1(const float *w, uint16_t *dst) {
+    static const int kq_base[4] = {0, 128, 64, 192};
+    for (int chunk = 0; chunk < 8; chunk++)
+        for (int wave = 0; wave < 4; wave++)
+            for (int nt = 0; nt < 4; nt++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int oc = 64 * wave + 16 * nt + (lane & 15);
+                        const int ch = 8 * chunk + kq_base[lane >> 4] + j;
+                        const _Float16 hv = (_Float16)w[(size_t)oc * 256 + ch];
+                        uint16_t bits;
+                        __builtin_memcpy(&bits, &hv, 2);
+                        dst[((((size_t)chunk * 4 + wave) * 4 + nt) * 64 + lane) * 8 + j] = bits;
+                    }
+}
+
 }  // namespace
 
 bool tower_resident_supported(int dtype, int h, int w, int channels, int depth) {
     return dtype == 1 && h == 8 && w == 8 && channels == C && depth >= 1;
 }
 
+bool tower_heads_supported(int policy_kind, int query_channels, int policy_len, int sh_channels, int sh_size) {
+    return policy_kind == 2 && query_channels == C && policy_len == POLICY && sh_channels == 4 && sh_size == 32;
+}
+
 size_t tower_packed_weight_elems(int cin_p, int depth) {
     return (size_t)9 * C * cin_p + (size_t)2 * depth * 9 * C * C;
 }
+
+size_t tower_heads_weight_elems() { return (size_t)HEAD_KSTEPS * 16 * 1024 / 2; }
 
 // OIHW f32 -> [tap 9][chunk cin_p/32][wave 4][nt 4][lane 64][8] f16: element j of lane (fr, kq) of (wave, nt) is
 // W[oc = 64*wave + 16*nt + fr][channel][tap] — the A fragment of v_mfma_f32_16x16x32_f16 — where the k-step's channel
@@ -337,8 +539,29 @@ void tower_pack_weights(const float *oihw, int cout, int cin, int cin_p, uint16_
                         }
 }
 
+// Heads part of the weight stream, in execution order: conv_under pass s = 0,1,2 (output channel 3q + s -> row q),
+// conv_bulk rows [0,256) (q_from), conv_bulk rows [256,512) (q_to).  bias5: the matching 5 x 256 bias rows.
+void tower_pack_heads(const float *w_bulk /*[512][256]*/, const float *b_bulk, const float *w_under /*[768][256]*/,
+                      const float *b_under, uint16_t *dst, float *bias5) {
+    const size_t pass = (size_t)8 * 16 * 1024 / 2;
+    std::vector<float> tmp((size_t)256 * 256);
+    for (int s = 0; s < 3; s++) {
+        for (int q = 0; q < 256; q++) {
+            for (int c = 0; c < 256; c++) tmp[(size_t)q * 256 + c] = w_under[(size_t)(3 * q + s) * 256 + c];
+            bias5[s * 256 + q] = b_under[3 * q + s];
+        }
+        pack_1x1(tmp.data(), dst + pass * s);
+    }
+    pack_1x1(w_bulk, dst + pass * 3);
+    pack_1x1(w_bulk + (size_t)256 * 256, dst + pass * 4);
+    for (int q = 0; q < 256; q++) {
+        bias5[3 * 256 + q] = b_bulk[q];
+        bias5[4 * 256 + q] = b_bulk[256 + q];
+    }
+}
+
 void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
-    TowerDev d;
+    TowerDev d{};
     d.x0 = static_cast<const h16 *>(t.x0);
     d.w_stem = static_cast<const uint4 *>(t.w_stem);
     d.w_tower = static_cast<const uint4 *>(t.w_tower);
@@ -349,18 +572,30 @@ void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
     d.cin_p = t.cin_p;
     d.batch = t.batch;
     d.depth = t.depth;
+    d.sh_w0 = t.sh_w0; d.sh_b0 = t.sh_b0; d.sh_w1 = t.sh_w1; d.sh_b1 = t.sh_b1; d.sh_w2 = t.sh_w2; d.sh_b2 = t.sh_b2;
+    d.att_idx = t.att_idx;
+    d.scalars = t.scalars;
+    d.policy = t.policy;
     static bool attr_done = [] {
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Layout<1>::BYTES);
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Layout<2>::BYTES);
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Layout<1>::BYTES);
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   Layout<2>::BYTES);
         return true;
     }();
     (void)attr_done;
+    const bool heads = t.fused_heads;
     if (boards_per_wg() == 1) {
-        kz_tower_resident<1><<<t.batch, 256, Layout<1>::BYTES, stream>>>(d);
+        if (heads) kz_tower_resident<1, true><<<t.batch, 256, Layout<1>::BYTES, stream>>>(d);
+        else kz_tower_resident<1, false><<<t.batch, 256, Layout<1>::BYTES, stream>>>(d);
     } else {
-        kz_tower_resident<2><<<(t.batch + 1) / 2, 256, Layout<2>::BYTES, stream>>>(d);
+        const int grid = (t.batch + 1) / 2;
+        if (heads) kz_tower_resident<2, true><<<grid, 256, Layout<2>::BYTES, stream>>>(d);
+        else kz_tower_resident<2, false><<<grid, 256, Layout<2>::BYTES, stream>>>(d);
     }
 }
 

@@ -232,7 +232,7 @@ def test_full_size_properties(dev, chess_full):
     assert np.array_equal(sp, s[perm]) and np.array_equal(pp, p[perm]), "not permutation equivariant"
     s7, p7 = eng.eval_packed(bits[:7], scalars_in[:7])
     assert np.array_equal(s7, s[:7]) and np.array_equal(p7, p[:7]), "result depends on the batch size"
-    if eng.tower_path == "tower_resident_f16":
+    if eng.tower_path.startswith("tower_resident_f16"):
         os.environ["KZ_FORCE_GENERIC"] = "1"
         try:
             gen = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
@@ -242,6 +242,24 @@ def test_full_size_properties(dev, chess_full):
         sg, pg = gen.eval_packed(bits, scalars_in)
         # both are f16-storage/f32-accumulate; they differ only in summation order
         assert np.abs(sg - s).max() < 2e-2 and np.abs(pg - p).max() < 2e-2
+
+
+def test_fused_heads_match_separate_head_kernels(dev, chess_full):
+    """The heads fused behind the resident tower (one launch per batch) vs the same tower followed by the generic
+    head kernels: both read the same f16 tower output, so they agree to f16-rounding of the 1x1 convolution outputs."""
+    blob, bits, scalars_in = chess_full
+    model = capi.Model(blob=blob)
+    fused = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    os.environ["KZ_NO_FUSED_HEADS"] = "1"
+    try:
+        split = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    finally:
+        del os.environ["KZ_NO_FUSED_HEADS"]
+    for n in (256, 255, 1):  # odd batches exercise the half-empty last workgroup
+        s1, p1 = fused.eval_packed(bits[:n], scalars_in[:n])
+        s2, p2 = split.eval_packed(bits[:n], scalars_in[:n])
+        assert np.abs(s1 - s2).max() < 2e-3, np.abs(s1 - s2).max()
+        assert np.abs(p1 - p2).max() < 1e-2, np.abs(p1 - p2).max()
 
 
 def test_go19_generic_path_vs_oracle(dev):
