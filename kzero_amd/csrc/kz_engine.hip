@@ -365,11 +365,24 @@ struct kz_engine {
         return 0;
     }
 
-    int run_tower(int batch, float *d_scalars, float *d_policy) {
+    // packed != nullptr (resident path only): the launch encodes the boards itself
+    struct PackedIn {
+        const void *bits;
+        size_t stride;
+        const void *scalars;
+    };
+    int run_tower(int batch, float *d_scalars, float *d_policy, const PackedIn *packed = nullptr) {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         if (resident) {
             kz::TowerArgs t{};
+            if (packed) {
+                t.bits = (const uint8_t *)packed->bits;
+                t.bits_stride = packed->stride;
+                t.scalars_in = (const float *)packed->scalars;
+                t.n_scalar = m.n_scalar;
+                t.n_bool = m.n_bool;
+            }
             t.x0 = x_in; t.cin_p = cin_p; t.w_stem = wts->res_w_stem; t.w_tower = wts->res_w_tower;
             t.bias = wts->res_bias; t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
             t.y = act[0]; t.batch = batch; t.h = m.h; t.w = m.w; t.depth = m.depth;
@@ -480,6 +493,11 @@ struct kz_engine {
 
     int forward_packed(const void *d_bits, size_t stride, const void *d_sin, int batch, void *d_sout, void *d_pol) {
         const Model &m = *model;
+        if (resident) {  // encode is fused into the tower launch
+            const PackedIn in{d_bits, stride, d_sin};
+            if (run_tower(batch, (float *)d_sout, (float *)d_pol, &in)) return 1;
+            return run_heads(batch, (float *)d_sout, (float *)d_pol);
+        }
         prof.begin("kz_encode_packed", stream);
         kz::launch_encode_packed(dtype, (const uint8_t *)d_bits, stride, (const float *)d_sin, batch, m.n_scalar,
                                  m.n_bool, m.h * m.w, x_in, cin_p, stream);
@@ -597,13 +615,11 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->fused_heads = e->resident && !(nofuse && nofuse[0] == '1') &&
                      kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,
                                                m.sh_fc0.out);
+    e->path = e->fused_heads ? "tower_resident_f16+heads"
+              : e->resident  ? "tower_resident_f16"
+                             : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
     const char *keep = getenv("KZ_KEEP_ACTIVATIONS");
     e->keep = keep && keep[0] == '1' && !e->resident;
-    e->path = e->resident ? "tower_resident_f16" : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
-    if (getenv("KZ_NO_FUSED_HEADS") == nullptr || getenv("KZ_NO_FUSED_HEADS")[0] != '1')
-        if (e->resident && kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len,
-                                                      m.sh_conv.cout, m.sh_fc0.out))
-            e->path = "tower_resident_f16+heads";
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);

@@ -94,8 +94,13 @@ void launch_attention(int dtype, const AttentionArgs &a, hipStream_t stream);
 // ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----
 // Requirements: f16, h*w <= 64, channels == 256 (cp), any depth >= 1.
 struct TowerArgs {
-    const void *x0;       // encoded input [batch*hw][cin_p] f16
+    const void *x0;       // encoded input [batch*hw][cin_p] f16 (used when bits == nullptr)
     int cin_p;            // 32
+    // fused board encode: packed boards straight into the launch (bits == nullptr: read x0 instead)
+    const uint8_t *bits;
+    size_t bits_stride;
+    const float *scalars_in;
+    int n_scalar, n_bool;
     const void *w_stem;   // fragment-packed stem weights
     const void *w_tower;  // fragment-packed weights of the 2*depth 3x3 convs
     const float *bias;    // [1 + 2*depth][256]

@@ -49,6 +49,11 @@ struct TowerDev {
     const float *bias, *post_scale, *post_shift;
     h16 *y;
     int cin_p, batch, depth;
+    // fused encode (F0): packed boards; when bits == nullptr the stem input comes from x0
+    const uint8_t *bits;
+    size_t bits_stride;
+    const float *scalars_in;
+    int n_scalar, n_bool;
     // fused heads
     const float *sh_w0, *sh_b0, *sh_w1, *sh_b1, *sh_w2, *sh_b2;
     const int32_t *att_idx;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
@@ -120,8 +125,30 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         const int row = id >> 2, c = id & 3;
         const int board = board0 + (row >> 6);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (board < a.batch)
-            v = *reinterpret_cast<const uint4 *>(a.x0 + ((size_t)board0 * 64 + row) * a.cin_p + c * 8);
+        if (board < a.batch) {
+            if (a.bits) {
+                // encode_input_full (rust/kz-core/src/mapping/mod.rs:40-63) for 8 channels of one square: scalar planes
+                // first, then the bool planes; bool i = bit i%8 of byte i/8 (bit_buffer.rs:73-75)
+                const uint8_t *bb = a.bits + (size_t)board * a.bits_stride;
+                const int p = row & 63;
+                h16x8 e;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int ch = c * 8 + j;
+                    float f = 0.0f;
+                    if (ch < a.n_scalar) {
+                        f = a.scalars_in[(size_t)board * a.n_scalar + ch];
+                    } else if (ch < a.n_scalar + a.n_bool) {
+                        const unsigned bit = (unsigned)(ch - a.n_scalar) * 64 + p;
+                        f = (float)((bb[bit >> 3] >> (bit & 7)) & 1);
+                    }
+                    e[j] = (h16)f;
+                }
+                v = *reinterpret_cast<const uint4 *>(&e);
+            } else {
+                v = *reinterpret_cast<const uint4 *>(a.x0 + ((size_t)board0 * 64 + row) * a.cin_p + c * 8);
+            }
+        }
         *reinterpret_cast<uint4 *>(lds + L::S_OFF + row * 64 + c * 16) = v;
     }
     __syncthreads();
@@ -572,6 +599,8 @@ void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
     d.cin_p = t.cin_p;
     d.batch = t.batch;
     d.depth = t.depth;
+    d.bits = t.bits; d.bits_stride = t.bits_stride; d.scalars_in = t.scalars_in; d.n_scalar = t.n_scalar;
+    d.n_bool = t.n_bool;
     d.sh_w0 = t.sh_w0; d.sh_b0 = t.sh_b0; d.sh_w1 = t.sh_w1; d.sh_b1 = t.sh_b1; d.sh_w2 = t.sh_w2; d.sh_b2 = t.sh_b2;
     d.att_idx = t.att_idx;
     d.scalars = t.scalars;
