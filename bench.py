@@ -150,10 +150,19 @@ def main():
     peak = 2500.0 if args.dtype == "f16" else 157.3
     avg_ms = k_ms / max(k_n, 1)
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if k_n else 0.0
+    # `achieved`/`frac` follow the contract literally: algorithmic FLOP of ONE launch / its average duration.  A resident
+    # launch covers ceil(batch / boards_per_workgroup) of the 256 CUs and `engines` launches run side by side, so the
+    # chip-level figure is `chip_frac` (all engines' FLOP / wall time), not `frac`.
+    nb = int(os.environ.get("KZ_TOWER_NB", "2")) if tower_path.startswith("tower_resident") else None
+    wgs = -(-B // (1 if nb == 1 else 2)) if nb else None
+    # HBM-side bytes per launch from the PMC passes of profiles/ (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+    # collected for this kernel at this shape; None for other shapes
+    traffic = 3.9e8 if (tower_path == "tower_resident_f16+heads" and B == 256 and args.workload == "chess-20x256") else None
     roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
                 "launches": k_n, "flop_per_launch": flops_per_launch,
-                "whole_path_frac": round(value / world * info.flops_per_eval / 1e12 / peak, 4)}
+                "workgroups_per_launch": wgs, "concurrent_launches": args.engines,
+                "chip_frac": round(value / world * info.flops_per_eval / 1e12 / peak, 4)}
 
     out = {
         "metric": "self-play NN evals/sec (node), Chess 20x256 ResNet b=256, 1/2/4/8 GPU",
