@@ -155,9 +155,12 @@ def main():
     # chip-level figure is `chip_frac` (all engines' FLOP / wall time), not `frac`.
     nb = int(os.environ.get("KZ_TOWER_NB", "2")) if tower_path.startswith("tower_resident") else None
     wgs = -(-B // (1 if nb == 1 else 2)) if nb else None
-    # HBM-side bytes per launch from the PMC passes of profiles/ (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
-    # collected for this kernel at this shape; None for other shapes
-    traffic = 3.9e8 if (tower_path == "tower_resident_f16+heads" and B == 256 and args.workload == "chess-20x256") else None
+    # HBM-side bytes per launch of this kernel at this shape, from the separate rocprofv3 --pmc passes committed under
+    # profiles/r1_pmc_final/ (FETCH_SIZE 188,179 KiB x2 per the gfx950 wide-read correction + WRITE_SIZE 1,888 KiB):
+    # each of the 8 non-coherent XCD L2s pulls the 49 MB weight stream once.  None for shapes that were not profiled.
+    traffic = None
+    if tower_path == "tower_resident_f16+heads" and B == 256 and args.workload == "chess-20x256":
+        traffic = (2 * 188179.35 + 1888.0) * 1024
     roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
                 "launches": k_n, "flop_per_launch": flops_per_launch,
