@@ -1,0 +1,94 @@
+// hip_network.hpp — `HipNetwork<B, M>`: the executor behind the `Network` contract, C++ mirror of the Rust shim in
+// kzero_amd/rust/hip.rs.  Same shape as `CudaNetwork` (rust/kz-core/src/network/cudnn.rs:18-88): encode every board
+// with the mapper, run the engine, decode the outputs.  Talks to the product only through the C ABI.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/kz_hip.h"
+#include "mapping.hpp"
+#include "network.hpp"
+
+namespace kz::host {
+
+inline void kz_check(int rc) {
+    if (rc != 0) throw std::runtime_error(std::string("kzhip: ") + kz_last_error());  // the reference panics
+}
+
+// the `Arc<Graph>` of the reference: immutable, shared by every executor
+class HipModel {
+    kz_model *ptr_ = nullptr;
+
+  public:
+    kz_model_info info{};
+    explicit HipModel(const std::string &path) {
+        kz_check(kz_model_load(path.c_str(), &ptr_));
+        kz_check(kz_model_get_info(ptr_, &info));
+    }
+    HipModel(const void *blob, size_t len) {
+        kz_check(kz_model_load_memory(blob, len, &ptr_));
+        kz_check(kz_model_get_info(ptr_, &info));
+    }
+    HipModel(const HipModel &) = delete;
+    HipModel &operator=(const HipModel &) = delete;
+    ~HipModel() { kz_model_free(ptr_); }
+    const kz_model *get() const { return ptr_; }
+};
+
+template <class B, class M>
+class HipNetwork : public Network<B> {
+    M mapper_;
+    std::shared_ptr<const HipModel> model_;
+    kz_engine *engine_ = nullptr;
+    size_t max_batch_size_;
+    std::vector<uint8_t> bits_;
+    std::vector<float> scalars_in_, scalars_out_, policy_out_;
+
+  public:
+    // cudnn.rs:29-43 (check_graph_shapes: common.rs:165-198)
+    HipNetwork(M mapper, std::shared_ptr<const HipModel> model, size_t max_batch_size, int device, int dtype)
+        : mapper_(mapper), model_(std::move(model)), max_batch_size_(max_batch_size) {
+        const kz_model_info &info = model_->info;
+        auto shape = input_full_shape(mapper_);
+        if ((size_t)info.input_channels != shape[0] || (size_t)info.board_h != shape[1] || (size_t)info.board_w != shape[2])
+            throw std::invalid_argument("Input shape mismatch between model and mapper");
+        if ((size_t)info.input_scalar_channels != mapper_.input_scalar_count())
+            throw std::invalid_argument("Scalar plane count mismatch between model and mapper");
+        if ((size_t)info.policy_len != mapper_.policy_len()) throw std::invalid_argument("Wrong policy shape");
+        kz_check(kz_engine_create(model_->get(), device, (int)max_batch_size, dtype, &engine_));
+        bits_.resize(max_batch_size * (size_t)info.bits_bytes);
+        scalars_out_.resize(max_batch_size * 5);
+        policy_out_.resize(max_batch_size * (size_t)info.policy_len);
+    }
+    HipNetwork(HipNetwork &&o) noexcept
+        : mapper_(o.mapper_), model_(std::move(o.model_)), engine_(o.engine_), max_batch_size_(o.max_batch_size_),
+          bits_(std::move(o.bits_)), scalars_in_(std::move(o.scalars_in_)), scalars_out_(std::move(o.scalars_out_)),
+          policy_out_(std::move(o.policy_out_)) {
+        o.engine_ = nullptr;
+    }
+    HipNetwork(const HipNetwork &) = delete;
+    ~HipNetwork() override { kz_engine_destroy(engine_); }
+
+    size_t max_batch_size() const override { return max_batch_size_; }
+
+    // cudnn.rs:55-87
+    std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
+        if (n > max_batch_size_) throw std::invalid_argument("batch_size <= max_batch_size");  // assert!, :58
+        if (n == 0) return {};
+        const size_t bool_count = input_bool_len(mapper_), bits_bytes = (bool_count + 7) / 8;
+        scalars_in_.clear();
+        BitBuffer buffer(bool_count);
+        for (size_t bi = 0; bi < n; bi++) {
+            buffer.clear();
+            mapper_.encode_input(buffer, scalars_in_, boards[bi]);
+            if (buffer.len() != bool_count) throw std::logic_error("mapper wrote the wrong number of bools");
+            std::copy(buffer.storage().begin(), buffer.storage().begin() + bits_bytes, bits_.begin() + bi * bits_bytes);
+        }
+        kz_check(kz_engine_eval_packed(engine_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n, scalars_out_.data(),
+                                       policy_out_.data()));
+        return decode_output(mapper_, boards, n, scalars_out_.data(), policy_out_.data());
+    }
+};
+
+}  // namespace kz::host

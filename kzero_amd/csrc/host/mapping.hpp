@@ -1,0 +1,250 @@
+// mapping.hpp — board -> tensor encoding (rust/kz-core/src/mapping/{mod.rs, bit_buffer.rs, chess.rs, ataxx.rs, go.rs}).
+//
+// Game rules live in the ext `board-game` crate on the Rust side; this mirror defines the mappers over plain position
+// records that carry exactly what the mappers read (bitboards, counters, the list of available moves).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <vector>
+
+namespace kz::host {
+
+// bit_buffer.rs:4-96: LSB-first bit packing
+class BitBuffer {
+    std::vector<uint8_t> storage_;
+    size_t capacity_, len_ = 0;
+
+  public:
+    explicit BitBuffer(size_t capacity) : storage_((capacity - 1) / 8 + 1, 0), capacity_(capacity) {}  // :8-14
+    void push(bool b) {                                                                                  // :16-36
+        if (len_ >= capacity_) throw std::out_of_range("BitBuffer: not enough space left, pushing 1");
+        const size_t index = len_ / 8, bit = len_ % 8;
+        len_++;
+        if (b) storage_[index] |= (uint8_t)(1u << bit);
+        else storage_[index] &= (uint8_t)~(1u << bit);
+    }
+    void push_block(uint64_t v) {  // :38-57: 8 little-endian bytes, byte-aligned only
+        if (len_ + 64 > capacity_) throw std::out_of_range("BitBuffer: not enough space left, pushing 64");
+        if (len_ % 8 != 0) throw std::logic_error("BitBuffer: can only push aligned blocks of bits");
+        for (int i = 0; i < 8; i++) storage_[len_ / 8 + i] = (uint8_t)(v >> (8 * i));
+        len_ += 64;
+    }
+    void clear() {  // :59-62
+        std::fill(storage_.begin(), storage_.end(), 0);
+        len_ = 0;
+    }
+    size_t len() const { return len_; }
+    const std::vector<uint8_t> &storage() const { return storage_; }
+    bool operator[](size_t i) const { return (storage_[i / 8] >> (i % 8)) & 1; }  // :80-90
+};
+
+// mapping/mod.rs:19-38 — InputMapper concept:
+//     std::array<size_t,3> input_bool_shape() const;  size_t input_scalar_count() const;
+//     void encode_input(BitBuffer&, std::vector<float>& scalars, const B&) const;
+template <class M>
+std::array<size_t, 3> input_full_shape(const M &m) {  // :23-27
+    auto s = m.input_bool_shape();
+    return {s[0] + m.input_scalar_count(), s[1], s[2]};
+}
+template <class M>
+size_t input_bool_len(const M &m) {  // :29-31
+    auto s = m.input_bool_shape();
+    return s[0] * s[1] * s[2];
+}
+
+// mapping/mod.rs:40-63: scalar planes first (each scalar broadcast over w*h), then the bool planes as 0/1
+template <class M, class B>
+void encode_input_full(const M &m, std::vector<float> &result, const B &board) {
+    const size_t bool_count = input_bool_len(m);
+    auto shape = m.input_bool_shape();
+    BitBuffer bools(bool_count);
+    std::vector<float> scalars;
+    m.encode_input(bools, scalars, board);
+    if (bools.len() != bool_count || scalars.size() != m.input_scalar_count())
+        throw std::logic_error("mapper wrote the wrong number of bools/scalars");
+    for (float s : scalars) result.insert(result.end(), shape[1] * shape[2], s);
+    for (size_t i = 0; i < bool_count; i++) result.push_back(bools[i] ? 1.0f : 0.0f);
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// Chess (chess.rs:125-178).  The record holds what ChessStdMapper reads from board-game's ChessBoard.
+// --------------------------------------------------------------------------------------------------------------
+struct ChessPosition {
+    using Move = int32_t;  // flat policy index in [0, 1880) (chess.rs:197-217); move generation is ext
+    bool white_to_move = true;
+    uint64_t pieces[2][6] = {};  // [color: 0 white, 1 black][pawn, knight, bishop, rook, queen, king], A1 = bit 0
+    uint64_t en_passant = 0;     // bitboard with the en-passant square, or 0
+    bool castle_kingside[2] = {}, castle_queenside[2] = {};  // [white, black]
+    int repetitions = 0, non_pawn_or_capture_moves = 0;
+    std::optional<std::vector<Move>> moves;
+    std::optional<std::vector<Move>> available_moves() const { return moves; }
+};
+
+// chess.rs:173-178: black sees the board with ranks flipped (BitBoard::reverse_colors = byte swap)
+inline uint64_t pov_ranks(uint64_t board, bool white_pov) { return white_pov ? board : __builtin_bswap64(board); }
+
+struct ChessStdMapper {
+    std::array<size_t, 3> input_bool_shape() const { return {13, 8, 8}; }  // :126-129
+    size_t input_scalar_count() const { return 8; }                        // :131-134
+    size_t policy_len() const { return 1880; }
+    size_t move_to_index(const ChessPosition &, int32_t mv) const { return (size_t)mv; }
+    void encode_input(BitBuffer &bools, std::vector<float> &scalars, const ChessPosition &b) const {  // :136-170
+        const int pov = b.white_to_move ? 0 : 1, other = 1 - pov;
+        scalars.push_back(pov == 0 ? 1.0f : 0.0f);  // absolute colour of the side to move (:144-146)
+        scalars.push_back(pov == 1 ? 1.0f : 0.0f);
+        for (int color : {pov, other}) {  // castling rights, us then them (:149-153)
+            scalars.push_back(b.castle_kingside[color] ? 1.0f : 0.0f);
+            scalars.push_back(b.castle_queenside[color] ? 1.0f : 0.0f);
+        }
+        scalars.push_back((float)b.repetitions);  // counters (:156-157)
+        scalars.push_back((float)b.non_pawn_or_capture_moves);
+        for (int color : {pov, other})  // pieces, us then them (:160-165)
+            for (int piece = 0; piece < 6; piece++) bools.push_block(pov_ranks(b.pieces[color][piece], b.white_to_move));
+        bools.push_block(pov_ranks(b.en_passant, b.white_to_move));  // :168-169
+    }
+};
+
+// --------------------------------------------------------------------------------------------------------------
+// Ataxx (ataxx.rs:8-116).  Tiles are indexed densely: i = y*size + x.
+// --------------------------------------------------------------------------------------------------------------
+struct AtaxxMove {
+    enum Kind { Pass, Copy, Jump } kind = Pass;
+    int from_x = 0, from_y = 0, to_x = 0, to_y = 0;
+    bool operator==(const AtaxxMove &o) const {
+        if (kind != o.kind) return false;
+        if (kind == Pass) return true;
+        if (to_x != o.to_x || to_y != o.to_y) return false;
+        return kind == Copy || (from_x == o.from_x && from_y == o.from_y);
+    }
+};
+
+struct AtaxxPosition {
+    using Move = AtaxxMove;
+    int size = 7;
+    uint64_t tiles_next = 0, tiles_other = 0, gaps = 0;  // dense bit i = y*size + x; tiles_pov() order
+    int moves_since_last_copy = 0;
+    std::optional<std::vector<AtaxxMove>> moves;
+    std::optional<std::vector<AtaxxMove>> available_moves() const { return moves; }
+};
+
+constexpr int ATAXX_MAX_MOVES_SINCE_LAST_COPY = 100;  // board_game::games::ataxx::MAX_MOVES_SINCE_LAST_COPY
+
+// ataxx.rs:135-152
+constexpr int ATAXX_FROM_DX_DY[16][2] = {{-2, -2}, {-1, -2}, {0, -2}, {1, -2}, {2, -2}, {-2, -1}, {2, -1}, {-2, 0},
+                                         {2, 0},   {-2, 1},  {2, 1},  {-2, 2}, {-1, 2}, {0, 2},   {1, 2},  {2, 2}};
+
+struct AtaxxStdMapper {
+    int size;
+    explicit AtaxxStdMapper(int size) : size(size) {}
+    std::array<size_t, 3> input_bool_shape() const { return {3, (size_t)size, (size_t)size}; }  // :94-96
+    size_t input_scalar_count() const { return 1; }                                             // :98-104
+    size_t policy_len() const { return 17 * (size_t)size * size + 1; }                          // :23
+    void encode_input(BitBuffer &bools, std::vector<float> &scalars, const AtaxxPosition &b) const {  // :106-115
+        scalars.push_back((float)b.moves_since_last_copy / (float)ATAXX_MAX_MOVES_SINCE_LAST_COPY);
+        const int area = size * size;
+        for (int i = 0; i < area; i++) bools.push((b.tiles_next >> i) & 1);
+        for (int i = 0; i < area; i++) bools.push((b.tiles_other >> i) & 1);
+        for (int i = 0; i < area; i++) bools.push((b.gaps >> i) & 1);
+    }
+    // ataxx.rs:60-81
+    size_t move_to_index(const AtaxxMove &mv) const {
+        const size_t area = (size_t)size * size;
+        switch (mv.kind) {
+            case AtaxxMove::Pass: return 17 * area;
+            case AtaxxMove::Copy: return (size_t)mv.to_y * size + mv.to_x;
+            case AtaxxMove::Jump: {
+                const int dx = mv.from_x - mv.to_x, dy = mv.from_y - mv.to_y;
+                for (int i = 0; i < 16; i++)
+                    if (ATAXX_FROM_DX_DY[i][0] == dx && ATAXX_FROM_DX_DY[i][1] == dy)
+                        return (1 + (size_t)i) * area + (size_t)mv.to_y * size + mv.to_x;
+                throw std::invalid_argument("not a jump of distance 2");
+            }
+        }
+        return 0;
+    }
+    size_t move_to_index(const AtaxxPosition &, const AtaxxMove &mv) const { return move_to_index(mv); }
+    // ataxx.rs:35-58
+    std::optional<AtaxxMove> index_to_move(size_t index) const {
+        const size_t area = (size_t)size * size;
+        if (index >= policy_len()) throw std::out_of_range("policy index");
+        const int to = (int)(index % area), tx = to % size, ty = to / size;
+        if (index == policy_len() - 1) return AtaxxMove{AtaxxMove::Pass};
+        if (index < area) return AtaxxMove{AtaxxMove::Copy, 0, 0, tx, ty};
+        const size_t from_index = index / area - 1;
+        const int fx = tx + ATAXX_FROM_DX_DY[from_index][0], fy = ty + ATAXX_FROM_DX_DY[from_index][1];
+        if (fx < 0 || fx >= size || fy < 0 || fy >= size) return std::nullopt;
+        return AtaxxMove{AtaxxMove::Jump, fx, fy, tx, ty};
+    }
+};
+
+// --------------------------------------------------------------------------------------------------------------
+// Go (go.rs:8-113).  Planes are over the max_size x max_size grid; tile i = y*max_size + x.
+// --------------------------------------------------------------------------------------------------------------
+struct GoPosition {
+    using Move = int32_t;  // policy index: 0 = pass, 1 + tile (go.rs:26-31)
+    int size = 19;
+    std::vector<uint8_t> stones_next, stones_other;  // [max_area] 0/1
+    std::vector<uint8_t> ko_illegal;                 // empty tiles that are not available (:73-77)
+    std::vector<int8_t> territory;                   // [max_area]: 0 next player, 1 neither, 2 other (:79-87)
+    bool next_is_black = true, pass_1 = false, pass_2 = false, multi_stone_suicide = false;
+    float komi_pov = 7.5f;  // already from the next player's point of view (:91-94)
+    std::optional<std::vector<Move>> moves;
+    std::optional<std::vector<Move>> available_moves() const { return moves; }
+};
+
+struct GoStdMapper {
+    int max_size;
+    bool territory;
+    GoStdMapper(int max_size, bool territory) : max_size(max_size), territory(territory) {}
+    std::array<size_t, 3> input_bool_shape() const {  // :46-55
+        return {(size_t)(4 + (territory ? 3 : 0)), (size_t)max_size, (size_t)max_size};
+    }
+    size_t input_scalar_count() const { return 6; }  // :57-62
+    size_t policy_len() const { return 1 + (size_t)max_size * max_size; }
+    size_t move_to_index(const GoPosition &, int32_t mv) const { return (size_t)mv; }
+    void encode_input(BitBuffer &bools, std::vector<float> &scalars, const GoPosition &b) const {  // :64-113
+        const int area = max_size * max_size;
+        auto exists = [&](int i) { return i % max_size < b.size && i / max_size < b.size; };
+        for (int i = 0; i < area; i++) bools.push(exists(i) && b.stones_next[i]);
+        for (int i = 0; i < area; i++) bools.push(exists(i) && b.stones_other[i]);
+        for (int i = 0; i < area; i++) bools.push(exists(i));
+        for (int i = 0; i < area; i++) bools.push(exists(i) && b.ko_illegal[i]);
+        if (territory)
+            for (int owner = 0; owner < 3; owner++)
+                for (int i = 0; i < area; i++) bools.push(exists(i) && b.territory[i] == owner);
+        scalars.push_back(b.next_is_black ? 1.0f : 0.0f);  // :105-110
+        scalars.push_back(b.next_is_black ? 0.0f : 1.0f);
+        scalars.push_back(b.pass_1 ? 1.0f : 0.0f);
+        scalars.push_back(b.pass_2 ? 1.0f : 0.0f);
+        scalars.push_back(b.komi_pov / 15.0f);
+        scalars.push_back(b.multi_stone_suicide ? 1.0f : 0.0f);
+    }
+};
+
+// --------------------------------------------------------------------------------------------------------------
+// Already-packed boards: what crosses the FFI boundary (BitBuffer storage + scalars + available-move indices).
+// --------------------------------------------------------------------------------------------------------------
+struct PackedBoard {
+    using Move = int32_t;
+    std::vector<uint8_t> bits;
+    std::vector<float> scalars;
+    std::optional<std::vector<Move>> moves;
+    std::optional<std::vector<Move>> available_moves() const { return moves; }
+};
+
+struct PackedMapper {
+    size_t planes, h, w, n_scalar, n_policy;
+    std::array<size_t, 3> input_bool_shape() const { return {planes, h, w}; }
+    size_t input_scalar_count() const { return n_scalar; }
+    size_t policy_len() const { return n_policy; }
+    size_t move_to_index(const PackedBoard &, int32_t mv) const { return (size_t)mv; }
+    void encode_input(BitBuffer &bools, std::vector<float> &scalars, const PackedBoard &b) const {
+        const size_t n = planes * h * w;
+        for (size_t i = 0; i < n; i++) bools.push((b.bits[i / 8] >> (i % 8)) & 1);
+        scalars.insert(scalars.end(), b.scalars.begin(), b.scalars.end());
+    }
+};
+
+}  // namespace kz::host

@@ -194,8 +194,24 @@ def gen_decode_kat():
         f.write(write_model({"batch": 6, "policy_len": 40}, tensors))
 
 
+def gen_ataxx_symmetry():
+    """D4 move/plane symmetry tables of Ataxx, sizes 2..8: a data file of the reference
+    (python/lib/mapping/ataxx_symmetry.json, written by rust/kz-misc/src/bin/write_ataxx_mapping.rs:62-88 from
+    board-game's D4Symmetry) re-encoded as text: one line per (size, symmetry):
+    size index transpose flip_x flip_y n map_mv[0..n)."""
+    import json
+    data = json.load(open(os.path.join(REF, "lib", "mapping", "ataxx_symmetry.json")))
+    with open(os.path.join(OUT, "ataxx_symmetry.txt"), "w") as f:
+        for si, syms in enumerate(data):
+            for i, e in enumerate(syms):
+                mv = e["map_mv"]
+                f.write(f"{si + 2} {i} {int(e['transpose'])} {int(e['flip_x'])} {int(e['flip_y'])} {len(mv)} "
+                        + " ".join(str(v) for v in mv) + "\n")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    gen_ataxx_symmetry()
     gen_net("ataxx7_2x16", 1, 4, 0.3, layers=True,
             game_name="ataxx-7", depth=2, channels=16, head_kind="ataxx_conv")
     gen_net("ataxx7_4x64", 2, 2, 0.3,

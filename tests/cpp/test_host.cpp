@@ -1,0 +1,461 @@
+// test_host.cpp — CPU tests of the host-side mirror (kzero_amd/csrc/host): BitBuffer, mappers, decode_output,
+// job channel, batched_executor_loop, symmetry.  Built and run by tests/test_host_cpp.py.
+//
+// Modelled on the reference's own tests: rust/kz-core/src/mapping/bit_buffer.rs:112-164 (BitBuffer known answers),
+// rust/kz-core/tests/mapper/mod.rs:13-82 (mapper shape validity, move <-> index round trip and uniqueness),
+// rust/kz-core/tests/tree.rs (a fake uniform network drives the machinery).
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <set>
+#include <sstream>
+#include <thread>
+
+#include "../../kzero_amd/csrc/host/executor.hpp"
+#include "../../kzero_amd/csrc/host/mapping.hpp"
+#include "../../kzero_amd/csrc/host/network.hpp"
+#include "../../kzero_amd/csrc/host/symmetry.hpp"
+
+using namespace kz::host;
+
+static int g_failed = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            g_failed++;                                                          \
+        }                                                                        \
+    } while (0)
+template <class F>
+static bool throws(F f) {
+    try {
+        f();
+    } catch (...) {
+        return true;
+    }
+    return false;
+}
+
+// ---- bit_buffer.rs:112-164 ----
+static void test_bitbuffer() {
+    {  // short
+        BitBuffer b(8);
+        b.push(true); b.push(false); b.push(true);
+        CHECK(b.storage() == std::vector<uint8_t>{0b101});
+    }
+    {  // edge_length
+        BitBuffer b(8);
+        for (int i = 0; i < 8; i++) b.push(true);
+        CHECK(b.storage() == std::vector<uint8_t>{0xFF});
+        BitBuffer c(9);
+        for (int i = 0; i < 9; i++) c.push(true);
+        CHECK((c.storage() == std::vector<uint8_t>{0xFF, 0b1}));
+    }
+    {  // longer
+        BitBuffer b(16);
+        for (int i = 0; i < 16; i++) b.push(i == 1 || i == 5 || i == 12);
+        CHECK((b.storage() == std::vector<uint8_t>{0b00100010, 0b10000}));
+    }
+    {  // overflow
+        BitBuffer b(32);
+        CHECK(throws([&] { for (int i = 0; i < 33; i++) b.push(false); }));
+    }
+    {  // block
+        BitBuffer b(64);
+        b.push_block(0b100000001);
+        CHECK(b.storage()[0] == 1 && b.storage()[1] == 1 && b.len() == 64);
+        for (int i = 2; i < 8; i++) CHECK(b.storage()[i] == 0);
+        BitBuffer c(128);
+        c.push(true);
+        CHECK(throws([&] { c.push_block(1); }));  // only aligned blocks
+    }
+}
+
+// ---- tests/mapper/mod.rs:13-82: shapes, scalars-first layout, move <-> index round trip ----
+static void test_mappers() {
+    {
+        ChessStdMapper m;
+        ChessPosition p;  // start position
+        p.pieces[0][0] = 0xFF00ull; p.pieces[0][1] = 0x42; p.pieces[0][2] = 0x24; p.pieces[0][3] = 0x81;
+        p.pieces[0][4] = 0x08; p.pieces[0][5] = 0x10;
+        for (int i = 0; i < 6; i++) p.pieces[1][i] = __builtin_bswap64(p.pieces[0][i]);
+        for (int c = 0; c < 2; c++) p.castle_kingside[c] = p.castle_queenside[c] = true;
+        BitBuffer bools(input_bool_len(m));
+        std::vector<float> scalars;
+        m.encode_input(bools, scalars, p);
+        CHECK(bools.len() == input_bool_len(m) && input_bool_len(m) == 13 * 64);  // mod.rs:21-27
+        CHECK(scalars.size() == m.input_scalar_count());
+        CHECK((scalars == std::vector<float>{1, 0, 1, 1, 1, 1, 0, 0}));
+        CHECK(bools[0 * 64 + 8] && !bools[0 * 64 + 0]);   // our pawns on rank 2
+        CHECK(bools[5 * 64 + 4]);                          // our king on e1
+        CHECK(bools[6 * 64 + 48] && bools[11 * 64 + 60]);  // their pawns on rank 7, their king on e8
+        // black to move sees the same picture from its side (pov_ranks, chess.rs:173-178)
+        ChessPosition q = p;
+        q.white_to_move = false;
+        BitBuffer bools2(input_bool_len(m));
+        std::vector<float> scalars2;
+        m.encode_input(bools2, scalars2, q);
+        CHECK(bools2.storage() == bools.storage());
+        CHECK(scalars2[0] == 0 && scalars2[1] == 1);
+        // encode_input_full: scalar planes first, then bools (mapping/mod.rs:54-59)
+        std::vector<float> full;
+        encode_input_full(m, full, p);
+        CHECK(full.size() == 21 * 64);
+        CHECK(full[0] == 1 && full[63] == 1 && full[64] == 0 && full[2 * 64 + 5] == 1);
+        CHECK(full[8 * 64 + 8] == 1 && full[8 * 64 + 0] == 0);
+    }
+    for (int size = 2; size <= 8; size++) {  // ataxx: every index maps to a unique move and back (mod.rs:37-72)
+        AtaxxStdMapper m(size);
+        std::set<size_t> seen;
+        size_t valid = 0;
+        for (size_t i = 0; i < m.policy_len(); i++) {
+            auto mv = m.index_to_move(i);
+            if (!mv) continue;
+            valid++;
+            CHECK(m.move_to_index(*mv) == i);
+            seen.insert(i);
+        }
+        CHECK(seen.size() == valid);
+        // python/lib/mapping/mapping.py:52: number of valid moves per size
+        static const size_t expect[] = {5, 42, 113, 218, 357, 530, 737};
+        CHECK(valid == expect[size - 2]);
+        AtaxxPosition p;
+        p.size = size;
+        p.tiles_next = 1;
+        p.tiles_other = 1ull << (size * size - 1);
+        p.moves_since_last_copy = 50;
+        BitBuffer bools(input_bool_len(m));
+        std::vector<float> scalars;
+        m.encode_input(bools, scalars, p);
+        CHECK(bools.len() == (size_t)3 * size * size && scalars.size() == 1 && scalars[0] == 0.5f);
+        CHECK(bools[0] && bools[(size_t)2 * size * size - 1] && !bools[1]);
+    }
+    {
+        GoStdMapper m(9, true);
+        GoPosition p;
+        p.size = 7;  // smaller board inside the 9x9 planes
+        p.stones_next.assign(81, 0); p.stones_other.assign(81, 0); p.ko_illegal.assign(81, 0); p.territory.assign(81, 1);
+        p.stones_next[3] = 1;
+        p.stones_next[8] = 1;  // x = 8 is outside a size-7 board: masked by `exists`
+        BitBuffer bools(input_bool_len(m));
+        std::vector<float> scalars;
+        m.encode_input(bools, scalars, p);
+        CHECK(bools.len() == 7 * 81 && scalars.size() == 6);
+        CHECK(bools[3] && !bools[8]);
+        CHECK(bools[2 * 81 + 0] && !bools[2 * 81 + 7] && !bools[2 * 81 + 7 * 9]);  // in-board plane
+        CHECK(std::fabs(scalars[4] - 0.5f) < 1e-6f);
+        CHECK(GoStdMapper(19, true).policy_len() == 362 && input_full_shape(GoStdMapper(19, true))[0] == 13);
+    }
+}
+
+// ---- network/common.rs:16-114 ----
+static void test_decode() {
+    PackedMapper m{1, 2, 2, 0, 6};
+    PackedBoard boards[3];
+    boards[0].moves = std::vector<int32_t>{4, 0, 5};
+    boards[1].moves = std::vector<int32_t>{2};  // a single legal move gets probability 1
+    boards[2].moves = std::nullopt;  // finished game: empty policy (map_or(vec![], ..))
+    const float scalars[15] = {0.5f, 1, 2, 3, 7, -2, 0, 0, 0, 1.5f, 0, 5, 5, 5, -1};
+    const float logits[18] = {1, 9, 9, 9, 2, 3, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6};
+    auto ev = decode_output(m, boards, 3, scalars, logits);
+    CHECK(ev.size() == 3);
+    CHECK(std::fabs(ev[0].values.value - std::tanh(0.5f)) < 1e-7f && ev[0].values.moves_left == 7);
+    const float e1 = std::exp(-2.f), e2 = std::exp(-1.f), es = e1 + e2 + 1;
+    CHECK(std::fabs(ev[0].values.wdl.win - e1 / es) < 1e-6f && std::fabs(ev[0].values.wdl.loss - 1 / es) < 1e-6f);
+    // policy: logits gathered in available_moves order {4, 0, 5} -> {2, 1, 3}, then softmax
+    const float p0 = std::exp(2.f - 3), p1 = std::exp(1.f - 3), p2 = 1, ps = p0 + p1 + p2;
+    CHECK(ev[0].policy.size() == 3 && std::fabs(ev[0].policy[0] - p0 / ps) < 1e-6f &&
+          std::fabs(ev[0].policy[1] - p1 / ps) < 1e-6f && std::fabs(ev[0].policy[2] - p2 / ps) < 1e-6f);
+    CHECK(ev[1].policy.size() == 1 && ev[1].policy[0] == 1.0f && ev[2].policy.empty());
+    PackedBoard none_left;  // Some(no moves) trips the reference's assert!(sum > 0.0) as well (common.rs:110)
+    none_left.moves = std::vector<int32_t>{};
+    CHECK(throws([&] { decode_output(m, &none_left, 1, scalars, logits); }));
+    CHECK(std::fabs(ev[2].values.wdl.win - 1.f / 3) < 1e-6f);
+    float bad[2] = {NAN, 1};
+    CHECK(throws([&] { softmax_in_place(bad, 2); }));  // assert!(sum > 0.0), common.rs:110
+    DummyNetwork<PackedBoard> dummy;  // dummy.rs:44-60
+    auto d = dummy.evaluate_batch(boards, 3);
+    CHECK(d[0].policy.size() == 3 && std::fabs(d[0].policy[1] - 1.f / 3) < 1e-7f && d[2].policy.empty());
+}
+
+// ---- job_channel.rs ----
+static void test_job_channel() {
+    auto [client, server] = job_pair<int, int>(2);
+    CHECK(client.map_blocking({}).empty());  // empty request short-circuits, nothing reaches the server (:37-40)
+    TryRecvError err;
+    CHECK(!server.receiver().try_recv(err) && err == TryRecvError::Empty);
+    std::thread worker([srv = server]() mutable {
+        auto rx = srv.into_receiver();
+        while (auto job = rx.recv()) {
+            std::vector<int> y;
+            for (int v : job->x) y.push_back(v * 2);
+            job->sender.send(std::move(y));
+        }
+    });
+    CHECK((client.map_blocking({1, 2, 3}) == std::vector<int>{2, 4, 6}));
+    auto fut = client.map_async({5});
+    auto single = client.map_async_single(7);
+    CHECK(fut.get() == std::vector<int>{10} && single.get() == 14);
+    client = JobClient<int, int>();  // drop the last sender -> the worker sees Disconnected
+    server = JobServer<int, int>();
+    worker.join();
+    // bounded: a full channel blocks the sender until the receiver takes an item
+    auto [tx, rx] = bounded<int>(1);
+    CHECK(tx.send(1));
+    std::atomic<bool> sent{false};
+    std::thread t([&, tx2 = tx] { tx2.send(2); sent = true; });
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    CHECK(!sent);
+    CHECK(*rx.recv() == 1 && *rx.recv() == 2);
+    t.join();
+    rx = Receiver<int>();
+    CHECK(!tx.send(3));  // SendError once every receiver is gone
+}
+
+// ---- executor.rs:176-302 ----
+static void test_executor_state() {
+    ExecutorState<int, int> st;
+    std::vector<Receiver<std::vector<int>>> replies;
+    auto push = [&](std::vector<int> x) {
+        auto [tx, rx] = bounded<std::vector<int>>(1);
+        replies.push_back(rx);
+        st.push_job(Job<int, int>{std::move(x), std::move(tx)});
+    };
+    CHECK(!st.should_eval(RunCondition::any(), 4));
+    push({});  // empty job answered immediately, never queued (:229-231)
+    CHECK(replies[0].recv()->empty() && st.sender_count() == 0);
+    push({1, 2, 3});
+    CHECK(st.should_eval(RunCondition::any(), 4) && !st.should_eval(RunCondition::full_batch(), 4));
+    CHECK(!st.should_eval(RunCondition::job_count(2), 4) && st.should_eval(RunCondition::job_count(1), 4));
+    push({4});
+    push({5, 6, 7, 8, 9});
+    CHECK(st.should_eval(RunCondition::full_batch(), 4) && st.items_to_eval() == 9);
+    auto eval = [&](size_t max) {
+        auto [data, n] = st.get_batch(max);
+        std::vector<int> y(data, data + n);
+        for (auto &v : y) v *= 10;
+        st.respond_batch(std::move(y));
+    };
+    TryRecvError err;
+    eval(4);  // {1,2,3,4}: completes jobs 1 and 2
+    CHECK((*replies[1].recv() == std::vector<int>{10, 20, 30}) && (*replies[2].recv() == std::vector<int>{40}));
+    CHECK(!replies[3].try_recv(err));
+    eval(4);  // {5,6,7,8}: job 3 still incomplete, results wait in leftover_y
+    CHECK(!replies[3].try_recv(err) && st.items_waiting_for_send() == 4 && st.items_to_eval() == 1);
+    eval(4);  // {9}
+    CHECK((*replies[3].recv() == std::vector<int>{50, 60, 70, 80, 90}));
+    CHECK(st.items_to_eval() == 0 && st.items_to_send() == 0);
+    push({1, 2});
+    eval(4);  // shortcut path: the whole batch belongs to one sender (:285-287)
+    CHECK((*replies[4].recv() == std::vector<int>{10, 20}));
+}
+
+struct FakeNet {
+    int id;
+    static std::atomic<int> alive;
+    explicit FakeNet(int id) : id(id) { alive++; }
+    FakeNet(FakeNet &&o) noexcept : id(o.id) { alive++; }
+    FakeNet(const FakeNet &) = delete;
+    ~FakeNet() { alive--; }
+};
+std::atomic<int> FakeNet::alive{0};
+
+struct Trace : ExecutorEvents {
+    std::mutex m;
+    std::vector<std::string> log;
+    std::vector<size_t> batches;
+    int max_alive = 0;
+    void on_drop_network() override { std::lock_guard<std::mutex> g(m); log.push_back("drop"); }
+    void on_load_network() override {
+        std::lock_guard<std::mutex> g(m);
+        log.push_back("load");
+        max_alive = std::max(max_alive, FakeNet::alive.load());
+    }
+    void on_eval(size_t n) override { std::lock_guard<std::mutex> g(m); batches.push_back(n); }
+};
+
+// ---- executor.rs:27-146 ----
+static void test_executor_loop() {
+    auto [client, server] = job_pair<int, int>(8);
+    auto [gtx, grx] = bounded<std::optional<int>>(1);
+    Trace trace;
+    std::thread exec([&, srv = std::move(server), rx = std::move(grx)]() mutable {
+        batched_executor_loop<int, FakeNet, int, int>(
+            4, RunCondition::any(), std::move(rx), std::move(srv), [](int g) { return FakeNet(g); },
+            [](FakeNet &n, const int *x, size_t len) {
+                std::vector<int> y(x, x + len);
+                for (auto &v : y) v = v * 100 + n.id;
+                return y;
+            },
+            &trace);
+    });
+    // jobs sent before any network exists wait in the channel (the loop only listens for jobs once it has a network)
+    auto early = client.map({1, 2});
+    auto early2 = client.map({3});
+    std::this_thread::sleep_for(std::chrono::milliseconds(30));
+    TryRecvError err;
+    CHECK(!early.try_recv(err));
+    gtx.send(7);
+    CHECK((*early.recv() == std::vector<int>{107, 207}) && (*early2.recv() == std::vector<int>{307}));
+    // many clients, order preserved per job, each job answered exactly once
+    std::vector<std::thread> gens;
+    std::atomic<int> wrong{0};
+    for (int t = 0; t < 4; t++)
+        gens.emplace_back([&, t, c = client] {
+            for (int i = 0; i < 50; i++) {
+                std::vector<int> x;
+                for (int k = 0; k <= (i + t) % 3; k++) x.push_back(t * 1000 + i * 4 + k);
+                auto y = c.map_blocking(x);
+                if (y.size() != x.size()) wrong++;
+                for (size_t k = 0; k < y.size(); k++)
+                    if (y[k] != x[k] * 100 + 7) wrong++;
+            }
+        });
+    for (auto &g : gens) g.join();
+    CHECK(wrong == 0);
+    for (size_t n : trace.batches) CHECK(n >= 1 && n <= 4);  // never above max_batch_size
+    // hot swap: None = "wait for new network" drops the current one; the next graph is loaded after the drop
+    gtx.send(std::nullopt);
+    gtx.send(9);
+    CHECK((client.map_blocking({5, 6}) == std::vector<int>{509, 609}));
+    client = JobClient<int, int>();
+    gtx = Sender<std::optional<int>>();
+    exec.join();
+    CHECK((trace.log == std::vector<std::string>{"load", "drop", "load"}));
+    CHECK(trace.max_alive <= 1 && FakeNet::alive == 0);  // the old network is dropped BEFORE the new one is built (:326-341)
+}
+
+// RunCondition::JobCount(n): a batch runs once n jobs (or max_batch items) are queued; what is left when the job
+// channel disconnects is evaluated before the loop exits (executor.rs:101-115)
+static void test_executor_job_count() {
+    auto [client, server] = job_pair<int, int>(8);
+    auto [gtx, grx] = bounded<std::optional<int>>(1);
+    Trace trace;
+    std::thread exec([&, srv = std::move(server), rx = std::move(grx)]() mutable {
+        batched_executor_loop<int, FakeNet, int, int>(
+            8, RunCondition::job_count(2), std::move(rx), std::move(srv), [](int g) { return FakeNet(g); },
+            [](FakeNet &, const int *x, size_t len) { return std::vector<int>(x, x + len); }, &trace);
+    });
+    gtx.send(1);
+    TryRecvError err;
+    auto a = client.map({1});
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    CHECK(!a.try_recv(err));  // one job < JobCount(2): pending
+    auto b = client.map({2, 3});
+    CHECK((*a.recv() == std::vector<int>{1}) && (*b.recv() == std::vector<int>{2, 3}));
+    auto last = client.map({8});
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    CHECK(!last.try_recv(err));
+    client = JobClient<int, int>();  // disconnect: the leftover is evaluated, then the loop exits
+    exec.join();
+    CHECK((*last.recv() == std::vector<int>{8}));
+    CHECK((trace.batches == std::vector<size_t>{3, 1}));
+}
+
+// executor exits when the graph channel closes before any network arrived and the job channel closes too (:119-143)
+static void test_executor_exit_without_network() {
+    auto [client, server] = job_pair<int, int>(1);
+    auto [gtx, grx] = bounded<std::optional<int>>(1);
+    std::thread exec([srv = std::move(server), rx = std::move(grx)]() mutable {
+        batched_executor_loop<int, FakeNet, int, int>(
+            4, RunCondition::any(), std::move(rx), std::move(srv), [](int g) { return FakeNet(g); },
+            [](FakeNet &, const int *x, size_t len) { return std::vector<int>(x, x + len); });
+    });
+    gtx = Sender<std::optional<int>>();
+    client = JobClient<int, int>();
+    exec.join();
+    CHECK(FakeNet::alive == 0);
+}
+
+// ---- symmetry: D4 tables of the reference + RandomSymmetryNetwork un-mapping ----
+struct CoordNet : Network<AtaxxSymBoard> {  // policy weight of a move depends on where it lands on the evaluated board
+    size_t max_batch_size() const override { return 64; }
+    std::vector<ZeroEvaluation> evaluate_batch(const AtaxxSymBoard *boards, size_t n) override {
+        std::vector<ZeroEvaluation> out(n);
+        for (size_t i = 0; i < n; i++) {
+            out[i].values.value = (float)__builtin_popcountll(boards[i].tiles_next);
+            for (const auto &mv : *boards[i].moves)
+                out[i].policy.push_back((float)AtaxxStdMapper(boards[i].size).move_to_index(mv));
+        }
+        return out;
+    }
+};
+
+static void test_symmetry(const std::string &golden_dir) {
+    std::ifstream f(golden_dir + "/ataxx_symmetry.txt");
+    CHECK(f.good());
+    std::string line;
+    int rows = 0;
+    while (std::getline(f, line)) {
+        std::istringstream is(line);
+        int size, index, tr, fx, fy;
+        size_t n;
+        is >> size >> index >> tr >> fx >> fy >> n;
+        const D4 d = D4::from_index(index);
+        CHECK(d.transpose == (bool)tr && d.flip_x == (bool)fx && d.flip_y == (bool)fy);
+        AtaxxStdMapper m(size);
+        CHECK(n == m.policy_len());
+        for (size_t i = 0; i < n; i++) {
+            long expect;
+            is >> expect;
+            auto mv = m.index_to_move(i);
+            if (!mv) {
+                CHECK(expect == -1);
+                continue;
+            }
+            CHECK((long)m.move_to_index(ataxx_map_move(size, index, *mv)) == expect);
+        }
+        rows++;
+    }
+    CHECK(rows == 7 * 8);
+
+    AtaxxSymBoard b;
+    b.size = 7;
+    b.tiles_next = 0b1000001;
+    b.tiles_other = 1ull << 48;
+    b.moves = std::vector<AtaxxMove>{{AtaxxMove::Copy, 0, 0, 1, 0}, {AtaxxMove::Jump, 0, 0, 2, 1}, {AtaxxMove::Copy, 0, 0, 5, 1},
+                                     {AtaxxMove::Jump, 6, 0, 4, 2}};
+    // plane mapping agrees with the move mapping: the tile at (x,y) lands where a copy to (x,y) lands
+    for (int sym = 0; sym < 8; sym++) {
+        AtaxxMove to{AtaxxMove::Copy, 0, 0, 6, 0};
+        auto mapped = ataxx_map_move(7, sym, to);
+        CHECK((ataxx_map_tiles(7, sym, 1ull << 6) >> (mapped.to_y * 7 + mapped.to_x)) & 1);
+    }
+    RandomSymmetryNetwork<AtaxxSymBoard, CoordNet> net(CoordNet{}, std::mt19937_64(3), true);
+    for (int rep = 0; rep < 20; rep++) {
+        auto ev = net.evaluate(b);
+        CHECK(ev.values.value == 2 && ev.policy.size() == 4);
+        // whatever symmetry was drawn, entry i belongs to the image of move i (symmetry.rs:126-148)
+        bool found = false;
+        for (int sym = 0; sym < 8 && !found; sym++) {
+            bool all = true;
+            for (size_t i = 0; i < 4; i++)
+                all &= ev.policy[i] == (float)AtaxxStdMapper(7).move_to_index(ataxx_map_move(7, sym, (*b.moves)[i]));
+            found = all;
+        }
+        CHECK(found);
+    }
+    RandomSymmetryNetwork<AtaxxSymBoard, CoordNet> off(CoordNet{}, std::mt19937_64(3), false);  // disabled: passthrough
+    auto ev = off.evaluate(b);
+    CHECK(ev.policy[0] == (float)AtaxxStdMapper(7).move_to_index((*b.moves)[0]));
+}
+
+int main(int argc, char **argv) {
+    const std::string golden = argc > 1 ? argv[1] : "tests/golden";
+    std::fputs("bitbuffer\n", stderr); test_bitbuffer();
+    std::fputs("mappers\n", stderr); test_mappers();
+    std::fputs("decode\n", stderr); test_decode();
+    std::fputs("job_channel\n", stderr); test_job_channel();
+    std::fputs("state\n", stderr); test_executor_state();
+    std::fputs("loop\n", stderr); test_executor_loop();
+    std::fputs("job_count\n", stderr); test_executor_job_count();
+    std::fputs("exit\n", stderr); test_executor_exit_without_network();
+    std::fputs("symmetry\n", stderr); test_symmetry(golden);
+    if (g_failed) {
+        std::fprintf(stderr, "%d check(s) failed\n", g_failed);
+        return 1;
+    }
+    std::puts("host tests ok");
+    return 0;
+}
