@@ -34,6 +34,9 @@ def parse_args():
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--workload", default="chess-20x256", choices=["chess-20x256", "ataxx-8x128", "go19-40x256"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-io", action="store_true",
+                    help="diagnostic: feed host buffers through kz_engine_submit_packed/kz_engine_wait (PCIe-inclusive, "
+                         "two slots per engine); never the configuration `value` is quoted on")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
     return ap.parse_args()
 
@@ -97,11 +100,25 @@ def main():
             for _ in engines]
     stride = bits.shape[1]
 
+    inflight = {}
+
+    def step_host(i):
+        # round-robin over (engine, slot); wait for the slot's previous batch before reusing it
+        e, slot = i % len(engines), (i // len(engines)) % capi.KZ_ENGINE_SLOTS
+        if (e, slot) in inflight:
+            engines[e].wait(slot, inflight.pop((e, slot)))
+        inflight[(e, slot)] = engines[e].submit_packed(slot, bits, scalars_in)
+
     def step(i):
+        if args.host_io:
+            return step_host(i)
         e = i % len(engines)
         engines[e].enqueue_packed_device(d_bits, stride, d_sin, B, outs[e][0], outs[e][1])
 
     def sync_all():
+        for (e, slot), n in list(inflight.items()):
+            engines[e].wait(slot, n)
+        inflight.clear()
         for e in engines:
             e.synchronize()
         capi.check(capi.load().kz_device_synchronize(device))
@@ -126,8 +143,9 @@ def main():
         e.set_profiling(False)
 
     # sanity: outputs are finite numbers
-    s_host = outs[0][0].to_host(np.float32, (B, 5))
-    assert np.isfinite(s_host).all(), "non-finite network output"
+    if not args.host_io:
+        s_host = outs[0][0].to_host(np.float32, (B, 5))
+        assert np.isfinite(s_host).all(), "non-finite network output"
 
     if rank != 0:
         if dist is not None:
@@ -172,7 +190,8 @@ def main():
         "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, packed boards resident in HBM",
+        "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, " +
+                               ("host buffers over PCIe (diagnostic)" if args.host_io else "packed boards resident in HBM"),
                    "engines_per_gpu": args.engines, "tower_path": tower_path, "parallelism": f"dp{world} (no collective)",
                    "flop_per_eval": info.flops_per_eval},
         "roofline": roofline,
