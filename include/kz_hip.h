@@ -41,13 +41,13 @@ typedef struct kz_model_info {
     int32_t input_channels;
     int32_t board_h;
     int32_t board_w;
-    int32_t input_scalar_channels;
-    int32_t input_bool_channels;
+    int32_t input_scalar_channels; /* -1: unknown (ONNX loaded without the split) */
+    int32_t input_bool_channels;   /* -1: unknown */
     int32_t policy_len;
     int32_t tower_depth;
     int32_t tower_channels;
     int32_t policy_kind;
-    int32_t bits_bytes;     /* ceil(input_bool_channels * h * w / 8): BitBuffer storage per board (bit_buffer.rs:8-14) */
+    int32_t bits_bytes;     /* ceil(input_bool_channels * h * w / 8): BitBuffer storage per board (bit_buffer.rs:8-14); -1: unknown */
     int64_t param_count;
     double flops_per_eval;  /* direct-convolution FLOPs (2 per MAC), heads included: the roofline numerator */
 } kz_model_info;
@@ -62,6 +62,13 @@ int kz_device_count(int *count);
  * Accepts the KZMODEL1 container (kzero_amd/model_file.py); Conv+BN folding happens here. */
 int kz_model_load(const char *path, kz_model **out);
 int kz_model_load_memory(const void *blob, size_t len, kz_model **out);
+/* The ONNX file the trainer already writes (python/lib/save_onnx.py:60-122: opset 10, input "input", outputs "scalars"
+ * and "policy"), i.e. what `Command::NewNetwork(path)` carries (kz-selfplay/src/server/protocol.rs:36).  The graph does
+ * not say how many of its input planes are broadcast scalars: pass the mapper's `input_scalar_count()`
+ * (kz-core/src/mapping/mod.rs:21).  kz_model_load/_memory also accept ONNX, with the split unknown: such a model
+ * serves kz_engine_eval_dense only and the packed entry points fail with a message. */
+int kz_model_load_onnx(const char *path, int input_scalar_channels, kz_model **out);
+int kz_model_load_onnx_memory(const void *blob, size_t len, int input_scalar_channels, kz_model **out);
 void kz_model_free(kz_model *model);
 int kz_model_get_info(const kz_model *model, kz_model_info *out);
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     "kz_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "kz_model_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "kz_model_load_memory": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "kz_model_load_onnx": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "kz_model_load_onnx_memory": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "kz_model_free": (None, [C.c_void_p]),
     "kz_model_get_info": (C.c_int, [C.c_void_p, C.POINTER(ModelInfo)]),
     "kz_engine_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -95,9 +97,16 @@ def device_count() -> int:
 class Model:
     """`Arc<Graph>`: immutable, shareable across engines, threads and devices."""
 
-    def __init__(self, blob: bytes = None, path: str = None):
+    def __init__(self, blob: bytes = None, path: str = None, onnx_scalar_channels: int = None):
+        """blob/path: a KZMODEL1 container or an ONNX file; onnx_scalar_channels: for ONNX, how many input planes are
+        broadcast scalars (the mapper's input_scalar_count) — needed for the packed-input entry points."""
         self._h = C.c_void_p()
-        if blob is not None:
+        if onnx_scalar_channels is not None:
+            if blob is not None:
+                check(load().kz_model_load_onnx_memory(blob, len(blob), onnx_scalar_channels, C.byref(self._h)))
+            else:
+                check(load().kz_model_load_onnx(path.encode(), onnx_scalar_channels, C.byref(self._h)))
+        elif blob is not None:
             check(load().kz_model_load_memory(blob, len(blob), C.byref(self._h)))
         else:
             check(load().kz_model_load(path.encode(), C.byref(self._h)))

@@ -14,12 +14,14 @@ for src in kz_kernels.hip kz_tower.hip kz_engine.hip; do
     pids+=($!)
   fi
 done
-obj=build/kz_model.o
-if [ ! -f "$obj" ] || [ kz_model.cpp -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ]; then
-  g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -c kz_model.cpp -o "$obj" &
-  pids+=($!)
-fi
+for src in kz_model.cpp kz_onnx.cpp; do
+  obj=build/${src%.cpp}.o
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ]; then
+    g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" build/kz_kernels.o build/kz_tower.o build/kz_engine.o build/kz_model.o \
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" build/kz_kernels.o build/kz_tower.o build/kz_engine.o build/kz_model.o build/kz_onnx.o \
   -Wl,-rpath,/opt/rocm/lib -Wl,--no-undefined
 echo "built $(realpath $OUT)"

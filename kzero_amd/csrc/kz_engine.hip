@@ -533,8 +533,18 @@ KZ_API int kz_device_count(int *count) {
     return 0;
 }
 
+KZ_API int kz_model_load_onnx_memory(const void *blob, size_t len, int input_scalar_channels, kz_model **out) {
+    if (!blob || !out) return fail("kz_model_load_onnx: null argument");
+    std::string err;
+    Model *m = kz::parse_onnx(blob, len, input_scalar_channels, err);
+    if (!m) return fail("kz_model_load_onnx: " + err);
+    *out = new kz_model{std::shared_ptr<Model>(m)};
+    return 0;
+}
+
 KZ_API int kz_model_load_memory(const void *blob, size_t len, kz_model **out) {
     if (!blob || !out) return fail("kz_model_load_memory: null argument");
+    if (kz::looks_like_onnx(blob, len)) return kz_model_load_onnx_memory(blob, len, -1, out);
     std::string err;
     Model *m = kz::parse_model(blob, len, err);
     if (!m) return fail("kz_model_load: " + err);
@@ -542,16 +552,28 @@ KZ_API int kz_model_load_memory(const void *blob, size_t len, kz_model **out) {
     return 0;
 }
 
-KZ_API int kz_model_load(const char *path, kz_model **out) {
-    if (!path || !out) return fail("kz_model_load: null argument");
+static int read_whole_file(const char *path, std::vector<uint8_t> &buf) {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(std::string("kz_model_load: cannot open '") + path + "'");
-    std::vector<uint8_t> buf;
     uint8_t tmp[1 << 16];
     size_t n;
     while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
     fclose(f);
+    return 0;
+}
+
+KZ_API int kz_model_load(const char *path, kz_model **out) {
+    if (!path || !out) return fail("kz_model_load: null argument");
+    std::vector<uint8_t> buf;
+    if (read_whole_file(path, buf)) return 1;
     return kz_model_load_memory(buf.data(), buf.size(), out);
+}
+
+KZ_API int kz_model_load_onnx(const char *path, int input_scalar_channels, kz_model **out) {
+    if (!path || !out) return fail("kz_model_load_onnx: null argument");
+    std::vector<uint8_t> buf;
+    if (read_whole_file(path, buf)) return 1;
+    return kz_model_load_onnx_memory(buf.data(), buf.size(), input_scalar_channels, out);
 }
 
 KZ_API void kz_model_free(kz_model *model) { delete model; }
@@ -568,7 +590,7 @@ KZ_API int kz_model_get_info(const kz_model *model, kz_model_info *out) {
     out->tower_depth = m.depth;
     out->tower_channels = m.channels;
     out->policy_kind = (int)m.policy_kind;
-    out->bits_bytes = (m.n_bool * m.h * m.w + 7) / 8;
+    out->bits_bytes = m.n_bool < 0 ? -1 : (m.n_bool * m.h * m.w + 7) / 8;
     out->param_count = m.param_count;
     out->flops_per_eval = m.flops_per_eval;
     return 0;
@@ -659,15 +681,16 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     }
     if (e->dmalloc(&e->head0, h0 * e->esz) || e->dmalloc(&e->head1, h1 * e->esz)) return 1;
 
-    const size_t bits_bytes = (size_t)(m.n_bool * hw + 7) / 8;
+    const int nb_planes = m.n_bool < 0 ? 0 : m.n_bool, ns_planes = m.n_scalar < 0 ? 0 : m.n_scalar;
+    const size_t bits_bytes = (size_t)(nb_planes * hw + 7) / 8;
     for (auto &s : e->slots) {
         if (e->dmalloc((void **)&s.d_bits, max_batch * bits_bytes) ||
-            e->dmalloc((void **)&s.d_sin, (size_t)max_batch * m.n_scalar * 4) ||
+            e->dmalloc((void **)&s.d_sin, (size_t)max_batch * ns_planes * 4) ||
             e->dmalloc((void **)&s.d_sout, (size_t)max_batch * 5 * 4) ||
             e->dmalloc((void **)&s.d_pol, (size_t)max_batch * m.policy_len * 4))
             return 1;
         if (e->hmalloc((void **)&s.h_bits, max_batch * bits_bytes) ||
-            e->hmalloc((void **)&s.h_sin, (size_t)max_batch * m.n_scalar * 4) ||
+            e->hmalloc((void **)&s.h_sin, (size_t)max_batch * ns_planes * 4) ||
             e->hmalloc((void **)&s.h_sout, (size_t)max_batch * 5 * 4) ||
             e->hmalloc((void **)&s.h_pol, (size_t)max_batch * m.policy_len * 4))
             return 1;
@@ -681,6 +704,13 @@ KZ_API int kz_engine_max_batch(const kz_engine *e) { return e ? e->max_batch : 0
 
 KZ_API const char *kz_engine_tower_path(const kz_engine *e) { return e ? e->path.c_str() : ""; }
 
+static int check_packed(const kz_engine *e, const char *fn) {
+    if (e && e->model->n_scalar < 0)
+        return fail(std::string(fn) + ": the model was loaded from ONNX without the scalar/bool plane split; load it "
+                                      "with kz_model_load_onnx(path, input_scalar_channels) to use packed inputs");
+    return 0;
+}
+
 static int check_batch(const kz_engine *e, int batch, const char *fn) {
     if (!e) return fail(std::string(fn) + ": null engine");
     if (batch < 0 || batch > e->max_batch)  // assert!(batch_size <= max_batch_size), cudnn.rs:58
@@ -691,7 +721,7 @@ static int check_batch(const kz_engine *e, int batch, const char *fn) {
 
 KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, size_t bits_stride,
                                    const float *scalars_in, int batch) {
-    if (check_batch(e, batch, "kz_engine_submit_packed")) return 1;
+    if (check_batch(e, batch, "kz_engine_submit_packed") || check_packed(e, "kz_engine_submit_packed")) return 1;
     if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail("kz_engine_submit_packed: bad slot");
     kz_engine::Slot &s = e->slots[slot];
     if (s.batch >= 0) return fail("kz_engine_submit_packed: slot still in flight (call kz_engine_wait first)");
@@ -763,7 +793,8 @@ KZ_API int kz_engine_eval_dense(kz_engine *e, const float *input_nchw, int batch
 KZ_API int kz_engine_enqueue_packed_device(kz_engine *e, const void *d_bits, size_t bits_stride,
                                            const void *d_scalars_in, int batch, void *d_scalars_out,
                                            void *d_policy_out) {
-    if (check_batch(e, batch, "kz_engine_enqueue_packed_device")) return 1;
+    if (check_batch(e, batch, "kz_engine_enqueue_packed_device") || check_packed(e, "kz_engine_enqueue_packed_device"))
+        return 1;
     if (batch == 0) return 0;
     if (!d_bits || !d_scalars_out || !d_policy_out) return fail("kz_engine_enqueue_packed_device: null argument");
     const Model &m = *e->model;

@@ -186,6 +186,50 @@ struct Loader {
 
 }  // namespace
 
+// parameter count and direct-convolution FLOPs (2 per MAC, heads included: BASELINE.md §2) from the folded model;
+// used for models that do not come from a KZMODEL1 container
+void finalize_model(Model &m) {
+    const int C = m.channels, hw = m.h * m.w;
+    double macs = 0;
+    int64_t params = 0;
+    auto conv = [&](const Conv &c, int pixels) {
+        if (!c.cout) return;
+        macs += (double)pixels * c.cout * c.cin * c.k * c.k;
+        params += (int64_t)c.w.size() + (int64_t)c.b.size();
+    };
+    auto lin = [&](const Linear &l) {
+        if (!l.out) return;
+        macs += (double)l.out * l.in;
+        params += (int64_t)l.w.size() + (int64_t)l.b.size();
+    };
+    for (auto &c : m.tower) conv(c, hw);
+    params += 2 * C;  // final BN as an affine
+    conv(m.sh_conv, hw);
+    lin(m.sh_fc0);
+    lin(m.sh_fc1);
+    switch (m.policy_kind) {
+        case POLICY_ATAXX_CONV:
+        case POLICY_CONV:
+            conv(m.p_conv0, hw);
+            conv(m.p_conv1, hw);
+            conv(m.p_extra_conv, hw);
+            lin(m.p_extra_fc);
+            break;
+        case POLICY_ATTENTION:
+            conv(m.p_bulk, hw);
+            conv(m.p_under, 8);
+            macs += 64.0 * 88 * m.policy_query_channels;
+            break;
+        case POLICY_DENSE:
+            conv(m.p_conv0, hw);
+            lin(m.p_fc0);
+            lin(m.p_fc1);
+            break;
+    }
+    m.flops_per_eval = 2.0 * macs;
+    if (m.param_count == 0) m.param_count = params;
+}
+
 Model *parse_model(const void *blob, size_t len, std::string &err) {
     Container c;
     if (!parse_container(blob, len, c, err)) return nullptr;

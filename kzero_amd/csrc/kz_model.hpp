@@ -57,4 +57,10 @@ struct Model {
 // Returns nullptr and sets `err` on failure.
 Model *parse_model(const void *blob, size_t len, std::string &err);
 
+// ONNX as exported by the trainer (python/lib/save_onnx.py:60-122), kz_onnx.cpp.  n_scalar = how many of the input
+// planes are broadcast scalars (InputMapper::input_scalar_count, rust/kz-core/src/mapping/mod.rs:21) — the graph does
+// not carry that split; pass -1 when unknown (then only the dense-input entry points work).
+bool looks_like_onnx(const void *blob, size_t len);
+Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err);
+
 }  // namespace kz

@@ -116,7 +116,22 @@ def write_io(path, batch, inputs, outputs):
             f.write(np.ascontiguousarray(o.detach().numpy(), dtype=np.float32).tobytes())
 
 
-def gen_net(name, seed, batch, p_bool, layers=False, **kw):
+def export_onnx(net, path, shape):
+    """The reference's own export call (python/lib/save_onnx.py:107-119: opset 10, names input/scalars/policy, dynamic
+    batch axis).  The `onnx` package is absent here; torch only needs it for an onnxscript post-pass, stubbed out."""
+    import warnings
+    import torch.onnx._internal.torchscript_exporter.onnx_proto_utils as opu
+    opu._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+    batch_axis = {0: "batch_size"}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.onnx.export(model=net, args=(torch.randn(2, *shape),), f=path, input_names=["input"],
+                          output_names=["scalars", "policy"],
+                          dynamic_axes={k: batch_axis for k in ["input", "scalars", "policy"]}, opset_version=10,
+                          dynamo=False)
+
+
+def gen_net(name, seed, batch, p_bool, layers=False, onnx=False, **kw):
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1)
     rng = np.random.default_rng(seed + 2)
@@ -134,6 +149,11 @@ def gen_net(name, seed, batch, p_bool, layers=False, **kw):
         f.write(write_model(meta, tensors))
 
     size = game.board_size
+    if onnx:
+        path = os.path.join(OUT, f"{name}.onnx")
+        if os.path.exists(path):
+            os.remove(path)
+        export_onnx(net, path, (n_scalar + n_bool, size, size))
     dense, bits, scalars_in = make_planes_input(rng, batch, n_scalar, n_bool, size, p_bool)
     with torch.no_grad():
         out_planes = net(torch.from_numpy(dense))
@@ -212,13 +232,13 @@ def gen_ataxx_symmetry():
 def main():
     os.makedirs(OUT, exist_ok=True)
     gen_ataxx_symmetry()
-    gen_net("ataxx7_2x16", 1, 4, 0.3, layers=True,
+    gen_net("ataxx7_2x16", 1, 4, 0.3, layers=True, onnx=True,
             game_name="ataxx-7", depth=2, channels=16, head_kind="ataxx_conv")
     gen_net("ataxx7_4x64", 2, 2, 0.3,
             game_name="ataxx-7", depth=4, channels=64, head_kind="ataxx_conv")
-    gen_net("chess_2x32_att", 3, 3, 0.05,
+    gen_net("chess_2x32_att", 3, 3, 0.05, onnx=True,
             game_name="chess", depth=2, channels=32, head_kind="attention", query_channels=16)
-    gen_net("chess_2x32_dense_h", 4, 2, 0.05,
+    gen_net("chess_2x32_dense_h", 4, 2, 0.05, onnx=True,
             game_name="chess", depth=2, channels=32, head_kind="dense", hidden_channels=2, hidden_size=24)
     gen_net("chess_1x32_dense", 5, 2, 0.05,
             game_name="chess", depth=1, channels=32, head_kind="dense", hidden_channels=1, hidden_size=None)
@@ -226,7 +246,7 @@ def main():
     # (rust/kz-selfplay/src/server/server.rs:193, kz-core/src/mapping/go.rs:46-55): cover both.
     gen_net("go9_2x16_conv", 6, 2, 0.25,
             game_name="go-9", depth=2, channels=16, head_kind="conv", extra_moves=1)
-    gen_net("go9_2x16_conv_terr", 7, 2, 0.25,
+    gen_net("go9_2x16_conv_terr", 7, 2, 0.25, onnx=True,
             game_name="go-9", depth=2, channels=16, head_kind="conv", extra_moves=1, input_bool_channels=7)
     gen_decode_kat()
 

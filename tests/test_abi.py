@@ -103,3 +103,34 @@ def test_product_never_touches_the_oracle():
                 assert "kzoracle" not in text and "oracle_lib" not in text and "kz_oracle" not in text, f
     out = os.popen(f"readelf -d {capi.LIB_PATH}").read()
     assert "oracle" not in out
+
+
+ONNX_NETS = {"ataxx7_2x16": 1, "chess_2x32_att": 8, "chess_2x32_dense_h": 8, "go9_2x16_conv_terr": 6}  # name: scalar planes
+
+
+@pytest.mark.parametrize("name", sorted(ONNX_NETS))
+def test_onnx_reader_recovers_the_architecture(name):
+    """N1: the ONNX file the reference's trainer emits (export call of python/lib/save_onnx.py:107-119, run on the
+    reference's modules by oracle/gen_golden.py) parses into the same architecture as the KZMODEL1 container of the
+    same network."""
+    kzm = capi.Model(blob=O.load_blob(name)).info
+    onnx = capi.Model(path=os.path.join(O.GOLDEN, f"{name}.onnx"), onnx_scalar_channels=ONNX_NETS[name]).info
+    for field in ("input_channels", "board_h", "board_w", "input_scalar_channels", "input_bool_channels", "policy_len",
+                  "tower_depth", "tower_channels", "policy_kind", "bits_bytes"):
+        assert getattr(onnx, field) == getattr(kzm, field), field
+    assert onnx.flops_per_eval == kzm.flops_per_eval
+    # generic entry point: ONNX is recognised, but the scalar/bool split is unknown
+    auto = capi.Model(path=os.path.join(O.GOLDEN, f"{name}.onnx")).info
+    assert auto.input_scalar_channels == -1 and auto.bits_bytes == -1 and auto.policy_len == kzm.policy_len
+
+
+def test_onnx_reader_rejects_what_it_does_not_understand():
+    blob = open(os.path.join(O.GOLDEN, "ataxx7_2x16.onnx"), "rb").read()
+    with pytest.raises(capi.KzError, match="ONNX"):
+        capi.Model(blob=blob[:len(blob) // 3], onnx_scalar_channels=1)
+    with pytest.raises(capi.KzError, match="exceeds the input channels"):
+        capi.Model(blob=blob, onnx_scalar_channels=9)
+    # a graph whose op type was renamed is not silently accepted
+    bad = blob.replace(b"BatchNormalization", b"BatchNormalizatioX")
+    with pytest.raises(capi.KzError, match="unsupported ONNX graph"):
+        capi.Model(blob=bad, onnx_scalar_channels=1)

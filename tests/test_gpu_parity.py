@@ -79,6 +79,29 @@ def test_packed_input(dev, name, dtype):
         assert np.abs(softmax(p) - softmax(p_gold)).max() < 5e-3
 
 
+@pytest.mark.parametrize("name,n_scalar", [("ataxx7_2x16", 1), ("chess_2x32_att", 8), ("chess_2x32_dense_h", 8),
+                                           ("go9_2x16_conv_terr", 6)])
+def test_onnx_models_match_golden(dev, name, n_scalar):
+    """N1: the engine fed with the trainer's ONNX file gives the reference PyTorch outputs (<= 1e-4, f32) and agrees
+    with the same network loaded from the KZMODEL1 container."""
+    net = O.OracleNet(O.load_blob(name))
+    x, s_gold, p_gold = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    bits, scalars_in = O.read_packed(name, net.n_bool, net.n_scalar, net.h, net.w)
+    onnx_path = os.path.join(O.GOLDEN, f"{name}.onnx")
+    eng = capi.Engine(capi.Model(path=onnx_path, onnx_scalar_channels=n_scalar), dev, 4, capi.KZ_DTYPE_F32)
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert_f32(s, s_gold, "scalars")
+    assert_f32(p, p_gold, "policy")
+    s2, p2 = capi.Engine(capi.Model(blob=O.load_blob(name)), dev, 4, capi.KZ_DTYPE_F32).eval_packed(bits, scalars_in)
+    assert np.abs(s - s2).max() < 1e-5 and np.abs(p - p2).max() < 1e-5
+    # loaded without the plane split: dense input works, packed input fails loudly
+    blind = capi.Engine(capi.Model(path=onnx_path), dev, 4, capi.KZ_DTYPE_F32)
+    s3, p3 = blind.eval_dense(x)
+    assert_f32(p3, p_gold, "policy (dense)")
+    with pytest.raises(capi.KzError, match="plane split"):
+        blind.eval_packed(bits, scalars_in)
+
+
 def test_per_layer_activations_f32(dev, monkeypatch):
     monkeypatch.setenv("KZ_FORCE_GENERIC", "1")
     monkeypatch.setenv("KZ_KEEP_ACTIVATIONS", "1")
