@@ -48,7 +48,7 @@ pub const KZ_DTYPE_F16: c_int = 1;
 extern "C" {
     fn kz_last_error() -> *const c_char;
     fn kz_device_count(count: *mut c_int) -> c_int;
-    fn kz_model_load(path: *const c_char, out: *mut *mut c_void) -> c_int;
+    fn kz_model_load_onnx(path: *const c_char, input_scalar_channels: c_int, out: *mut *mut c_void) -> c_int;
     fn kz_model_free(model: *mut c_void);
     fn kz_model_get_info(model: *const c_void, out: *mut KzModelInfo) -> c_int;
     fn kz_engine_create(model: *const c_void, device: c_int, max_batch: c_int, dtype: c_int, out: *mut *mut c_void) -> c_int;
@@ -89,10 +89,12 @@ unsafe impl Send for HipModel {}
 unsafe impl Sync for HipModel {}
 
 impl HipModel {
-    pub fn load(path: &str) -> Self {
+    /// `path`: the ONNX file the trainer writes (python/lib/save_onnx.py); `input_scalar_count`: the mapper's, the
+    /// graph itself does not say which of its input planes are broadcast scalars.
+    pub fn load(path: &str, input_scalar_count: usize) -> Self {
         let c_path = CString::new(path).unwrap();
         let mut ptr = std::ptr::null_mut();
-        check(unsafe { kz_model_load(c_path.as_ptr(), &mut ptr) });
+        check(unsafe { kz_model_load_onnx(c_path.as_ptr(), input_scalar_count as c_int, &mut ptr) });
         let mut info = KzModelInfo::default();
         check(unsafe { kz_model_get_info(ptr, &mut info) });
         HipModel { ptr, info }

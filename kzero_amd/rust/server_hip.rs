@@ -111,9 +111,9 @@ impl<B: Board + Hash, M: BoardMapper<B> + 'static> ZeroSpecialization<B, M> for 
         (settings_senders, graph_senders)
     }
 
-    /// Replaces `optimize_graph(&load_graph_from_onnx_path(path, false)?, ..)` (server_alphazero.rs:126-128).
-    /// Today `path` is a KZMODEL1 container written next to the ONNX by the trainer.
-    fn load_graph(&self, path: &str, _: M, _: &StartupSettings) -> HipModel {
-        HipModel::load(path)
+    /// Replaces `optimize_graph(&load_graph_from_onnx_path(path, false)?, ..)` (server_alphazero.rs:126-128): the same
+    /// ONNX path the commander receives in `Command::NewNetwork` (protocol.rs:36) goes straight to the C ABI.
+    fn load_graph(&self, path: &str, mapper: M, _: &StartupSettings) -> HipModel {
+        HipModel::load(path, mapper.input_scalar_count())
     }
 }
