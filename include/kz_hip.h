@@ -91,6 +91,17 @@ int kz_engine_eval_dense(kz_engine *engine, const float *input_nchw, int batch, 
 int kz_engine_eval_packed(kz_engine *engine, const uint8_t *bits, size_t bits_stride, const float *scalars_in,
                           int batch, float *scalars_out, float *policy_out);
 
+/* Packed input AND decoded output: decode_output (rust/kz-core/src/network/common.rs:16-100) runs on the GPU, so only
+ * the decoded values and the probabilities of the available moves cross PCIe (~0.2 KB instead of 7.5 KB per chess eval).
+ * move_offsets [batch+1] (CSR; move_offsets[0] == 0) and move_indices [move_offsets[batch]] list, per board and in
+ * available_moves() order, `PolicyMapper::move_to_index(board, mv)` (kz-core/src/mapping/mod.rs:74) of every available
+ * move; a finished board has an empty range (common.rs:77 `map_or(vec![], ..)`).
+ * values_out [batch,5] = value (tanh), win, draw, loss (softmax), moves_left; probs_out parallel to move_indices.
+ * Fails — where the reference asserts `sum > 0.0` (common.rs:110) — when a softmax sum is not strictly positive. */
+int kz_engine_eval_packed_decoded(kz_engine *engine, const uint8_t *bits, size_t bits_stride, const float *scalars_in,
+                                  int batch, const int64_t *move_offsets, const int32_t *move_indices,
+                                  float *values_out, float *probs_out);
+
 /* ---- asynchronous pair: >= 2 batches in flight per executor thread (replaces gpu_threads_per_device blocking
  * threads, rust/Readme.md:51).  slot in [0, KZ_ENGINE_SLOTS).  Inputs are copied to pinned staging before submit
  * returns; outputs are written to the caller's buffers by kz_engine_wait. */

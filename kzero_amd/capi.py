@@ -47,6 +47,8 @@ SIGNATURES = {
     "kz_engine_eval_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kz_engine_eval_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p]),
+    "kz_engine_eval_packed_decoded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "kz_engine_submit_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     "kz_engine_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kz_engine_enqueue_packed_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
@@ -192,6 +194,22 @@ class Engine:
         check(load().kz_engine_eval_packed(self._h, bits.ctypes.data, stride, scalars_in.ctypes.data, batch,
                                            scalars.ctypes.data, policy.ctypes.data))
         return scalars, policy
+
+    def eval_packed_decoded(self, bits: np.ndarray, scalars_in: np.ndarray, move_lists):
+        """decode_output on the GPU: returns (values [batch,5], [probs per board])."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        scalars_in = np.ascontiguousarray(scalars_in, dtype=np.float32)
+        batch = bits.shape[0]
+        offsets = np.zeros(batch + 1, np.int64)
+        offsets[1:] = np.cumsum([len(m) for m in move_lists])
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(m, np.int32) for m in move_lists] + [np.zeros(0, np.int32)]),
+                                   dtype=np.int32)
+        values = np.empty((batch, 5), np.float32)
+        probs = np.empty(max(len(idx), 1), np.float32)
+        check(load().kz_engine_eval_packed_decoded(self._h, bits.ctypes.data, bits.shape[1] if bits.ndim == 2 else 0,
+                                                   scalars_in.ctypes.data, batch, offsets.ctypes.data, idx.ctypes.data,
+                                                   values.ctypes.data, probs.ctypes.data))
+        return values, [probs[offsets[i]:offsets[i + 1]].copy() for i in range(batch)]
 
     def submit_packed(self, slot: int, bits: np.ndarray, scalars_in: np.ndarray):
         bits = np.ascontiguousarray(bits, dtype=np.uint8)

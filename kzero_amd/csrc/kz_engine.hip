@@ -7,6 +7,7 @@
 // on the generic path) -> ScalarHead -> policy head.  Only `batch` rows are ever touched.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -318,6 +319,12 @@ struct kz_engine {
         int batch = -1;
     } slots[KZ_ENGINE_SLOTS];
     float *d_dense = nullptr, *h_dense = nullptr;
+    // device-side decode (N2): CSR move lists, decoded values, probabilities, error flag; grown on demand
+    size_t move_cap = 0;
+    int64_t *d_moff = nullptr, *h_moff = nullptr;
+    int32_t *d_midx = nullptr, *h_midx = nullptr;
+    float *d_values = nullptr, *h_values = nullptr, *d_probs = nullptr, *h_probs = nullptr;
+    int *d_err = nullptr, *h_err = nullptr;
 
     // debugging
     bool keep = false;
@@ -763,6 +770,63 @@ KZ_API int kz_engine_eval_packed(kz_engine *e, const uint8_t *bits, size_t bits_
                                  int batch, float *scalars_out, float *policy_out) {
     if (kz_engine_submit_packed(e, 0, bits, bits_stride, scalars_in, batch)) return 1;
     return kz_engine_wait(e, 0, scalars_out, policy_out);
+}
+
+KZ_API int kz_engine_eval_packed_decoded(kz_engine *e, const uint8_t *bits, size_t bits_stride, const float *scalars_in,
+                                         int batch, const int64_t *move_offsets, const int32_t *move_indices,
+                                         float *values_out, float *probs_out) {
+    if (check_batch(e, batch, "kz_engine_eval_packed_decoded") || check_packed(e, "kz_engine_eval_packed_decoded")) return 1;
+    if (batch == 0) return 0;
+    if (!bits || !move_offsets || !values_out) return fail("kz_engine_eval_packed_decoded: null argument");
+    const Model &m = *e->model;
+    const size_t bits_bytes = (size_t)(m.n_bool * m.h * m.w + 7) / 8;
+    if (bits_stride < bits_bytes) return fail("kz_engine_eval_packed_decoded: bits_stride too small");
+    if (m.n_scalar && !scalars_in) return fail("kz_engine_eval_packed_decoded: null scalars");
+    if (move_offsets[0] != 0) return fail("kz_engine_eval_packed_decoded: move_offsets[0] must be 0");
+    for (int b = 0; b < batch; b++)
+        if (move_offsets[b + 1] < move_offsets[b]) return fail("kz_engine_eval_packed_decoded: move_offsets must be non-decreasing");
+    const size_t total = (size_t)move_offsets[batch];
+    if (total && (!move_indices || !probs_out)) return fail("kz_engine_eval_packed_decoded: null move list");
+    kz_engine::Slot &s = e->slots[0];
+    if (s.batch >= 0) return fail("kz_engine_eval_packed_decoded: slot 0 still in flight");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->d_moff) {
+        if (e->dmalloc((void **)&e->d_moff, (size_t)(e->max_batch + 1) * 8) || e->hmalloc((void **)&e->h_moff, (size_t)(e->max_batch + 1) * 8) ||
+            e->dmalloc((void **)&e->d_values, (size_t)e->max_batch * 20) || e->hmalloc((void **)&e->h_values, (size_t)e->max_batch * 20) ||
+            e->dmalloc((void **)&e->d_err, 16) || e->hmalloc((void **)&e->h_err, 16))
+            return 1;
+    }
+    if (total > e->move_cap) {  // the old (smaller) buffers stay on the engine's free list until it is destroyed
+        const size_t cap = std::max(total, std::max(e->move_cap * 2, (size_t)e->max_batch * 64));
+        if (e->dmalloc((void **)&e->d_midx, cap * 4) || e->hmalloc((void **)&e->h_midx, cap * 4) ||
+            e->dmalloc((void **)&e->d_probs, cap * 4) || e->hmalloc((void **)&e->h_probs, cap * 4))
+            return 1;
+        e->move_cap = cap;
+    }
+    for (int b = 0; b < batch; b++) memcpy(s.h_bits + b * bits_bytes, bits + b * bits_stride, bits_bytes);
+    if (m.n_scalar) memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
+    memcpy(e->h_moff, move_offsets, (size_t)(batch + 1) * 8);
+    if (total) memcpy(e->h_midx, move_indices, total * 4);
+    *e->h_err = 0;
+    HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_moff, e->h_moff, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, e->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(e->d_midx, e->h_midx, total * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_err, 0, 4, e->stream));
+    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout, s.d_pol)) return 1;
+    e->prof.begin("kz_decode_output", e->stream);
+    kz::launch_decode_output(s.d_sout, s.d_pol, batch, m.policy_len, e->d_moff, e->d_midx, e->d_values, e->d_probs,
+                             e->d_err, e->stream);
+    e->prof.end(e->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_values, e->d_values, (size_t)batch * 20, hipMemcpyDeviceToHost, e->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(e->h_probs, e->d_probs, total * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (*e->h_err) return fail("kz_engine_eval_packed_decoded: Softmax input sum must be strictly positive (or a move index is out of range)");
+    memcpy(values_out, e->h_values, (size_t)batch * 20);
+    if (total) memcpy(probs_out, e->h_probs, total * 4);
+    return 0;
 }
 
 KZ_API int kz_engine_eval_dense(kz_engine *e, const float *input_nchw, int batch, float *scalars_out,

@@ -91,6 +91,12 @@ struct AttentionArgs {
 };
 void launch_attention(int dtype, const AttentionArgs &a, hipStream_t stream);
 
+// F7 — decode_output (rust/kz-core/src/network/common.rs:16-100) on the device: values [batch][5] = tanh / wdl softmax /
+// moves_left; probs = per-board softmax over the logits at the available-move indices (CSR lists).
+void launch_decode_output(const float *scalars, const float *logits, int batch, int policy_len,
+                          const int64_t *move_offsets, const int32_t *move_indices, float *values, float *probs,
+                          int *error_flag, hipStream_t stream);
+
 // ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----
 // Requirements: f16, h*w <= 64, channels == 256 (cp), any depth >= 1.
 struct TowerArgs {

@@ -102,6 +102,31 @@ def test_onnx_models_match_golden(dev, name, n_scalar):
         blind.eval_packed(bits, scalars_in)
 
 
+def test_device_side_decode_output(dev):
+    """N2: decode_output on the GPU (tanh, wdl softmax, legal-move gather + softmax) against the oracle's restatement
+    of rust/kz-core/src/network/common.rs:16-100 applied to the engine's own logits."""
+    name = "chess_2x32_att"
+    blob = O.load_blob(name)
+    net = O.OracleNet(blob)
+    bits, scalars_in = O.read_packed(name, net.n_bool, net.n_scalar, net.h, net.w)
+    rng = np.random.default_rng(9)
+    moves = [rng.permutation(net.policy_len)[:n].astype(np.int32) for n in (37, 0, 300)]  # 0: a finished game
+    eng = capi.Engine(capi.Model(blob=blob), dev, 4, capi.KZ_DTYPE_F32)
+    s, p = eng.eval_packed(bits, scalars_in)
+    v_ref, probs_ref = O.decode_output(s, p, moves)
+    v, probs = eng.eval_packed_decoded(bits, scalars_in, moves)
+    np.testing.assert_allclose(v, v_ref, rtol=1e-5, atol=1e-6)
+    for a, b in zip(probs, probs_ref):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
+    assert abs(probs[0].sum() - 1) < 1e-5 and abs(probs[2].sum() - 1) < 1e-5 and probs[1].size == 0
+    # where the reference asserts (sum > 0.0, common.rs:110) the call fails: an out-of-range index poisons the sum
+    with pytest.raises(capi.KzError, match="strictly positive"):
+        eng.eval_packed_decoded(bits, scalars_in, [np.array([5, net.policy_len], np.int32), moves[1], moves[2]])
+    v2, _ = eng.eval_packed_decoded(bits, scalars_in, moves)  # still usable afterwards
+    assert np.array_equal(v, v2)
+
+
 def test_per_layer_activations_f32(dev, monkeypatch):
     monkeypatch.setenv("KZ_FORCE_GENERIC", "1")
     monkeypatch.setenv("KZ_KEEP_ACTIVATIONS", "1")
