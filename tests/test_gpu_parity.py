@@ -127,6 +127,26 @@ def test_device_side_decode_output(dev):
     assert np.array_equal(v, v2)
 
 
+def test_replay_recorded_positions(dev, tmp_path):
+    """N4: positions recorded in the self-play output format (binary_output.rs:210-256) replay through the engine; the
+    recorded move lists drive the device-side decode."""
+    from kzero_amd.position_file import PositionFile
+    from tests.test_position_file import _games, _write
+    games, shape, ns, pshape = _games(np.random.default_rng(4))
+    path = str(tmp_path / "games_3")
+    _write(path, games, shape, ns, pshape)
+    bits, scalars_in, moves = PositionFile(path).read_boards()
+    blob = O.load_blob("ataxx7_2x16")
+    net = O.OracleNet(blob)
+    s_ref, p_ref = net.forward(O.encode_input_full(bits, scalars_in, 1, 3, 7, 7))
+    v_ref, probs_ref = O.decode_output(s_ref, p_ref, moves)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 16, capi.KZ_DTYPE_F32)
+    v, probs = eng.eval_packed_decoded(bits, scalars_in, moves)
+    np.testing.assert_allclose(v, v_ref, rtol=1e-4, atol=1e-5)
+    for a, b in zip(probs, probs_ref):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
 def test_per_layer_activations_f32(dev, monkeypatch):
     monkeypatch.setenv("KZ_FORCE_GENERIC", "1")
     monkeypatch.setenv("KZ_KEEP_ACTIVATIONS", "1")

@@ -1,0 +1,105 @@
+"""N4: the packed position record format (rust/kz-selfplay/src/binary_output.rs:210-289)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from kzero_amd import synth
+from kzero_amd.position_file import SCALAR_NAMES, PositionFile, PositionFileWriter, PositionRecord
+from tests import oracle_lib as O
+
+REF = "/root/reference/python"
+
+
+def _games(rng, game="ataxx-7", n_games=3):
+    g = synth.GAMES[game]
+    size, policy_len = g["size"], g["policy_len"]
+    games = []
+    for gi in range(n_games):
+        length = 3 + gi
+        bits, scalars = synth.random_boards(game, length + 1, seed=50 + gi, n_bool=3)
+        recs = []
+        for pi in range(length + 1):
+            terminal = pi == length
+            mv = 0 if terminal else int(rng.integers(1, 12))
+            idx = rng.permutation(policy_len)[:mv].astype(np.uint32)
+            vals = rng.uniform(0.1, 1, size=mv).astype(np.float32)
+            vals = vals / vals.sum() if mv else vals
+            sc = {n: 0.0 for n in SCALAR_NAMES}
+            sc.update(game_id=float(gi), pos_index=float(pi), game_length=float(length), zero_visits=100.0,
+                      is_full_search=1.0, is_final_position=float(terminal), is_terminal=float(terminal),
+                      available_mv_count=float(mv), played_mv=float(idx[0]) if mv else -1.0, kdl_policy=0.25,
+                      final_v=1.0, final_wdl_w=1.0, zero_v=0.5, zero_wdl_w=0.6, zero_wdl_d=0.3, zero_wdl_l=0.1,
+                      net_v=0.1, net_wdl_w=0.4, net_wdl_d=0.3, net_wdl_l=0.3, final_moves_left=float(length - pi),
+                      zero_moves_left=3.0, net_moves_left=2.0)
+            recs.append(PositionRecord(sc, bits[pi], scalars[pi], idx, vals))
+        games.append(recs)
+    return games, (3, size, size), 1, (policy_len,)
+
+
+def _write(path, games, shape, n_scalar, policy_shape, game="ataxx-7"):
+    w = PositionFileWriter(path, game, shape, n_scalar, policy_shape)
+    for g in games:
+        w.append_game(g)
+    w.finish()
+
+
+def test_round_trip(tmp_path):
+    games, shape, ns, pshape = _games(np.random.default_rng(1))
+    path = str(tmp_path / "games_0")
+    _write(path, games, shape, ns, pshape)
+    assert not os.path.exists(path + ".json.tmp")
+    f = PositionFile(path)
+    flat = [r for g in games for r in g]
+    assert len(f) == len(flat) and f.meta.game_count == 3
+    assert f.game_starts.tolist() == [0, 4, 9]
+    assert (f.meta.min_game_length, f.meta.max_game_length) == (3, 5)
+    for i, r in enumerate(flat):
+        q = f.position(i)
+        assert q.scalars == pytest.approx(r.scalars)
+        assert np.array_equal(q.bits, r.bits) and np.array_equal(q.input_scalars, r.input_scalars)
+        assert np.array_equal(q.policy_indices, r.policy_indices) and np.array_equal(q.policy_values, r.policy_values)
+    bits, scalars, moves = f.read_boards([0, 5])
+    assert bits.shape == (2, 19) and scalars.shape == (2, 1) and len(moves[1]) == int(flat[5].scalars["available_mv_count"])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference's own reader only exists in the build container")
+def test_reference_reader_accepts_our_files(tmp_path):
+    """Pins the writer against the reference's own consumer of this format: python/lib/data/file.py + position.py."""
+    games, shape, ns, pshape = _games(np.random.default_rng(2))
+    path = str(tmp_path / "games_7")
+    _write(path, games, shape, ns, pshape)
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        from lib.data.file import DataFile
+        from lib.games import Game
+        df = DataFile.open(Game.find("ataxx-7"), path)
+        flat = [r for g in games for r in g]
+        assert len(df.positions) == len(flat) and len(df.simulations) == 3
+        for i, r in enumerate(flat):
+            p = df.positions[i]
+            assert p.move_index == int(r.scalars["pos_index"]) and p.available_mv_count == len(r.policy_indices)
+            unpacked = np.unpackbits(r.bits, bitorder="little")[:3 * 49].reshape(3, 7, 7)
+            assert np.array_equal(p.input_bools, unpacked)
+            assert np.array_equal(p.input_scalars, r.input_scalars)
+            assert np.array_equal(p.policy_indices, r.policy_indices.astype(np.int32))
+            assert np.array_equal(p.policy_values, r.policy_values)
+            assert p.zero_v == pytest.approx(0.5) and p.is_final == bool(r.scalars["is_final_position"])
+        sim = df.simulations[1]
+        assert sim.start_file_pi == 4 and sim.move_count == 4
+    finally:
+        sys.path.remove(REF)
+
+
+def test_recorded_boards_are_engine_inputs(tmp_path):
+    """The board part of a record is the packed engine input: expanding it gives the planes of encode_input_full."""
+    games, shape, ns, pshape = _games(np.random.default_rng(3))
+    path = str(tmp_path / "games_1")
+    _write(path, games, shape, ns, pshape)
+    bits, scalars, _ = PositionFile(path).read_boards()
+    dense = O.encode_input_full(bits, scalars, 1, 3, 7, 7)
+    assert dense.shape == (15, 4, 7, 7)
+    assert np.array_equal(dense[:, 0, 0, 0], scalars[:, 0])
+    assert np.array_equal(dense[3, 1:].reshape(-1).astype(np.uint8), np.unpackbits(bits[3], bitorder="little")[:147])
