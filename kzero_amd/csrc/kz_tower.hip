@@ -40,7 +40,6 @@ constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row: 512 B of channels + 
 constexpr int URS = 3 * C * 2 + 16;  // row stride of the conv_under image (768 channels)
 constexpr int KSTEPS = 72;      // 9 taps x 8 chunks of 32 channels
 constexpr int HEAD_KSTEPS = 5 * 8;  // conv_under as 3 passes of 256 channels, conv_bulk as 2: 8 k-steps each
-constexpr int PF = 4;           // weight prefetch distance in k-steps (register stages)
 constexpr int POLICY = 1880, LOGIT_LD = 96;  // 64 x 88 attention logits, rows padded to 96
 
 struct TowerDev {
@@ -83,7 +82,10 @@ struct Layout {
 // LLVM SchedGroupMask bits for __builtin_amdgcn_sched_group_barrier
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
-template <int NB, bool HEADS>
+// PF = weight prefetch distance in k-steps (register ring stages, a power of two <= 8); PF * 16 KB are in flight per
+// CU.  Measured at one board per workgroup: PF = 8 is SLOWER than PF = 4 (0.665 vs 0.611 ms per batch) — that
+// configuration is bound by L2->CU bandwidth (~80 GB/s per CU), not by latency.
+template <int NB, bool HEADS, int PF>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     using L = Layout<NB>;
     constexpr int M = L::M, MT = L::MT;
@@ -499,6 +501,14 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     }
 }
 
+#ifndef KZ_PF_NB1
+#define KZ_PF_NB1 4
+#endif
+#ifndef KZ_PF_NB2
+#define KZ_PF_NB2 4
+#endif
+constexpr int PF_NB1 = KZ_PF_NB1, PF_NB2 = KZ_PF_NB2;
+
 int boards_per_wg() {
     static int nb = [] {
         const char *e = getenv("KZ_TOWER_NB");
@@ -605,26 +615,18 @@ void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
     d.att_idx = t.att_idx;
     d.scalars = t.scalars;
     d.policy = t.policy;
-    static bool attr_done = [] {
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Layout<1>::BYTES);
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Layout<2>::BYTES);
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Layout<1>::BYTES);
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Layout<2>::BYTES);
-        return true;
-    }();
-    (void)attr_done;
     const bool heads = t.fused_heads;
+    auto launch = [&](auto kernel, int grid, int bytes) {
+        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        kernel<<<grid, 256, bytes, stream>>>(d);
+    };
     if (boards_per_wg() == 1) {
-        if (heads) kz_tower_resident<1, true><<<t.batch, 256, Layout<1>::BYTES, stream>>>(d);
-        else kz_tower_resident<1, false><<<t.batch, 256, Layout<1>::BYTES, stream>>>(d);
+        if (heads) launch(kz_tower_resident<1, true, PF_NB1>, t.batch, Layout<1>::BYTES);
+        else launch(kz_tower_resident<1, false, PF_NB1>, t.batch, Layout<1>::BYTES);
     } else {
         const int grid = (t.batch + 1) / 2;
-        if (heads) kz_tower_resident<2, true><<<grid, 256, Layout<2>::BYTES, stream>>>(d);
-        else kz_tower_resident<2, false><<<grid, 256, Layout<2>::BYTES, stream>>>(d);
+        if (heads) launch(kz_tower_resident<2, true, PF_NB2>, grid, Layout<2>::BYTES);
+        else launch(kz_tower_resident<2, false, PF_NB2>, grid, Layout<2>::BYTES);
     }
 }
 
