@@ -134,7 +134,8 @@ def main():
     # dominant kernel, timed with HIP events on the engines' own streams over the timed region
     tower_path = engines[0].tower_path
     kname = {"tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
-             "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
+             "board_conv_f16": "kz_board_conv_f16", "conv_igemm_f16": "kz_conv_igemm_f16",
+             "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
     k_ms, k_n = 0.0, 0
     for e in engines:
         ms, n = e.kernel_time(kname)
@@ -160,6 +161,9 @@ def main():
         flops_per_launch = info.flops_per_eval * B  # one launch = tower + heads for one batch
     elif tower_path == "tower_resident_f16":
         flops_per_launch = tower_flops * B  # one launch = the whole tower for one batch
+    elif tower_path == "board_conv_f16":
+        # one launch per 3x3 tower convolution except the stem (which has too few input channels for this kernel)
+        flops_per_launch = 2.0 * hw * 9 * C * C * B
     else:
         # per-layer launches (tower + the 1x1 head convolutions that share the kernel): average over the step
         head_flops = info.flops_per_eval - tower_flops

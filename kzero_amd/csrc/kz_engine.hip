@@ -59,6 +59,7 @@ struct DevConv {  // packed for kz_conv_igemm: [k*k][cout_p][cin_p] in T, bias f
     void *w = nullptr;
     float *b = nullptr;
     int cin_p = 0, cout_p = 0, cout = 0, k = 1;
+    void *bw = nullptr;  // instead of w: packed for kz_board_conv_f16 (3x3, f16, channels % 128 == 0)
 };
 
 struct DeviceWeights {
@@ -111,6 +112,17 @@ struct DeviceWeights {
         return upload(p.data(), p.size() * 2, dst);
     }
 
+    // 3x3 tower conv for the board-tile kernel (kz_board_conv.hip)
+    int upload_board_conv(const Conv &cv, DevConv &d) {
+        d.k = 3;
+        d.cout = d.cout_p = cv.cout;
+        d.cin_p = cv.cin;
+        std::vector<uint16_t> packed(kz::board_conv_weight_elems(cv.cin, cv.cout));
+        kz::board_conv_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        if (upload(packed.data(), packed.size() * 2, &d.bw)) return 1;
+        return upload_f32(cv.b, &d.b);
+    }
+
     // OIHW conv -> [tap][cout_p][cin_p]; tap = ky*k + kx
     int upload_conv(const Conv &cv, DevConv &d) {
         d.k = cv.k;
@@ -161,6 +173,7 @@ struct DeviceWeights {
         return upload_f32(b, &d.b);
     }
 
+    bool use_board_conv = false;
     int build(const Model &m, bool want_resident, bool want_fused) {
         const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
         HIP_TRY(hipSetDevice(device));
@@ -197,8 +210,12 @@ struct DeviceWeights {
             if (upload_f32(bias, &res_bias)) return 1;
         } else {
             tower.resize(m.tower.size());
-            for (size_t i = 0; i < m.tower.size(); i++)
-                if (upload_conv(m.tower[i], tower[i])) return 1;
+            const char *noboard = getenv("KZ_NO_BOARD_CONV");
+            for (size_t i = 0; i < m.tower.size(); i++) {
+                const bool board = use_board_conv && !(noboard && noboard[0] == '1') &&
+                                   kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
+                if (board ? upload_board_conv(m.tower[i], tower[i]) : upload_conv(m.tower[i], tower[i])) return 1;
+            }
         }
 
         // scalar head: w0 [hc][C] is the OIHW 1x1 conv as is; w1 keeps the channel-major flatten order
@@ -243,7 +260,7 @@ struct DeviceWeights {
 };
 
 std::mutex g_cache_mutex;
-std::map<std::tuple<const Model *, int, int, bool, bool>, std::weak_ptr<DeviceWeights>> g_cache;
+std::map<std::tuple<const Model *, int, int, bool, bool, bool>, std::weak_ptr<DeviceWeights>> g_cache;
 
 struct Prof {
     struct Rec {
@@ -358,6 +375,18 @@ struct kz_engine {
 
     int conv(const DevConv &w, const void *x, int ldx, void *y, int ldy, int M, int relu, const void *res, bool post,
              int h, int wd, int group, int src_group, int src_off, float *y32 = nullptr, int ldy32 = 0) {
+        if (w.bw) {  // whole boards as LDS-resident spatial tiles
+            kz::BoardConvArgs b{};
+            b.x = x; b.ldx = ldx; b.weights = w.bw; b.bias = w.b; b.res = res; b.y = y; b.ldy = ldy;
+            b.post_scale = post ? wts->post_scale : nullptr;
+            b.post_shift = post ? wts->post_shift : nullptr;
+            b.boards = M / (h * wd); b.h = h; b.w = wd; b.cin = w.cin_p; b.cout = w.cout; b.relu = relu;
+            prof.begin("kz_board_conv_f16", stream);
+            kz::launch_board_conv(b, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         kz::ConvArgs a{};
         a.x = x; a.ldx = ldx; a.w = w.w; a.bias = w.b; a.res = res; a.ldres = ldy;
         a.post_scale = post ? wts->post_scale : nullptr;
@@ -644,21 +673,29 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->fused_heads = e->resident && !(nofuse && nofuse[0] == '1') &&
                      kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,
                                                m.sh_fc0.out);
+    const char *noboard = getenv("KZ_NO_BOARD_CONV");
+    // the board-tile kernel needs enough workgroups to fill the chip: 24 / ceil(hw/16) boards per workgroup
+    const int bc_tpb = (m.h * m.w + 15) / 16, bc_bpw = bc_tpb <= 24 ? 24 / bc_tpb : 1;
+    const bool board_conv = !e->resident && !(noboard && noboard[0] == '1') && m.depth >= 1 &&
+                            kz::board_conv_supported(dtype, m.h, m.w, m.channels, m.channels) &&
+                            ((max_batch + bc_bpw - 1) / bc_bpw) * (m.channels / 128) >= 80;
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
+              : board_conv   ? "board_conv_f16"
                              : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
     const char *keep = getenv("KZ_KEEP_ACTIVATIONS");
     e->keep = keep && keep[0] == '1' && !e->resident;
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident, e->fused_heads);
+        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident, e->fused_heads, board_conv);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) e->wts = it->second.lock();
         if (!e->wts) {
             auto w = std::make_shared<DeviceWeights>();
             w->device = device;
             w->dtype = dtype;
+            w->use_board_conv = board_conv;
             if (w->build(m, e->resident, e->fused_heads)) return 1;
             g_cache[key] = w;
             e->wts = w;

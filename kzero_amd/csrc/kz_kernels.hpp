@@ -97,6 +97,22 @@ void launch_decode_output(const float *scalars, const float *logits, int batch, 
                           const int64_t *move_offsets, const int32_t *move_indices, float *values, float *probs,
                           int *error_flag, hipStream_t stream);
 
+// ---- per-layer 3x3 convolution with the board as an LDS-resident spatial tile (kz_board_conv.hip): f16, cin and cout
+// multiples of 128, h*w <= 384.  Same epilogue contract as ConvArgs. ----
+struct BoardConvArgs {
+    const void *x;   // [boards*h*w][ldx] f16
+    int ldx;
+    const void *weights;  // board_conv_pack_weights layout
+    const float *bias, *post_scale, *post_shift;
+    const void *res; // optional, [boards*h*w][ldy]
+    void *y;
+    int ldy, boards, h, w, cin, cout, relu;
+};
+bool board_conv_supported(int dtype, int h, int w, int cin, int cout);
+size_t board_conv_weight_elems(int cin, int cout);
+void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
+void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);
+
 // ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----
 // Requirements: f16, h*w <= 64, channels == 256 (cp), any depth >= 1.
 struct TowerArgs {

@@ -616,8 +616,16 @@ void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
     d.scalars = t.scalars;
     d.policy = t.policy;
     const bool heads = t.fused_heads;
+    // (the dynamic-LDS attribute is per device: set it on every launch's current device, it is a cheap host call,
+    //  but only once per kernel and device)
     auto launch = [&](auto kernel, int grid, int bytes) {
-        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        static thread_local unsigned long long done_mask = 0;  // per instantiation (the lambda is generic)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((done_mask >> (dev & 63)) & 1)) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            done_mask |= 1ull << (dev & 63);
+        }
         kernel<<<grid, 256, bytes, stream>>>(d);
     };
     if (boards_per_wg() == 1) {

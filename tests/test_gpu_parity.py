@@ -306,7 +306,7 @@ def test_full_size_properties(dev, chess_full):
             gen = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
         finally:
             del os.environ["KZ_FORCE_GENERIC"]
-        assert gen.tower_path == "conv_igemm_f16"
+        assert gen.tower_path in ("board_conv_f16", "conv_igemm_f16")
         sg, pg = gen.eval_packed(bits, scalars_in)
         # both are f16-storage/f32-accumulate; they differ only in summation order
         assert np.abs(sg - s).max() < 2e-2 and np.abs(pg - p).max() < 2e-2
@@ -341,6 +341,33 @@ def test_go19_generic_path_vs_oracle(dev):
     s, p = eng.eval_packed(bits, scalars_in)
     assert_f32(s, s_ref, "scalars")
     assert_f32(p, p_ref, "policy")
+
+
+@pytest.mark.parametrize("game,depth,batch", [("go-19", 2, 5), ("go-9", 2, 11), ("ataxx-7", 2, 13)])
+def test_board_conv_path_vs_oracle(dev, game, depth, batch):
+    """f16 per-layer path with whole boards as LDS-resident spatial tiles (kz_board_conv_f16): 128-channel towers on
+    boards of 1 (go-19), 4 (go-9) and 6 (ataxx-7) boards per workgroup, ragged last workgroup included; and the same
+    engine with that kernel disabled (generic implicit GEMM) must agree with it."""
+    head = "ataxx_conv" if game.startswith("ataxx") else "conv"
+    blob = synth.random_model(game, depth, 128, head, seed=41)
+    bits, scalars_in = synth.random_boards(game, batch, seed=42)
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    model = capi.Model(blob=blob)
+    eng = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
+    assert eng.tower_path == "board_conv_f16"
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert_f16(s, s_ref, "scalars")
+    assert_f16(p, p_ref, "policy")
+    os.environ["KZ_NO_BOARD_CONV"] = "1"
+    try:
+        gen = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
+    finally:
+        del os.environ["KZ_NO_BOARD_CONV"]
+    assert gen.tower_path == "conv_igemm_f16"
+    sg, pg = gen.eval_packed(bits, scalars_in)
+    assert np.abs(sg - s).max() < 5e-3 and np.abs(pg - p).max() < 2e-2
 
 
 def test_profiling_reports_kernel_time(dev):
