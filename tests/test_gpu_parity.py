@@ -330,6 +330,23 @@ def test_fused_heads_match_separate_head_kernels(dev, chess_full):
         assert np.abs(p1 - p2).max() < 1e-2, np.abs(p1 - p2).max()
 
 
+def test_dense_and_packed_inputs_agree_on_the_resident_path(dev):
+    """kz_engine_eval_dense (bit-compatible with CudaExecutor::evaluate: f32 NCHW planes) and kz_engine_eval_packed
+    (bits + scalars, encode fused into the launch) must give identical results: same planes, same kernel."""
+    blob = synth.random_model("chess", 2, 256, "attention", seed=51)
+    bits, scalars_in = synth.random_boards("chess", 37, seed=52)
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 64, capi.KZ_DTYPE_F16)
+    assert eng.tower_path == "tower_resident_f16+heads"
+    s1, p1 = eng.eval_packed(bits, scalars_in)
+    s2, p2 = eng.eval_dense(dense)
+    assert np.array_equal(s1, s2) and np.array_equal(p1, p2)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    assert_f16(s1, s_ref, "scalars")
+    assert_f16(p1, p_ref, "policy")
+
+
 def test_go19_generic_path_vs_oracle(dev):
     """Large board (19x19, 13 input planes, conv head + pass move): the per-layer implicit-GEMM path."""
     blob = synth.random_model("go-19", 3, 64, "conv", seed=31)
