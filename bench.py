@@ -48,13 +48,34 @@ WORKLOADS = {
 }
 
 
+def usable_cores():
+    """Host threads this process can actually run on: the affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the machine, not the container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(blob, bits, scalars_in, target_seconds):
     """The CPU restatement (oracle, kind 'port') timed on this box's host cores, on a bounded sample of the same
     boards.  Reported beside the GPU number; never the thing measured as `value`."""
     import numpy as np
     from tests import oracle_lib as O
     net = O.OracleNet(blob)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
     t0 = time.perf_counter()
     net.forward(dense[:1], threads=1)
@@ -67,7 +88,8 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 3), "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{n} boards of the same synthetic batch, oracle/kz_oracle.c f32 NCHW direct conv, "
-                      f"OpenMP over boards on {cores} threads, {dt:.1f} s; single-thread {1.0 / one:.3f} evals/s"}
+                      f"OpenMP over boards on {cores} threads (of {os.cpu_count()} the machine reports), {dt:.1f} s; "
+                      f"single-thread {1.0 / one:.3f} evals/s"}
 
 
 def main():

@@ -1,0 +1,90 @@
+// device_threads.hpp — per-device construction of the executor side
+// (rust/kz-selfplay/src/server/server_alphazero.rs:32-124, `AlphaZeroSpecialization::spawn_device_threads`):
+// one job channel per device, `gpu_threads` OS threads each running batched_executor_loop with its own network
+// (engines of one device share the uploaded weights), every executed batch reported as ExpandEvals(real, potential).
+// The generator side (MCTS, futures thread pool) stays the caller's.
+#pragma once
+#include <atomic>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "executor.hpp"
+#include "hip_network.hpp"
+
+namespace kz::host {
+
+inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }  // kz_util::math::ceil_div
+
+// rust/kz-selfplay/src/server/protocol.rs:10-29 (the fields this layer reads)
+struct StartupSettings {
+    size_t cpu_threads_per_device = 4;
+    size_t gpu_threads_per_device = 2;
+    size_t gpu_batch_size = 256;
+    size_t search_batch_size = 16;
+};
+
+struct DeviceSizing {
+    size_t concurrent_games, eval_job_count, job_buffer_size;
+    explicit DeviceSizing(const StartupSettings &s)
+        : concurrent_games(ceil_div((s.gpu_threads_per_device + 1) * s.gpu_batch_size, s.search_batch_size)),  // :47
+          eval_job_count(s.gpu_batch_size / s.search_batch_size),                                              // :48
+          job_buffer_size(ceil_div(s.gpu_threads_per_device * s.gpu_batch_size, s.search_batch_size)) {}       // :55
+};
+
+// Evals::new(real, potential, cached) (protocol.rs:52-72); `real`/s is the north-star metric (collector.rs:172-191)
+struct EvalCounters {
+    std::atomic<uint64_t> real{0}, potential{0};
+};
+
+template <class B, class M>
+struct DeviceExecutors {
+    using Graph = std::shared_ptr<const HipModel>;
+    JobClient<B, ZeroEvaluation> eval_client;
+    std::vector<Sender<std::optional<Graph>>> graph_senders;  // one per executor thread (commander.rs:19-25)
+    std::vector<std::thread> threads;
+
+    void send_graph(std::optional<Graph> g) {
+        for (auto &s : graph_senders) s.send(g);
+    }
+    // drop the channel ends and wait for the executors to drain and exit
+    void join() {
+        eval_client = JobClient<B, ZeroEvaluation>();
+        graph_senders.clear();
+        for (auto &t : threads) t.join();
+        threads.clear();
+    }
+};
+
+// server_alphazero.rs:89-121
+template <class B, class M>
+std::unique_ptr<DeviceExecutors<B, M>> spawn_device_executors(int device, const StartupSettings &startup, M mapper,
+                                                               int dtype, EvalCounters *counters) {
+    const DeviceSizing sizing(startup);
+    auto dev = std::make_unique<DeviceExecutors<B, M>>();
+    auto [client, server] = job_pair<B, ZeroEvaluation>(sizing.job_buffer_size);
+    dev->eval_client = client;
+    const size_t gpu_batch_size = startup.gpu_batch_size;
+    for (size_t local_id = 0; local_id < startup.gpu_threads_per_device; local_id++) {
+        auto [gtx, grx] = bounded<std::optional<typename DeviceExecutors<B, M>::Graph>>(1);  // :90
+        dev->graph_senders.push_back(gtx);
+        dev->threads.emplace_back([=, srv = server, rx = std::move(grx)]() mutable {
+            using Net = HipNetwork<B, M>;
+            batched_executor_loop<typename DeviceExecutors<B, M>::Graph, Net, B, ZeroEvaluation>(
+                gpu_batch_size, RunCondition::job_count(sizing.eval_job_count), std::move(rx), std::move(srv),
+                [=](typename DeviceExecutors<B, M>::Graph g) { return Net(mapper, std::move(g), gpu_batch_size, device, dtype); },
+                [=](Net &net, const B *x, size_t n) {
+                    auto y = net.evaluate_batch(x, n);
+                    if (counters) {
+                        counters->real += n;  // ExpandEvals(real = x.len(), potential = gpu_batch_size) (:113-115)
+                        counters->potential += gpu_batch_size;
+                    }
+                    return y;
+                });
+        });
+    }
+    return dev;
+}
+
+}  // namespace kz::host

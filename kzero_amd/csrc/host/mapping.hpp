@@ -242,7 +242,13 @@ struct PackedMapper {
     size_t move_to_index(const PackedBoard &, int32_t mv) const { return (size_t)mv; }
     void encode_input(BitBuffer &bools, std::vector<float> &scalars, const PackedBoard &b) const {
         const size_t n = planes * h * w;
-        for (size_t i = 0; i < n; i++) bools.push((b.bits[i / 8] >> (i % 8)) & 1);
+        size_t i = 0;
+        for (; i + 64 <= n; i += 64) {  // whole 64-bit blocks, like the chess mapper's push_block (chess.rs:160-169)
+            uint64_t v = 0;
+            for (int k = 0; k < 8; k++) v |= (uint64_t)b.bits[i / 8 + k] << (8 * k);
+            bools.push_block(v);
+        }
+        for (; i < n; i++) bools.push((b.bits[i / 8] >> (i % 8)) & 1);
         scalars.insert(scalars.end(), b.scalars.begin(), b.scalars.end());
     }
 };

@@ -1,0 +1,89 @@
+// bench_executor.cpp — NN evals/s THROUGH the drop-in seam: generator threads -> job channel -> batched_executor_loop ->
+// HipNetwork::evaluate_batch (host encode_input, kz_engine_eval_packed over PCIe, host decode_output) -> replies.
+// Sized like the self-play server (rust/kz-selfplay/src/server/server_alphazero.rs:47-55) and counted like its
+// collector (`real` evals/s, collector.rs:172-191).  Not a test: a measurement of the host side next to bench.py.
+//
+//   bench_executor <model.kzm|onnx> <seconds> <gpu_threads> <generator_threads> [gpu_batch] [search_batch] [dtype]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../kzero_amd/csrc/host/device_threads.hpp"
+
+using namespace kz::host;
+
+int main(int argc, char **argv) {
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: %s model seconds gpu_threads generator_threads [gpu_batch] [search_batch] [f16|f32]\n", argv[0]);
+        return 2;
+    }
+    const double seconds = atof(argv[2]);
+    StartupSettings st;
+    st.gpu_threads_per_device = (size_t)atoi(argv[3]);
+    const int generators = atoi(argv[4]);
+    if (argc > 5) st.gpu_batch_size = (size_t)atoi(argv[5]);
+    if (argc > 6) st.search_batch_size = (size_t)atoi(argv[6]);
+    const int dtype = (argc > 7 && std::string(argv[7]) == "f32") ? KZ_DTYPE_F32 : KZ_DTYPE_F16;
+
+    auto model = std::make_shared<const HipModel>(argv[1]);
+    const kz_model_info info = model->info;
+    PackedMapper mapper{(size_t)info.input_bool_channels, (size_t)info.board_h, (size_t)info.board_w,
+                        (size_t)info.input_scalar_channels, (size_t)info.policy_len};
+    // a pool of synthetic positions with ~30 legal moves each
+    std::mt19937 rng(1);
+    std::vector<PackedBoard> pool(1024);
+    for (auto &b : pool) {
+        b.bits.resize((size_t)info.bits_bytes);
+        for (auto &byte : b.bits) byte = (uint8_t)(rng() & rng() & rng() & 0xff);
+        b.scalars.assign((size_t)info.input_scalar_channels, 0.0f);
+        if (!b.scalars.empty()) b.scalars[0] = 1.0f;
+        std::vector<int32_t> moves(20 + rng() % 21);
+        for (auto &m : moves) m = (int32_t)(rng() % info.policy_len);
+        b.moves = moves;
+    }
+
+    EvalCounters counters;
+    auto dev = spawn_device_executors<PackedBoard, PackedMapper>(0, st, mapper, dtype, &counters);
+    dev->send_graph(model);
+    const DeviceSizing sizing(st);
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> replies{0};
+    // each generator thread stands for concurrent_games / generators games, each with one request in flight
+    const size_t games_per_thread = ceil_div(sizing.concurrent_games, (size_t)generators);
+    std::vector<std::thread> gens;
+    for (int t = 0; t < generators; t++)
+        gens.emplace_back([&, t, client = dev->eval_client] {
+            std::mt19937 r(100 + t);
+            std::vector<Receiver<std::vector<ZeroEvaluation>>> inflight;
+            auto request = [&] {
+                std::vector<PackedBoard> x;
+                for (size_t k = 0; k < st.search_batch_size; k++) x.push_back(pool[r() % pool.size()]);
+                return client.map(std::move(x));
+            };
+            for (size_t gme = 0; gme < games_per_thread; gme++) inflight.push_back(request());
+            size_t next = 0;
+            while (!stop) {
+                auto y = inflight[next].recv();
+                if (!y) break;
+                replies += y->size();
+                inflight[next] = request();
+                next = (next + 1) % inflight.size();
+            }
+        });
+    std::this_thread::sleep_for(std::chrono::milliseconds(500));  // warm-up
+    const uint64_t r0 = counters.real, p0 = counters.potential;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    const uint64_t r1 = counters.real, p1 = counters.potential;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    stop = true;
+    std::printf("{\"evals_per_s\": %.1f, \"fill\": %.3f, \"gpu_threads\": %zu, \"generator_threads\": %d, "
+                "\"concurrent_games\": %zu, \"gpu_batch\": %zu, \"search_batch\": %zu, \"seconds\": %.2f}\n",
+                (r1 - r0) / dt, (double)(r1 - r0) / (double)(p1 - p0 ? p1 - p0 : 1), st.gpu_threads_per_device, generators,
+                sizing.concurrent_games, st.gpu_batch_size, st.search_batch_size, dt);
+    std::fflush(stdout);
+    // generators block in recv(); the process exit tears everything down (the reference server has no clean stop
+    // either: commander.rs:63-64)
+    std::_Exit(0);
+}
