@@ -314,7 +314,14 @@ struct kz_engine {
     std::shared_ptr<DeviceWeights> wts;
     int device = 0, dtype = 0, max_batch = 0;
     size_t esz = 4;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the stream the forward pass is currently enqueued on
+    hipStream_t slot_stream[KZ_ENGINE_SLOTS] = {};  // [0] = the main stream; [1..]: own streams on the fused path, where
+                                                    // a launch touches nothing but its slot's buffers
+    int sync_all() {
+        for (auto st : slot_stream)
+            if (st) HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
     std::vector<void *> allocs, pinned;
     bool resident = false, fused_heads = false;
     std::string path;
@@ -635,13 +642,15 @@ KZ_API int kz_model_get_info(const kz_model *model, kz_model_info *out) {
 KZ_API void kz_engine_destroy(kz_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto st : e->slot_stream)
+        if (st) (void)hipStreamSynchronize(st);
     e->prof.destroy();
     for (auto &s : e->slots)
         if (s.done) (void)hipEventDestroy(s.done);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->pinned) (void)hipHostFree(p);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    for (auto st : e->slot_stream)
+        if (st) (void)hipStreamDestroy(st);
     e->wts.reset();
     delete e;
 }
@@ -702,7 +711,10 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         }
     }
 
-    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[0], hipStreamNonBlocking));
+    e->stream = e->slot_stream[0];
+    if (e->fused_heads)
+        for (int i = 1; i < KZ_ENGINE_SLOTS; i++) HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[i], hipStreamNonBlocking));
     const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
     if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
     const int nact = e->resident ? 1 : 3;
@@ -778,6 +790,14 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
     if (batch == 0) return 0;
     for (int b = 0; b < batch; b++) memcpy(s.h_bits + b * bits_bytes, bits + b * bits_stride, bits_bytes);
     memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
+    // on the fused path every slot has its own stream, so two submitted batches run side by side (each resident
+    // launch covers half of the CUs at batch 256); otherwise the slots share the activation buffers and one stream
+    struct StreamSwap {
+        kz_engine *e;
+        hipStream_t saved;
+        ~StreamSwap() { e->stream = saved; }
+    } swap{e, e->stream};
+    if (e->slot_stream[slot]) e->stream = e->slot_stream[slot];
     HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
     if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout, s.d_pol)) return 1;
@@ -917,8 +937,7 @@ KZ_API int kz_engine_enqueue_dense_device(kz_engine *e, const void *d_input_nchw
 KZ_API int kz_engine_synchronize(kz_engine *e) {
     if (!e) return fail("kz_engine_synchronize: null engine");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return 0;
+    return e->sync_all();
 }
 
 KZ_API int kz_device_malloc(int device, size_t bytes, void **out) {
@@ -955,7 +974,7 @@ KZ_API int kz_device_synchronize(int device) {
 KZ_API int kz_engine_set_profiling(kz_engine *e, int enable) {
     if (!e) return fail("kz_engine_set_profiling: null engine");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->sync_all()) return 1;
     e->prof.clear();
     e->prof.on = enable != 0;
     return 0;
@@ -964,7 +983,7 @@ KZ_API int kz_engine_set_profiling(kz_engine *e, int enable) {
 KZ_API int kz_engine_kernel_time(kz_engine *e, const char *prefix, double *total_ms, int64_t *launches) {
     if (!e || !prefix || !total_ms || !launches) return fail("kz_engine_kernel_time: null argument");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->sync_all()) return 1;
     double total = 0;
     int64_t n = 0;
     const size_t plen = strlen(prefix);
