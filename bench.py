@@ -27,8 +27,8 @@ sys.path.insert(0, REPO)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=256, help="executor batch (gpu_batch_size)")
     ap.add_argument("--engines", type=int, default=2, help="executor engines (streams) per GPU")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
