@@ -347,6 +347,27 @@ def test_dense_and_packed_inputs_agree_on_the_resident_path(dev):
     assert_f16(p1, p_ref, "policy")
 
 
+def test_large_batches_and_engine_churn(dev):
+    """Maximum sizes: a 2048-board executor batch (1024 resident workgroups, 4 per CU queued) gives, row for row, the
+    results of small batches; engines can be created and destroyed repeatedly without disturbing others."""
+    blob = synth.random_model("chess", 2, 256, "attention", seed=61)
+    bits, scalars_in = synth.random_boards("chess", 2048, seed=62)
+    model = capi.Model(blob=blob)
+    big = capi.Engine(model, dev, 2048, capi.KZ_DTYPE_F16)
+    s, p = big.eval_packed(bits, scalars_in)
+    assert np.isfinite(p).all() and np.isfinite(s).all()
+    small = capi.Engine(model, dev, 64, capi.KZ_DTYPE_F16)
+    for lo in (0, 1000, 1984):
+        s2, p2 = small.eval_packed(bits[lo:lo + 64], scalars_in[lo:lo + 64])
+        assert np.array_equal(s2, s[lo:lo + 64]) and np.array_equal(p2, p[lo:lo + 64])
+    for i in range(5):
+        tmp = capi.Engine(model, dev, 32 + i, capi.KZ_DTYPE_F16 if i % 2 else capi.KZ_DTYPE_F32)
+        tmp.eval_packed(bits[:3], scalars_in[:3])
+        tmp.close()
+    s3, _ = small.eval_packed(bits[:64], scalars_in[:64])
+    assert np.array_equal(s3, s[:64])
+
+
 def test_go19_generic_path_vs_oracle(dev):
     """Large board (19x19, 13 input planes, conv head + pass move): the per-layer implicit-GEMM path."""
     blob = synth.random_model("go-19", 3, 64, "conv", seed=31)
