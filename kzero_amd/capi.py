@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkzhip.so")
+LIB_PATH = os.environ.get("KZ_LIB_PATH") or os.path.join(_HERE, "libkzhip.so")
 
 KZ_DTYPE_F32 = 0
 KZ_DTYPE_F16 = 1

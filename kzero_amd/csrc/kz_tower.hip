@@ -300,19 +300,20 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[cur][mt], acc[nt][mt], 0, 0, 0);
-                // issue order: the LDS reads and the weight loads ride in the shadow of the MFMAs
-                constexpr int PER = (4 * MT) / (MT + 4) >= 2 ? 2 : 1;  // MFMAs per memory instruction
-#pragma unroll
-                for (int i = 0; i < MT; i++) {
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, PER, 0);
-                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
-                }
+                // issue order: every memory instruction rides in the shadow of one MFMA — first the 4 ring refills,
+                // then the MT LDS fragment reads, then the remaining MFMAs back to back.  (Same-box A/B: +0.5 % over a
+                // 2:1 interleave with the LDS reads first, +3 % over the compiler's own order.)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, PER, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4 * MT - PER * (MT + 4), 0);
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4 * MT - (MT + 4), 0);
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
