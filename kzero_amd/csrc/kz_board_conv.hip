@@ -44,6 +44,7 @@ struct BoardConvDev {
     const h16 *res;     // optional residual [boards*hw][ldy]
     h16 *y;             // [boards*hw][ldy]
     int ldx, ldy, boards, h, w_, hw, tpb, bpw, cin, relu;
+    unsigned inv_w;  // ceil(65536 / w): q / w == (q * inv_w) >> 16 for q < 512, w <= 32
 };
 
 __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
@@ -79,16 +80,16 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
     // so a tap costs 3 VALU per tile in the k-loop instead of a dozen.
     unsigned rowmask = 0;
     unsigned okmask[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         const int b = mt / a.tpb, t = mt - b * a.tpb, q = t * 16 + fr;
-        const bool valid = b < a.bpw && board0 + b < a.boards && q < a.hw;
-        const int yy = q / a.w_, xx = q - yy * a.w_;
-        rowmask |= (unsigned)valid << mt;
+        const unsigned valid = b < a.bpw && board0 + b < a.boards && q < a.hw;
+        const int yy = (int)(((unsigned)q * a.inv_w) >> 16), xx = q - yy * a.w_;
+        const unsigned ym[3] = {(unsigned)(yy >= 1), 1u, (unsigned)(yy <= a.h - 2)};
+        const unsigned xm[3] = {(unsigned)(xx >= 1), 1u, (unsigned)(xx <= a.w_ - 2)};
+        rowmask |= valid << mt;
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int y2 = yy + tap / 3 - 1, x2 = xx + tap % 3 - 1;
-            okmask[tap] |= (unsigned)(valid && (unsigned)y2 < (unsigned)a.h && (unsigned)x2 < (unsigned)a.w_) << mt;
-        }
+        for (int tap = 0; tap < 9; tap++) okmask[tap] |= (valid & ym[tap / 3] & xm[tap % 3]) << mt;
     }
 
     f32x4 acc[2][MT];
@@ -214,45 +215,69 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
     }
 
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
+    // Staged through LDS (the image is dead now) so that HBM sees whole 256-byte rows (this workgroup's 128 output
+    // channels of a pixel) instead of 8-byte pieces: O[row][128 oc] f16, row stride 272 B.
+    constexpr int ORS = 128 * 2 + 16;
+    static_assert(ROWS * ORS <= LDS_BYTES, "output tile fits the image buffer");
+    auto row_pixel = [&](int row, bool &ok) {  // global pixel row of tile row `row`
+        const int mt = row >> 4, b = mt / a.tpb, q = (mt - b * a.tpb) * 16 + (row & 15);
+        ok = b < a.bpw && board0 + b < a.boards && q < a.hw;
+        return ok ? (size_t)(board0 + b) * a.hw + q : (size_t)0;
+    };
+    __syncthreads();  // every wave is done with the last chunk's fragments
+    if (a.res) {      // residual tile, coalesced: 24 sixteen-byte pieces per thread in two batches
+#pragma unroll 1
+        for (int part = 0; part < 2; part++) {
+            uint4 v[12];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-        const int oc = nhalf * 128 + wave * 32 + nt * 16 + kq * 4;
-        f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.post_scale) {
-            ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-            pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-        }
+            for (int i = 0; i < 12; i++) {
+                const int id = tid + (part * 12 + i) * 256;
+                bool ok;
+                const size_t gr = row_pixel(id >> 4, ok);
+                v[i] = *reinterpret_cast<const uint4 *>(a.res + gr * a.ldy + nhalf * 128 + (id & 15) * 8);
+            }
 #pragma unroll
-      for (int part = 0; part < 2; part++) {
-        h16x4 rv[MT / 2];
-        if (a.res) {
-#pragma unroll
-            for (int i = 0; i < MT / 2; i++) {
-                const int mt = part * (MT / 2) + i;
-                const int b = mt / a.tpb, q = (mt - b * a.tpb) * 16 + fr;
-                const size_t src_row = ((rowmask >> mt) & 1) ? (size_t)(board0 + b) * a.hw + q : 0;  // clamped, see staging
-                rv[i] = *reinterpret_cast<const h16x4 *>(a.res + src_row * a.ldy + oc);
+            for (int i = 0; i < 12; i++) {
+                const int id = tid + (part * 12 + i) * 256;
+                *reinterpret_cast<uint4 *>(lds + (id >> 4) * ORS + (id & 15) * 16) = v[i];
             }
         }
+        __syncthreads();
+    }
 #pragma unroll
-        for (int i = 0; i < MT / 2; i++) {
-            const int mt = part * (MT / 2) + i;
-            if (!((rowmask >> mt) & 1)) continue;
-            const int b = mt / a.tpb, q = (mt - b * a.tpb) * 16 + fr;
-            const size_t off = ((size_t)(board0 + b) * a.hw + q) * a.ldy + oc;
+    for (int nt = 0; nt < 2; nt++) {
+        const int ocl = wave * 32 + nt * 16 + kq * 4;  // within this workgroup's 128 channels
+        f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.post_scale) {
+            ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nhalf * 128 + ocl);
+            pt = *reinterpret_cast<const f32x4 *>(a.post_shift + nhalf * 128 + ocl);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            unsigned char *slot = lds + (mt * 16 + fr) * ORS + ocl * 2;  // owned by exactly this lane
             f32x4 v = acc[nt][mt];
             if (a.relu) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
             }
             if (a.res) {
+                const h16x4 r = *reinterpret_cast<const h16x4 *>(slot);
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] += (float)rv[i][j];
+                for (int j = 0; j < 4; j++) v[j] += (float)r[j];  // added in f32, AFTER the ReLU (post_act.py:227-228)
             }
             if (a.post_scale) v = v * ps + pt;
-            *reinterpret_cast<h16x4 *>(a.y + off) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+            *reinterpret_cast<h16x4 *>(slot) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
         }
-      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 24; i++) {
+        const int id = tid + i * 256;
+        bool ok;
+        const size_t gr = row_pixel(id >> 4, ok);
+        if (ok)
+            *reinterpret_cast<uint4 *>(a.y + gr * a.ldy + nhalf * 128 + (id & 15) * 8) =
+                *reinterpret_cast<const uint4 *>(lds + (id >> 4) * ORS + (id & 15) * 16);
     }
 }
 
@@ -260,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
 
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout) {
     const int hw = h * w, tpb = (hw + 15) / 16;
-    return dtype == 1 && cin % 128 == 0 && cout % 128 == 0 && tpb <= MT && w <= 255 && h <= 255;
+    return dtype == 1 && cin % 128 == 0 && cout % 128 == 0 && tpb <= MT && w <= 32 && h <= 32;
 }
 
 size_t board_conv_weight_elems(int cin, int cout) { return (size_t)9 * cin * cout; }
@@ -307,6 +332,7 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.bpw = MT / d.tpb;
     d.cin = t.cin;
     d.relu = t.relu;
+    d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
