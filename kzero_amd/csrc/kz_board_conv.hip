@@ -1,18 +1,25 @@
 // kz_board_conv.hip — per-layer 3x3 convolution for boards whose whole tower does not fit in LDS (Go 19x19: a
-// 361 x 256 f16 board is 185 KB), f16, channels a multiple of 128.
+// 361 x 256 f16 board is 185 KB), f16, channels a multiple of 64.
 //
 // Same inner loop as the resident tower (kz_tower.hip): a workgroup keeps whole boards' pixels in LDS and the 9 taps
 // are 9 shifted views of that image (a tap outside the board reads a zero row), so the activations are fetched from
-// L2/HBM ONCE per layer instead of once per tap; the weights stream from L2 straight into MFMA A-fragment registers in
-// host-packed fragment order.  What differs from the tower: one launch per layer (activations round-trip through HBM:
-// 2 x 94.6 MB per layer at Go B=512 — 0.4 TB/s at the kernel's MFMA-bound pace), the board is staged in two
-// 128-channel chunks (a 384-row x 128-channel image is 110 KB), and a workgroup owns 128 of the output channels.
+// L2 ONCE per layer and workgroup instead of once per tap; the weights stream from L2 straight into MFMA A-fragment
+// registers in host-packed fragment order.  What differs from the tower: one launch per layer (activations round-trip
+// through HBM: 2-3 x 94.6 MB per layer at Go B=512, the same order of time as the MFMAs), so the kernel is shaped
+// for TWO workgroups per CU — one stages or stores while the other multiplies:
 //
-//   grid  = (ceil(boards / bpw), C / 128);  256 threads = 4 waves, wave w owns output channels [32w, 32w + 32)
-//   rows  = 24 tiles of 16 pixel rows: bpw boards, each padded to tpb = ceil(h*w / 16) tiles (Go: 23 tiles, bpw = 1)
-//   LDS   = two planes (channels [0,64) and [64,128) of the chunk) of 384 rows x 144 B: the two lane groups that share
-//           a ds_read_b128 bank group read the two planes at the same row offset, the planes are a multiple of 256 B
-//           apart and rows advance by 9 sixteen-byte slots -> conflict-free fragment reads for every tap.
+//   workgroup = 24 tiles of 16 pixel rows (bpw boards, each padded to tpb = ceil(h*w/16) tiles; Go: 23 tiles, bpw = 1)
+//               x 64 output channels; 256 threads = 4 waves; wave = (row half: 12 tiles) x (32 output channels)
+//   LDS       = one 64-channel chunk of the image: two planes (channels [0,32) and [32,64)) of 400 rows x 80 B = 64 KB.
+//               The two lane groups that share a ds_read_b128 bank group read the two planes at the same row offset, the
+//               planes are a multiple of 256 B apart and rows advance by 5 sixteen-byte slots -> conflict-free
+//               fragment reads for every tap.
+//   registers = 96 accumulators + 48 fragment + 24..48 weight ring: < 256, two waves per SIMD.
+//   grid      = 1-D, XCD-aware: the cout/64 workgroups of one board group run on ONE XCD back to back, so the
+//               image is read from HBM once and from that XCD's L2 by the others.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 #include "kz_kernels.hpp"
@@ -23,49 +30,80 @@ typedef _Float16 h16;
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef h16 h16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int MT = 24;                 // 16-row tiles per workgroup
+constexpr int MTW = MT / 2;            // tiles per wave (row half)
 constexpr int ROWS = MT * 16;          // 384
-constexpr int PRS = 64 * 2 + 16;       // plane row stride: 64 channels + 16 B pad = 144 B
-constexpr int PLANE = (ROWS + 16) * PRS;  // 400 rows (384 + 16 zero rows) = 57,600 B = 225 * 256
+constexpr int OCW = 64;                // output channels per workgroup
+constexpr int CH = 64;                 // input channels per staged chunk
+constexpr int PRS = 32 * 2 + 16;       // plane row stride: 32 channels + 16 B pad = 80 B
+constexpr int PLANE = (ROWS + 16) * PRS;  // 400 rows (384 + 16 zero rows) = 32,000 B = 125 * 256
 constexpr int ZROW = ROWS;             // first zero row
-constexpr int LDS_BYTES = 2 * PLANE;   // 115,200 B
-constexpr int PF = 4;                  // weight ring depth in k-steps (a k-step is 48 MFMAs = 768 cycles)
+constexpr int LDS_BYTES = 2 * PLANE;   // 64,000 B: two workgroups per CU
+constexpr int KPC = 18;                // k-steps (32 channels of one tap) per chunk: 9 taps x 2
+constexpr int PF = 3;                  // weight ring depth in k-steps (a k-step is 24 MFMAs = 384 cycles per wave)
 static_assert(PLANE % 256 == 0, "planes must be a whole number of bank rows apart");
+static_assert(KPC % PF == 0, "ring stage of a k-step must not depend on the chunk");
 
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
+// Diagnostic build only (-DKZ_BC_STAMPS): s_memtime stamps at the phase boundaries of every wave, dumped by the
+// launcher to $KZ_BC_STAMP_FILE after the 20th launch.  No stamp executes in the real kernel.
+#ifdef KZ_BC_STAMPS
+#define KZ_STAMP(slot)                                                                         \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (slot)] = t_;           \
+    } while (0)
+#else
+#define KZ_STAMP(slot) do { } while (0)
+#endif
+
 struct BoardConvDev {
-    const h16 *x;       // [boards*hw][ldx]
-    const uint4 *w;     // fragment-packed: [n_half][k-step][wave 4][nt 2][lane 64] x 16 B
+    const h16 *x;       // [boards*hw][ld]
+    const uint4 *w;     // fragment-packed: [n_quarter][k-step][oc half 2][nt 2][lane 64] x 16 B
     const float *bias, *post_scale, *post_shift;  // [cout]
-    const h16 *res;     // optional residual [boards*hw][ldy]
-    h16 *y;             // [boards*hw][ldy]
-    int ldx, ldy, boards, h, w_, hw, tpb, bpw, cin, relu;
-    unsigned inv_w;  // ceil(65536 / w): q / w == (q * inv_w) >> 16 for q < 512, w <= 32
+    const h16 *res;     // optional residual [boards*hw][ld]
+    h16 *y;             // [boards*hw][ld]
+    int bytes;          // size of each of those tensors: boards * hw * ld * 2 (< 2^31)
+    int ld, boards, h, w_, hw, tpb, bpw, cin, relu, groups, nq;
+    unsigned inv_w;    // ceil(65536 / w): q / w == (q * inv_w) >> 16 for q < 512, w <= 32
+    unsigned long long *stamps;  // diagnostic build only
+    int ablate;        // timing experiments only (KZ_BC_ABLATE): 1 no staging loads, 2 no residual/output traffic, 4 no MFMA
+    unsigned inv_tpb;  // ceil(65536 / tpb): mt / tpb == (mt * inv_tpb) >> 16 for mt < 24
 };
 
-__global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
+__global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave & 1, wr = wave >> 1;  // output-channel half, row half
     const int lane = tid & 63;
     const int fr = lane & 15, kq = lane >> 4;
-    const int board0 = blockIdx.x * a.bpw;
-    const int nhalf = blockIdx.y;
-    const int chunks = a.cin / 128;
-    const int total_ksteps = chunks * 36;  // 9 taps x 4 k-steps of 32 channels per chunk
+    // XCD-aware order: consecutive workgroup ids go to consecutive XCDs, so id = (slot, xcd); the nq channel quarters of
+    // a board group take consecutive slots of one XCD
+    KZ_STAMP(0);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nquarter = slot % a.nq, group = (slot / a.nq) * 8 + xcd;
+    if (group >= a.groups) return;
+    const int board0 = group * a.bpw;
+    const int chunks = a.cin / CH;
+    const int total_ksteps = chunks * KPC;
 
-    // weight ring: k-step g of this (layer, n-half): 8 KB = [wave][nt 2][lane] x 16 B
-    const uint4 *wp = a.w + (size_t)nhalf * total_ksteps * 512 + wave * 128 + lane;
+    // weight ring: k-step g of this (layer, quarter): 4 KB = [oc half][nt 2][lane] x 16 B
+    const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + wo * 128 + lane;
     uint4 wreg[PF][2];
 #pragma unroll
     for (int s = 0; s < PF; s++) {
         const int g = s < total_ksteps ? s : total_ksteps - 1;
-        wreg[s][0] = wp[(size_t)g * 512];
-        wreg[s][1] = wp[(size_t)g * 512 + 64];
+        wreg[s][0] = wp[(size_t)g * 256];
+        wreg[s][1] = wp[(size_t)g * 256 + 64];
     }
     int g = 0;
 
@@ -75,107 +113,116 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
         *reinterpret_cast<uint4 *>(lds + plane * PLANE + ZROW * PRS + off * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // Validity of (tile row, tap) as bitmasks: bit mt of okmask[tap] says that, for this lane's row of tile mt, the tap
-    // lands on the board; bit mt of rowmask says the row is a real pixel of a board of this batch.  Computed once,
-    // so a tap costs 3 VALU per tile in the k-loop instead of a dozen.
-    unsigned rowmask = 0;
+    // The 12 (pixel row, 16-byte piece) slots this thread copies, for staging and for the epilogue alike: slot i is tile
+    // row (tid >> 3) + 32 i, piece tid & 7.  po[i] = byte offset of that slot in a [pixels][ld] activation tensor
+    // (x, y and the residual share ld), or -1 for a padding row; 32-bit offsets on a uniform base keep the twelve
+    // addresses in twelve registers.
+    const int piece = tid & 7;
+    int po[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int row = (tid >> 3) + i * 32;
+        const int mt = row >> 4, b = (int)(((unsigned)mt * a.inv_tpb) >> 16), q = (mt - b * a.tpb) * 16 + (row & 15);
+        po[i] = (b < a.bpw && board0 + b < a.boards && q < a.hw) ? (((board0 + b) * a.hw + q) * a.ld + piece * 8) * 2 : -1;
+    }
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.x), 0, a.bytes, 0x00020000);
+    const int stage_lds = (piece >> 2) * PLANE + (tid >> 3) * PRS + (piece & 3) * 16;  // + i * 32 * PRS
+
+    // Validity of (tile row, tap) as bitmasks over this wave's 12 tiles: bit i of okmask[tap] says that, for this lane's
+    // row of tile 12*wr + i, the tap lands on the board.  Computed once, so a tap costs 3 VALU per tile in the k-loop.
     unsigned okmask[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int b = mt / a.tpb, t = mt - b * a.tpb, q = t * 16 + fr;
+    for (int i = 0; i < MTW; i++) {
+        const int mt = wr * MTW + i;
+        const int b = (int)(((unsigned)mt * a.inv_tpb) >> 16), t = mt - b * a.tpb, q = t * 16 + fr;
         const unsigned valid = b < a.bpw && board0 + b < a.boards && q < a.hw;
         const int yy = (int)(((unsigned)q * a.inv_w) >> 16), xx = q - yy * a.w_;
         const unsigned ym[3] = {(unsigned)(yy >= 1), 1u, (unsigned)(yy <= a.h - 2)};
         const unsigned xm[3] = {(unsigned)(xx >= 1), 1u, (unsigned)(xx <= a.w_ - 2)};
-        rowmask |= valid << mt;
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) okmask[tap] |= (valid & ym[tap / 3] & xm[tap % 3]) << mt;
+        for (int tap = 0; tap < 9; tap++) okmask[tap] |= (valid & ym[tap / 3] & xm[tap % 3]) << i;
     }
 
-    f32x4 acc[2][MT];
+    f32x4 acc[2][MTW];
     {
-        const int oc = nhalf * 128 + wave * 32 + kq * 4;
+        const int oc = nquarter * OCW + wo * 32 + kq * 4;
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + oc + nt * 16);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[nt][mt] = b;
+            for (int i = 0; i < MTW; i++) acc[nt][i] = b;
         }
     }
 
-    // fragment address pieces that do not depend on the tap: plane (kq & 1), 16-byte piece (kq >> 1) of the k-step
-    const int lane_off = (kq & 1) * PLANE + (kq >> 1) * 16;
+    // fragment address pieces that do not depend on the tap: plane (kq & 1), 16-byte piece (kq >> 1) of the k-step,
+    // first row of this wave's row half
+    const int lane_off = (kq & 1) * PLANE + (kq >> 1) * 16 + wr * MTW * 16 * PRS;
 
     // LDS address of this lane's fragment row per tile for one tap (pixel shifted by the tap, or a zero row)
-    auto tap_rows = [&](int tap, int lo, int hi, int (&T)[MT]) {
+    // (frow is fr behind an optimisation barrier inside the chunk loop: the rows are the same for every chunk, and the
+    // compiler would otherwise hoist all 9 x 12 of them out of the loop and spill them)
+    auto tap_rows = [&](int tap, int lo, int hi, int frow, int (&T)[MTW]) {
         const int shift = (tap / 3 - 1) * a.w_ + (tap % 3 - 1);
-        const unsigned ok = tap == 0   ? okmask[0] : tap == 1 ? okmask[1] : tap == 2 ? okmask[2] : tap == 3 ? okmask[3]
-                            : tap == 4 ? okmask[4] : tap == 5 ? okmask[5] : tap == 6 ? okmask[6] : tap == 7 ? okmask[7]
-                                                                                                           : okmask[8];
-        const int shifted = (fr + shift) * PRS + lane_off;                       // + mt * 16 * PRS per tile
-        const int zero = (ZROW + ((fr + shift) & 15)) * PRS + lane_off;          // same 16-byte slot pattern
+        unsigned ok = okmask[tap];
+        asm volatile("" : "+v"(ok));  // same reason: 108 hoisted lane masks would not fit the SGPR file
+        const int shifted = (frow + shift) * PRS + lane_off;                                    // + i * 16 * PRS per tile
+        const int zero = (ZROW + ((frow + shift) & 15)) * PRS + (kq & 1) * PLANE + (kq >> 1) * 16;  // same slot pattern
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            if (mt < lo || mt >= hi) continue;
-            T[mt] = ((ok >> mt) & 1) ? shifted + mt * 16 * PRS : zero;
+        for (int i = 0; i < MTW; i++) {
+            if (i < lo || i >= hi) continue;
+            T[i] = ((ok >> i) & 1) ? shifted + i * 16 * PRS : zero;
         }
     };
 
+    KZ_STAMP(1);
     for (int chunk = 0; chunk < chunks; chunk++) {
-        // ---- stage channels [128*chunk, +128) of this workgroup's boards: 16 pieces of 16 B per pixel row ----
+        // ---- stage channels [64*chunk, +64) of this workgroup's boards: 8 pieces of 16 B per pixel row ----
         __syncthreads();  // everyone is done reading the previous chunk
-        // 24 pieces per thread, in two batches of 12 loads in flight (a load-wait-store per piece would serialise
-        // 24 HBM/L2 round trips; the fragment registers are dead here, so the batch is free)
-#pragma unroll 1
-        for (int part = 0; part < 2; part++) {
-            uint4 v[12];
+        KZ_STAMP(2 + chunk * 4);
+        {
+            // 12 pieces per thread, all in flight at once (the fragment registers are dead here); a padding row's offset
+            // is out of the descriptor's range and reads as zeros
+            u32x4 v[12];
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const int id = tid + (part * 12 + i) * 256;
-                const int row = id >> 4, piece = id & 15;
-                const int mt = row >> 4, b = mt / a.tpb, q = (mt - b * a.tpb) * 16 + (row & 15);
-                // unconditional load from a clamped address + select: a branch around the load would make the compiler
-                // wait for vmcnt(0) per element
-                const bool ok = b < a.bpw && board0 + b < a.boards && q < a.hw;
-                const size_t src_row = ok ? (size_t)(board0 + b) * a.hw + q : 0;
-                const uint4 ld = *reinterpret_cast<const uint4 *>(a.x + src_row * a.ldx + chunk * 128 + piece * 8);
-                v[i] = ok ? ld : make_uint4(0, 0, 0, 0);
-            }
+            for (int i = 0; i < 12; i++)
+                v[i] = (a.ablate & 1) ? u32x4{0, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], chunk * CH * 2, 0);
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const int id = tid + (part * 12 + i) * 256;
-                const int row = id >> 4, piece = id & 15;
-                *reinterpret_cast<uint4 *>(lds + (piece >> 3) * PLANE + row * PRS + (piece & 7) * 16) = v[i];
-            }
+            for (int i = 0; i < 12; i++) *reinterpret_cast<u32x4 *>(lds + stage_lds + i * 32 * PRS) = v[i];
         }
+        KZ_STAMP(3 + chunk * 4);
         __syncthreads();
+        KZ_STAMP(4 + chunk * 4);
 
-        // Two half-steps per k-step: the MFMAs of tiles 0..11 run while the fragments of tiles 12..23 are read, and
-        // vice versa (the fragments of the NEXT k-step's first half), so every LDS read has ~400 cycles of cover.
-        int T[MT];
-        h16x8 bfA[MT / 2], bfB[MT / 2];
-        tap_rows(0, 0, MT, T);
+        // Two half-steps per k-step: the MFMAs of tiles 0..5 run while the fragments of tiles 6..11 are read, and
+        // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (same workgroup or
+        // the CU's second workgroup) fills whatever latency is left.
+        int T[MTW];
+        h16x8 bfA[MTW / 2], bfB[MTW / 2];
+        int frow = fr;
+        asm volatile("" : "+v"(frow));
+        tap_rows(0, 0, MTW, frow, T);
 #pragma unroll
-        for (int i = 0; i < MT / 2; i++) bfA[i] = *reinterpret_cast<const h16x8 *>(lds + T[i]);
+        for (int i = 0; i < MTW / 2; i++) bfA[i] = *reinterpret_cast<const h16x8 *>(lds + T[i]);
+#pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int next_tap = tap < 8 ? tap + 1 : 8;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const int stage = ks & (PF - 1);  // 36 k-steps per chunk, 4 per tap: g % 4 == ks
+            for (int ks = 0; ks < 2; ks++) {
+                const int stage = (tap * 2 + ks) % PF;
                 // ---- half 1 ----
 #pragma unroll
-                for (int i = 0; i < MT / 2; i++)
-                    bfB[i] = *reinterpret_cast<const h16x8 *>(lds + T[MT / 2 + i] + ks * 32);
+                for (int i = 0; i < MTW / 2; i++)
+                    bfB[i] = *reinterpret_cast<const h16x8 *>(lds + T[MTW / 2 + i] + ks * 32);
                 h16x8 af[2];
                 af[0] = *reinterpret_cast<const h16x8 *>(&wreg[stage][0]);
                 af[1] = *reinterpret_cast<const h16x8 *>(&wreg[stage][1]);
                 {
                     const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
-                    wreg[stage][0] = wp[(size_t)gn * 512];
-                    wreg[stage][1] = wp[(size_t)gn * 512 + 64];
+                    wreg[stage][0] = wp[(size_t)gn * 256];
+                    wreg[stage][1] = wp[(size_t)gn * 256 + 64];
                 }
 #pragma unroll
-                for (int i = 0; i < MT / 2; i++) {
+                for (int i = 0; i < MTW / 2; i++) {
                     acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfA[i], acc[0][i], 0, 0, 0);
                     acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bfA[i], acc[1][i], 0, 0, 0);
                 }
@@ -184,27 +231,27 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
 #pragma unroll
-                for (int i = 0; i < MT / 2 - 2; i++) {
+                for (int i = 0; i < MTW / 2 - 2; i++) {
                     __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 2, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- half 2 ----
-                // T is updated in place for the next tap: rows 0..11 are dead after the last half-2 read of this tap,
-                // rows 12..23 after the half-1 read above
-                if (ks == 3) tap_rows(next_tap, 0, MT / 2, T);
+                // T is updated in place for the next tap: rows 0..5 are dead after the last half-2 read of this tap,
+                // rows 6..11 after the half-1 read above
+                if (ks == 1) tap_rows(next_tap, 0, MTW / 2, frow, T);
 #pragma unroll
-                for (int i = 0; i < MT / 2; i++)
-                    bfA[i] = *reinterpret_cast<const h16x8 *>(lds + T[i] + (ks < 3 ? (ks + 1) * 32 : 0));
-                if (ks == 3) tap_rows(next_tap, MT / 2, MT, T);
+                for (int i = 0; i < MTW / 2; i++)
+                    bfA[i] = *reinterpret_cast<const h16x8 *>(lds + T[i] + (ks < 1 ? (ks + 1) * 32 : 0));
+                if (ks == 1) tap_rows(next_tap, MTW / 2, MTW, frow, T);
 #pragma unroll
-                for (int i = 0; i < MT / 2; i++) {
-                    acc[0][MT / 2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfB[i], acc[0][MT / 2 + i], 0, 0, 0);
-                    acc[1][MT / 2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bfB[i], acc[1][MT / 2 + i], 0, 0, 0);
+                for (int i = 0; i < MTW / 2; i++) {
+                    acc[0][MTW / 2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfB[i], acc[0][MTW / 2 + i], 0, 0, 0);
+                    acc[1][MTW / 2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bfB[i], acc[1][MTW / 2 + i], 0, 0, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < MT / 2; i++) {
+                for (int i = 0; i < MTW / 2; i++) {
                     __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
                 }
@@ -212,55 +259,43 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
                 g++;
             }
         }
+        KZ_STAMP(5 + chunk * 4);
     }
 
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
-    // Staged through LDS (the image is dead now) so that HBM sees whole 256-byte rows (this workgroup's 128 output
-    // channels of a pixel) instead of 8-byte pieces: O[row][128 oc] f16, row stride 272 B.
-    constexpr int ORS = 128 * 2 + 16;
+    // Staged through LDS (the image is dead now) so that HBM sees whole 128-byte lines (this workgroup's 64 output
+    // channels of a pixel) instead of 8-byte pieces: O[row][64 oc] f16, row stride 144 B.
+    constexpr int ORS = OCW * 2 + 16;
     static_assert(ROWS * ORS <= LDS_BYTES, "output tile fits the image buffer");
-    auto row_pixel = [&](int row, bool &ok) {  // global pixel row of tile row `row`
-        const int mt = row >> 4, b = mt / a.tpb, q = (mt - b * a.tpb) * 16 + (row & 15);
-        ok = b < a.bpw && board0 + b < a.boards && q < a.hw;
-        return ok ? (size_t)(board0 + b) * a.hw + q : (size_t)0;
-    };
     __syncthreads();  // every wave is done with the last chunk's fragments
-    if (a.res) {      // residual tile, coalesced: 24 sixteen-byte pieces per thread in two batches
-#pragma unroll 1
-        for (int part = 0; part < 2; part++) {
-            uint4 v[12];
+    KZ_STAMP(18);
+    const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
+    if (a.res && !(a.ablate & 2)) {      // residual tile, coalesced: 12 sixteen-byte pieces per thread
+        const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.res), 0, a.bytes, 0x00020000);
+        u32x4 v[12];
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const int id = tid + (part * 12 + i) * 256;
-                bool ok;
-                const size_t gr = row_pixel(id >> 4, ok);
-                v[i] = *reinterpret_cast<const uint4 *>(a.res + gr * a.ldy + nhalf * 128 + (id & 15) * 8);
-            }
+        for (int i = 0; i < 12; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, po[i], nquarter * OCW * 2, 0);
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const int id = tid + (part * 12 + i) * 256;
-                *reinterpret_cast<uint4 *>(lds + (id >> 4) * ORS + (id & 15) * 16) = v[i];
-            }
-        }
+        for (int i = 0; i < 12; i++) *reinterpret_cast<u32x4 *>(lds + out_lds + i * 32 * ORS) = v[i];
         __syncthreads();
     }
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
-        const int ocl = wave * 32 + nt * 16 + kq * 4;  // within this workgroup's 128 channels
+        const int ocl = wo * 32 + nt * 16 + kq * 4;  // within this workgroup's 64 channels
         f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.post_scale) {
-            ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nhalf * 128 + ocl);
-            pt = *reinterpret_cast<const f32x4 *>(a.post_shift + nhalf * 128 + ocl);
+            ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nquarter * OCW + ocl);
+            pt = *reinterpret_cast<const f32x4 *>(a.post_shift + nquarter * OCW + ocl);
         }
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            unsigned char *slot = lds + (mt * 16 + fr) * ORS + ocl * 2;  // owned by exactly this lane
-            f32x4 v = acc[nt][mt];
+        for (int i = 0; i < MTW; i++) {
+            unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + ocl * 2;  // owned by exactly this lane
+            f32x4 v = acc[nt][i];
             if (a.relu) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
             }
-            if (a.res) {
+            if (a.res && !(a.ablate & 2)) {
                 const h16x4 r = *reinterpret_cast<const h16x4 *>(slot);
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] += (float)r[j];  // added in f32, AFTER the ReLU (post_act.py:227-228)
@@ -270,42 +305,46 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv_f16(BoardConvDev a) {
         }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int i = 0; i < 24; i++) {
-        const int id = tid + i * 256;
-        bool ok;
-        const size_t gr = row_pixel(id >> 4, ok);
-        if (ok)
-            *reinterpret_cast<uint4 *>(a.y + gr * a.ldy + nhalf * 128 + (id & 15) * 8) =
-                *reinterpret_cast<const uint4 *>(lds + (id >> 4) * ORS + (id & 15) * 16);
-    }
+    KZ_STAMP(19);
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
+    if (!(a.ablate & 2))
+#pragma unroll
+    for (int i = 0; i < 12; i++)  // a padding row's store is out of range and dropped
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
+                                               nquarter * OCW * 2, 0);
+    KZ_STAMP(20);
 }
 
 }  // namespace
 
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout) {
     const int hw = h * w, tpb = (hw + 15) / 16;
-    return dtype == 1 && cin % 128 == 0 && cout % 128 == 0 && tpb <= MT && w <= 32 && h <= 32;
+    return dtype == 1 && cin % CH == 0 && cout % OCW == 0 && tpb <= MT && w <= 32 && h <= 32;
+}
+
+int board_conv_workgroups(int boards, int h, int w, int cout) {
+    const int tpb = (h * w + 15) / 16, bpw = tpb <= MT ? MT / tpb : 1;
+    return ((boards + bpw - 1) / bpw) * (cout / OCW);
 }
 
 size_t board_conv_weight_elems(int cin, int cout) { return (size_t)9 * cin * cout; }
 
-// OIHW f32 (BN folded) -> [n_half][chunk][tap][ks 4][wave 4][nt 2][lane 64][8] f16: element j of lane (fr, kq) is
-// W[oc = 128*n_half + 32*wave + 16*nt + fr][channel = 128*chunk + 64*(kq&1) + 16*ks + 8*(kq>>1) + j][tap]
+// OIHW f32 (BN folded) -> [n_quarter][chunk][tap][ks 2][oc half 2][nt 2][lane 64][8] f16: element j of lane (fr, kq) is
+// W[oc = 64*n_quarter + 32*half + 16*nt + fr][channel = 64*chunk + 32*(kq&1) + 16*ks + 8*(kq>>1) + j][tap]
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst) {
-    const int chunks = cin / 128, halves = cout / 128;
+    const int chunks = cin / CH, quarters = cout / OCW;
     size_t o = 0;
-    for (int nh = 0; nh < halves; nh++)
+    for (int nq = 0; nq < quarters; nq++)
         for (int chunk = 0; chunk < chunks; chunk++)
             for (int tap = 0; tap < 9; tap++)
-                for (int ks = 0; ks < 4; ks++)
-                    for (int wave = 0; wave < 4; wave++)
+                for (int ks = 0; ks < 2; ks++)
+                    for (int half = 0; half < 2; half++)
                         for (int nt = 0; nt < 2; nt++)
                             for (int lane = 0; lane < 64; lane++)
                                 for (int j = 0; j < 8; j++) {
                                     const int kq = lane >> 4;
-                                    const int oc = 128 * nh + 32 * wave + 16 * nt + (lane & 15);
-                                    const int ch = 128 * chunk + 64 * (kq & 1) + 16 * ks + 8 * (kq >> 1) + j;
+                                    const int oc = OCW * nq + 32 * half + 16 * nt + (lane & 15);
+                                    const int ch = CH * chunk + 32 * (kq & 1) + 16 * ks + 8 * (kq >> 1) + j;
                                     const _Float16 hv = (_Float16)oihw[((size_t)oc * cin + ch) * 9 + tap];
                                     uint16_t bits;
                                     __builtin_memcpy(&bits, &hv, 2);
@@ -322,8 +361,8 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.post_shift = t.post_shift;
     d.res = static_cast<const h16 *>(t.res);
     d.y = static_cast<h16 *>(t.y);
-    d.ldx = t.ldx;
-    d.ldy = t.ldy;
+    d.bytes = (int)((size_t)t.boards * t.h * t.w * t.ldx * 2);
+    d.ld = t.ldx;  // == t.ldy (board_conv_supported callers pass tower activations of one width)
     d.boards = t.boards;
     d.h = t.h;
     d.w_ = t.w;
@@ -333,6 +372,11 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.cin = t.cin;
     d.relu = t.relu;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
+    d.inv_tpb = (65536u + (unsigned)d.tpb - 1) / (unsigned)d.tpb;
+    static const int ablate = getenv("KZ_BC_ABLATE") ? atoi(getenv("KZ_BC_ABLATE")) : 0;
+    d.ablate = ablate;
+    d.groups = (t.boards + d.bpw - 1) / d.bpw;
+    d.nq = t.cout / OCW;
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -340,8 +384,29 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         done_mask |= 1ull << (dev & 63);
     }
-    dim3 grid((t.boards + d.bpw - 1) / d.bpw, t.cout / 128);
+    const int grid = ((d.groups + 7) / 8) * 8 * d.nq;
+#ifdef KZ_BC_STAMPS
+    static unsigned long long *stamp_buf = nullptr;
+    static int launches = 0;
+    const size_t stamp_bytes = (size_t)grid * 4 * 32 * sizeof(unsigned long long);
+    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, (size_t)8192 * 4 * 32 * 8);
+    d.stamps = stamp_buf;
+    if (launches == 20) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, stream);
+#else
+    d.stamps = nullptr;
+#endif
     kz_board_conv_f16<<<grid, 256, LDS_BYTES, stream>>>(d);
+#ifdef KZ_BC_STAMPS
+    if (launches++ == 20 && getenv("KZ_BC_STAMP_FILE")) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> host(stamp_bytes / 8);
+        (void)hipMemcpy(host.data(), stamp_buf, stamp_bytes, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("KZ_BC_STAMP_FILE"), "wb")) {
+            fwrite(host.data(), 1, stamp_bytes, f);
+            fclose(f);
+        }
+    }
+#endif
 }
 
 }  // namespace kz

@@ -59,7 +59,7 @@ struct DevConv {  // packed for kz_conv_igemm: [k*k][cout_p][cin_p] in T, bias f
     void *w = nullptr;
     float *b = nullptr;
     int cin_p = 0, cout_p = 0, cout = 0, k = 1;
-    void *bw = nullptr;  // instead of w: packed for kz_board_conv_f16 (3x3, f16, channels % 128 == 0)
+    void *bw = nullptr;  // instead of w: packed for kz_board_conv_f16 (3x3, f16, channels % 64 == 0)
 };
 
 struct DeviceWeights {
@@ -683,11 +683,11 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                      kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,
                                                m.sh_fc0.out);
     const char *noboard = getenv("KZ_NO_BOARD_CONV");
-    // the board-tile kernel needs enough workgroups to fill the chip: 24 / ceil(hw/16) boards per workgroup
-    const int bc_tpb = (m.h * m.w + 15) / 16, bc_bpw = bc_tpb <= 24 ? 24 / bc_tpb : 1;
+    // the board-tile kernel needs enough workgroups to fill the chip (two per CU when it is busy)
     const bool board_conv = !e->resident && !(noboard && noboard[0] == '1') && m.depth >= 1 &&
                             kz::board_conv_supported(dtype, m.h, m.w, m.channels, m.channels) &&
-                            ((max_batch + bc_bpw - 1) / bc_bpw) * (m.channels / 128) >= 80;
+                            kz::board_conv_workgroups(max_batch, m.h, m.w, m.channels) >= 160 &&
+                            (size_t)max_batch * m.h * m.w * m.channels * 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
               : board_conv   ? "board_conv_f16"

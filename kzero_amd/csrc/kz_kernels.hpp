@@ -98,7 +98,7 @@ void launch_decode_output(const float *scalars, const float *logits, int batch, 
                           int *error_flag, hipStream_t stream);
 
 // ---- per-layer 3x3 convolution with the board as an LDS-resident spatial tile (kz_board_conv.hip): f16, cin and cout
-// multiples of 128, h*w <= 384.  Same epilogue contract as ConvArgs. ----
+// multiples of 64, h*w <= 384.  Same epilogue contract as ConvArgs. ----
 struct BoardConvArgs {
     const void *x;   // [boards*h*w][ldx] f16
     int ldx;
@@ -109,6 +109,7 @@ struct BoardConvArgs {
     int ldy, boards, h, w, cin, cout, relu;
 };
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout);
+int board_conv_workgroups(int boards, int h, int w, int cout);  // grid size: 64 output channels per workgroup
 size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
 void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);

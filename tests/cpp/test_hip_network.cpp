@@ -121,8 +121,10 @@ int main(int argc, char **argv) {
         graph_senders.push_back(gtx);
         executors.emplace_back([&, srv = server, rx = std::move(grx)]() mutable {
             batched_executor_loop<std::shared_ptr<const HipModel>, Net, PackedBoard, ZeroEvaluation>(
-                8, RunCondition::any(), std::move(rx), std::move(srv),
-                [&](std::shared_ptr<const HipModel> m) { return Net(mapper, std::move(m), 8, 0, KZ_DTYPE_F32); },
+                // 16 >= the 4 x 3 boards that can be outstanding: a job is never split over two batches (the loop
+                // evaluates one batch per message, so a split job's tail would wait for the next message)
+                16, RunCondition::any(), std::move(rx), std::move(srv),
+                [&](std::shared_ptr<const HipModel> m) { return Net(mapper, std::move(m), 16, 0, KZ_DTYPE_F32); },
                 [&](Net &net, const PackedBoard *x, size_t n) {
                     evals += (long)n;  // the `real` evals counter (server_alphazero.rs:113-115)
                     return net.evaluate_batch(x, n);

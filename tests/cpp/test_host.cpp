@@ -300,7 +300,7 @@ static void test_executor_loop() {
     CHECK((*early.recv() == std::vector<int>{107, 207}) && (*early2.recv() == std::vector<int>{307}));
     // many clients, order preserved per job, each job answered exactly once
     std::vector<std::thread> gens;
-    std::atomic<int> wrong{0};
+    std::atomic<int> wrong{0}, finished{0};
     for (int t = 0; t < 4; t++)
         gens.emplace_back([&, t, c = client] {
             for (int i = 0; i < 50; i++) {
@@ -311,7 +311,15 @@ static void test_executor_loop() {
                 for (size_t k = 0; k < y.size(); k++)
                     if (y[k] != x[k] * 100 + 7) wrong++;
             }
+            finished++;
         });
+    // The loop evaluates at most ONE batch per message (executor.rs:93-96), so the tail of a job that was split over
+    // two batches waits for the next message.  The server never splits (search_batch_size divides gpu_batch_size);
+    // these job sizes do, so a ticker keeps messages coming until the blocking clients are done.
+    while (finished < 4) {
+        CHECK((client.map_blocking({0}) == std::vector<int>{7}));
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
     for (auto &g : gens) g.join();
     CHECK(wrong == 0);
     for (size_t n : trace.batches) CHECK(n >= 1 && n <= 4);  // never above max_batch_size

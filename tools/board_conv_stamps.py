@@ -1,0 +1,20 @@
+import sys, numpy as np
+d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4, 32).astype(np.int64)
+ok = d[:, 0, 0] > 0
+d = d[ok]
+print("workgroups with stamps:", d.shape[0])
+t0 = d[:, :, 0].min()
+names = ["start", "prologue"]
+for c in range(4): names += [f"c{c}.bar1", f"c{c}.staged", f"c{c}.bar2", f"c{c}.kloop"]
+names += ["epi.bar", "epi.math", "epi.store"]
+prev = d[:, :, 0]
+print("kernel span (cycles):", (d[:, :, 20].max() - t0))
+life = d[:, :, 20] - d[:, :, 0]
+print("wave lifetime mean/min/max:", life.mean(), life.min(), life.max())
+tot = {}
+for i in range(1, 21):
+    seg = d[:, :, i] - d[:, :, i - 1]
+    print(f"{names[i]:12s} mean {seg.mean():9.0f}  p10 {np.percentile(seg,10):9.0f}  p90 {np.percentile(seg,90):9.0f}  share {seg.mean()/life.mean()*100:5.1f}%")
+# start times: how WGs are spread
+st = np.sort(d[:, 0, 0] - t0)
+print("start-time quantiles:", [int(np.percentile(st, q)) for q in (0, 25, 50, 75, 100)])
