@@ -156,6 +156,7 @@ def main():
     # dominant kernel, timed with HIP events on the engines' own streams over the timed region
     tower_path = engines[0].tower_path
     kname = {"tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
+             "tower_resident_f32": "kz_tower_resident_f32",
              "board_conv_f16": "kz_board_conv_f16", "conv_igemm_f16": "kz_conv_igemm_f16",
              "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
     k_ms, k_n = 0.0, 0
@@ -181,7 +182,7 @@ def main():
     tower_flops = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
     if tower_path == "tower_resident_f16+heads":
         flops_per_launch = info.flops_per_eval * B  # one launch = tower + heads for one batch
-    elif tower_path == "tower_resident_f16":
+    elif tower_path in ("tower_resident_f16", "tower_resident_f32"):
         flops_per_launch = tower_flops * B  # one launch = the whole tower for one batch
     elif tower_path == "board_conv_f16":
         # one launch per 3x3 tower convolution except the stem (which has too few input channels for this kernel)
@@ -197,7 +198,7 @@ def main():
     # `achieved`/`frac` follow the contract literally: algorithmic FLOP of ONE launch / its average duration.  A resident
     # launch covers ceil(batch / boards_per_workgroup) of the 256 CUs and `engines` launches run side by side, so the
     # chip-level figure is `chip_frac` (all engines' FLOP / wall time), not `frac`.
-    nb = int(os.environ.get("KZ_TOWER_NB", "2")) if tower_path.startswith("tower_resident") else None
+    nb = int(os.environ.get("KZ_TOWER_NB", "2")) if tower_path.startswith("tower_resident_f16") else None
     wgs = -(-B // (1 if nb == 1 else 2)) if nb else None
     # HBM-side bytes per launch of this kernel at this shape, from the separate rocprofv3 --pmc passes committed under
     # profiles/r1_pmc_final/ (FETCH_SIZE 188,179 KiB x2 per the gfx950 wide-read correction + WRITE_SIZE 1,888 KiB):

@@ -70,7 +70,8 @@ struct DeviceWeights {
     float *post_scale = nullptr, *post_shift = nullptr;
 
     // resident tower
-    bool resident = false, fused_heads = false;
+    bool resident = false, fused_heads = false, resident32 = false;
+    void *res32_w = nullptr;  // f32 resident launch: one packed weight stream
     void *res_w_stem = nullptr, *res_w_tower = nullptr;
     float *res_bias = nullptr;
     int32_t *att_idx = nullptr;
@@ -174,7 +175,8 @@ struct DeviceWeights {
     }
 
     bool use_board_conv = false;
-    int build(const Model &m, bool want_resident, bool want_fused) {
+    int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32) {
+        resident32 = want_resident32;
         const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
         HIP_TRY(hipSetDevice(device));
         resident = want_resident;
@@ -187,7 +189,18 @@ struct DeviceWeights {
         }
         if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
 
-        if (resident) {
+        if (resident32) {
+            std::vector<float> packed(kz::tower32_weight_elems(m.c_in, C, m.depth));
+            const size_t stem_elems = (size_t)9 * ((m.c_in + 15) / 16) * 16 * C, layer_elems = (size_t)9 * C * C;
+            kz::tower32_pack_weights(m.tower[0].w.data(), C, m.c_in, true, packed.data());
+            for (int l = 0; l < 2 * m.depth; l++)
+                kz::tower32_pack_weights(m.tower[1 + l].w.data(), C, C, false, packed.data() + stem_elems + layer_elems * l);
+            std::vector<float> bias((size_t)(1 + 2 * m.depth) * C);
+            for (int l = 0; l < 1 + 2 * m.depth; l++)
+                for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
+            if (upload(packed.data(), packed.size() * 4, &res32_w)) return 1;
+            if (upload_f32(bias, &res_bias)) return 1;
+        } else if (resident) {
             const int cin_p = round_up(m.c_in, 32);
             const size_t stem_elems = (size_t)9 * 256 * cin_p, layer_elems = (size_t)9 * 256 * 256;
             const size_t head_elems = fused_heads ? kz::tower_heads_weight_elems() : 0;
@@ -323,7 +336,7 @@ struct kz_engine {
         return 0;
     }
     std::vector<void *> allocs, pinned;
-    bool resident = false, fused_heads = false;
+    bool resident = false, fused_heads = false, resident32 = false;
     std::string path;
 
     // activations
@@ -435,6 +448,19 @@ struct kz_engine {
             t.scalars = d_scalars; t.policy = d_policy;
             prof.begin("kz_tower_resident_f16", stream);
             kz::launch_tower_resident(t, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            tower_out = 0;
+            return 0;
+        }
+        if (resident32) {
+            kz::Tower32Args t{};
+            t.x0 = (const float *)x_in; t.ldx0 = cin_p; t.c_in = m.c_in; t.weights = wts->res32_w; t.bias = wts->res_bias;
+            t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
+            t.y = (float *)act[0]; t.ldy = cp; t.batch = batch; t.h = m.h; t.w = m.w; t.channels = m.channels;
+            t.depth = m.depth;
+            prof.begin("kz_tower_resident_f32", stream);
+            kz::launch_tower32(t, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             tower_out = 0;
@@ -688,16 +714,20 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                             kz::board_conv_supported(dtype, m.h, m.w, m.channels, m.channels) &&
                             kz::board_conv_workgroups(max_batch, m.h, m.w, m.channels) >= 160 &&
                             (size_t)max_batch * m.h * m.w * m.channels * 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
-    e->path = e->fused_heads ? "tower_resident_f16+heads"
-              : e->resident  ? "tower_resident_f16"
-              : board_conv   ? "board_conv_f16"
-                             : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
     const char *keep = getenv("KZ_KEEP_ACTIVATIONS");
     e->keep = keep && keep[0] == '1' && !e->resident;
+    // exact-f32 resident launch (the per-layer activation taps of KZ_KEEP_ACTIVATIONS need the per-layer path)
+    e->resident32 = kz::tower32_supported(dtype, m.h, m.w, m.channels, m.depth) && m.c_in <= e->cin_p &&
+                    !(force && force[0] == '1') && !e->keep;
+    e->path = e->fused_heads ? "tower_resident_f16+heads"
+              : e->resident  ? "tower_resident_f16"
+              : e->resident32 ? "tower_resident_f32"
+              : board_conv   ? "board_conv_f16"
+                             : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident, e->fused_heads, board_conv);
+        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident || e->resident32, e->fused_heads, board_conv);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) e->wts = it->second.lock();
         if (!e->wts) {
@@ -705,7 +735,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->device = device;
             w->dtype = dtype;
             w->use_board_conv = board_conv;
-            if (w->build(m, e->resident, e->fused_heads)) return 1;
+            if (w->build(m, e->resident, e->fused_heads, e->resident32)) return 1;
             g_cache[key] = w;
             e->wts = w;
         }
@@ -717,7 +747,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         for (int i = 1; i < KZ_ENGINE_SLOTS; i++) HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[i], hipStreamNonBlocking));
     const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
     if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
-    const int nact = e->resident ? 1 : 3;
+    const int nact = (e->resident || e->resident32) ? 1 : 3;
     for (int i = 0; i < nact; i++)
         if (e->dmalloc(&e->act[i], rows * e->cp * e->esz)) return 1;
     // head temporaries

@@ -114,6 +114,23 @@ size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
 void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);
 
+// ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----
+// Requirements: f32, channels 256 with h*w <= 64, or channels 128 with h*w <= 96; depth >= 1.
+struct Tower32Args {
+    const float *x0;      // encoded input [batch*hw][ldx0] f32 (channels beyond c_in are zero)
+    int ldx0, c_in;
+    const void *weights;  // tower32_pack_weights: stem, then the 2*depth tower convolutions
+    const float *bias;    // [1 + 2*depth][channels]
+    const float *post_scale, *post_shift;  // final BN [channels]
+    float *y;             // tower output [batch*hw][ldy] f32
+    int ldy, batch, h, w, channels, depth;
+};
+bool tower32_supported(int dtype, int h, int w, int channels, int depth);
+int tower32_boards_per_workgroup(int h, int w, int channels);
+size_t tower32_weight_elems(int c_in, int channels, int depth);
+void tower32_pack_weights(const float *oihw, int cout, int cin, bool stem, float *dst);
+void launch_tower32(const Tower32Args &a, hipStream_t stream);
+
 // ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----
 // Requirements: f16, h*w <= 64, channels == 256 (cp), any depth >= 1.
 struct TowerArgs {

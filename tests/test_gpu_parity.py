@@ -408,6 +408,40 @@ def test_board_conv_path_vs_oracle(dev, game, depth, batch):
     assert np.abs(sg - s).max() < 5e-3 and np.abs(pg - p).max() < 2e-2
 
 
+@pytest.mark.parametrize("game,depth,channels,head,batches", [
+    ("ataxx-7", 3, 128, "ataxx_conv", (1, 2, 13)),   # two boards per workgroup, ragged last workgroup
+    ("chess", 2, 256, "attention", (1, 5)),          # one board per workgroup, 64 rows
+    ("chess", 2, 128, "attention", (3,)),            # 128 channels on an 8x8 board: one board per workgroup
+    ("go-9", 2, 128, "conv", (3,)),                  # 81 pixels: six tiles
+])
+def test_resident_f32_tower_vs_oracle(dev, game, depth, channels, head, batches):
+    """Exact-f32 board-resident launch (kz_tower_resident_f32): <= 1e-4 against the oracle for every supported
+    shape, and the per-layer implicit-GEMM path of the same engine (KZ_FORCE_GENERIC) agrees with it."""
+    blob = synth.random_model(game, depth, channels, head, seed=71)
+    net = O.OracleNet(blob)
+    model = capi.Model(blob=blob)
+    eng = capi.Engine(model, dev, 16, capi.KZ_DTYPE_F32)
+    assert eng.tower_path == "tower_resident_f32"
+    os.environ["KZ_FORCE_GENERIC"] = "1"
+    try:
+        gen = capi.Engine(model, dev, 16, capi.KZ_DTYPE_F32)
+    finally:
+        del os.environ["KZ_FORCE_GENERIC"]
+    assert gen.tower_path == "conv_igemm_f32"
+    for batch in batches:
+        bits, scalars_in = synth.random_boards(game, batch, seed=72 + batch)
+        dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+        s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+        s, p = eng.eval_packed(bits, scalars_in)
+        assert_f32(s, s_ref, f"scalars b={batch}")
+        assert_f32(p, p_ref, f"policy b={batch}")
+        sd, pd = eng.eval_dense(dense)
+        assert np.array_equal(sd, s) and np.array_equal(pd, p)  # dense and packed entry points: same launch
+        sg, pg = gen.eval_packed(bits, scalars_in)
+        assert_f32(sg, s, f"generic vs resident scalars b={batch}")
+        assert_f32(pg, p, f"generic vs resident policy b={batch}")
+
+
 def test_profiling_reports_kernel_time(dev):
     blob = O.load_blob("ataxx7_4x64")
     net = O.OracleNet(blob)
