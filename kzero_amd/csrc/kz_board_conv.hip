@@ -9,12 +9,15 @@
 // for TWO workgroups per CU — one stages or stores while the other multiplies:
 //
 //   workgroup = 24 tiles of 16 pixel rows (bpw boards, each padded to tpb = ceil(h*w/16) tiles; Go: 23 tiles, bpw = 1)
-//               x 64 output channels; 256 threads = 4 waves; wave = (row half: 12 tiles) x (32 output channels)
-//   LDS       = one 64-channel chunk of the image: two planes (channels [0,32) and [32,64)) of 400 rows x 80 B = 64 KB.
-//               The two lane groups that share a ds_read_b128 bank group read the two planes at the same row offset, the
-//               planes are a multiple of 256 B apart and rows advance by 5 sixteen-byte slots -> conflict-free
-//               fragment reads for every tap.
-//   registers = 96 accumulators + 48 fragment + 24..48 weight ring: < 256, two waves per SIMD.
+//               x 64 output channels; 256 threads = 4 waves; wave = (row quarter: 6 tiles) x (all 64 output channels)
+//   LDS       = one 64-channel chunk of the image, WITH a zero halo: board b, pixel (y, x) is image row
+//               b*rpb + (y+1)*(w+1) + x+1 (the right halo of a line is the left halo of the next), so a tap is a constant
+//               row offset and needs no validity test in the k-loop — per tap and tile ONE v_add, against a
+//               compare/select chain per tile that made the loop issue-bound.  Two planes (channels [0,32) and
+//               [32,64)) of rows x 80 B, a multiple of 256 B apart: the two lane groups that share a ds_read_b128
+//               bank group read the two planes at the same row offset and rows advance by 5 sixteen-byte slots ->
+//               conflict-free fragment reads, except one 2-way pair in tiles that cross a line end.  Go: 66 KB.
+//   registers = 96 accumulators + 24 fragment + 48 weight ring: < 256, two waves per SIMD.
 //   grid      = 1-D, XCD-aware: the cout/64 workgroups of one board group run on ONE XCD back to back, so the
 //               image is read from HBM once and from that XCD's L2 by the others.
 #include <cstdio>
@@ -35,20 +38,31 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int MT = 24;                 // 16-row tiles per workgroup
-constexpr int MTW = MT / 2;            // tiles per wave (row half)
+constexpr int MTW = MT / 4;            // tiles per wave (row quarter)
+constexpr int NTW = 4;                 // 16-channel output tiles per wave: all 64 channels of the workgroup
 constexpr int ROWS = MT * 16;          // 384
 constexpr int OCW = 64;                // output channels per workgroup
 constexpr int CH = 64;                 // input channels per staged chunk
 constexpr int PRS = 32 * 2 + 16;       // plane row stride: 32 channels + 16 B pad = 80 B
-constexpr int PLANE = (ROWS + 16) * PRS;  // 400 rows (384 + 16 zero rows) = 32,000 B = 125 * 256
-constexpr int ZROW = ROWS;             // first zero row
-constexpr int LDS_BYTES = 2 * PLANE;   // 64,000 B: two workgroups per CU
+constexpr int LDS_MAX = 80 * 1024;     // two workgroups per CU
+constexpr int ORS = OCW * 2 + 16;      // row stride of the epilogue's output tile
 constexpr int KPC = 18;                // k-steps (32 channels of one tap) per chunk: 9 taps x 2
 constexpr int PF = 3;                  // weight ring depth in k-steps (a k-step is 24 MFMAs = 384 cycles per wave)
-static_assert(PLANE % 256 == 0, "planes must be a whole number of bank rows apart");
 static_assert(KPC % PF == 0, "ring stage of a k-step must not depend on the chunk");
 
-constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
+// fragment read from an integer LDS byte address (the dynamic LDS block starts at 0; going through the `lds` symbol
+// costs a v_add per read)
+__device__ __forceinline__ h16x8 lds_frag(int addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const h16x8 __attribute__((address_space(3))) * lds_cptr;
+    return *(lds_cptr)(unsigned)addr;
+#else
+    (void)addr;
+    return h16x8{};
+#endif
+}
+
+constexpr int SG_MFMA = 0x8, SG_DS_READ = 0x100;
 
 // Diagnostic build only (-DKZ_BC_STAMPS): s_memtime stamps at the phase boundaries of every wave, dumped by the
 // launcher to $KZ_BC_STAMP_FILE after the 20th launch.  No stamp executes in the real kernel.
@@ -67,15 +81,17 @@ constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
 struct BoardConvDev {
     const h16 *x;       // [boards*hw][ld]
-    const uint4 *w;     // fragment-packed: [n_quarter][k-step][oc half 2][nt 2][lane 64] x 16 B
+    const uint4 *w;     // fragment-packed: [n_quarter][k-step][nt 4][lane 64] x 16 B
     const float *bias, *post_scale, *post_shift;  // [cout]
     const h16 *res;     // optional residual [boards*hw][ld]
     h16 *y;             // [boards*hw][ld]
     int bytes;          // size of each of those tensors: boards * hw * ld * 2 (< 2^31)
     int ld, boards, h, w_, hw, tpb, bpw, cin, relu, groups, nq;
+    int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
     unsigned inv_w;    // ceil(65536 / w): q / w == (q * inv_w) >> 16 for q < 512, w <= 32
     unsigned long long *stamps;  // diagnostic build only
-    int ablate;        // timing experiments only (KZ_BC_ABLATE): 1 no staging loads, 2 no residual/output traffic, 4 no MFMA
+    int ablate;        // timing experiments only (KZ_BC_ABLATE): 1 no staging loads, 2 no residual/output traffic,
+                       // 16 no issue priority
     unsigned inv_tpb;  // ceil(65536 / tpb): mt / tpb == (mt * inv_tpb) >> 16 for mt < 24
 };
 
@@ -83,12 +99,21 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = wave & 1, wr = wave >> 1;  // output-channel half, row half
+    const int wr = wave;  // row quarter: a wave owns 6 tiles x all 64 output channels, so an activation fragment
+                          // feeds 4 MFMAs (LDS bandwidth was the k-loop's co-bottleneck at 2) and a weight fragment 6
     const int lane = tid & 63;
     const int fr = lane & 15, kq = lane >> 4;
     // XCD-aware order: consecutive workgroup ids go to consecutive XCDs, so id = (slot, xcd); the nq channel quarters of
     // a board group take consecutive slots of one XCD
     KZ_STAMP(0);
+    // Two workgroups share a CU.  Left alone they run in lockstep — same work, MFMA pipe shared 50/50, so both stage,
+    // both multiply, both store at the same time and nothing overlaps.  Giving ONE of them issue priority (the one
+    // whose LDS allocation starts at 0) lets it run its k-loops at full rate and reach its staging/epilogue phases
+    // while the other multiplies: the pair falls into complementary phases.
+    if (!(a.ablate & 16)) {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);  // HW_REG_LDS_ALLOC.LDS_BASE
+        if (lds_base == 0) __builtin_amdgcn_s_setprio(3);
+    }
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nquarter = slot % a.nq, group = (slot / a.nq) * 8 + xcd;
     if (group >= a.groups) return;
@@ -96,81 +121,70 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const int chunks = a.cin / CH;
     const int total_ksteps = chunks * KPC;
 
-    // weight ring: k-step g of this (layer, quarter): 4 KB = [oc half][nt 2][lane] x 16 B
-    const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + wo * 128 + lane;
-    uint4 wreg[PF][2];
+    // weight ring: k-step g of this (layer, quarter): 4 KB = [nt 4][lane] x 16 B, the same for the four waves
+    const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + lane;
+    uint4 wreg[PF][NTW];
 #pragma unroll
     for (int s = 0; s < PF; s++) {
         const int g = s < total_ksteps ? s : total_ksteps - 1;
-        wreg[s][0] = wp[(size_t)g * 256];
-        wreg[s][1] = wp[(size_t)g * 256 + 64];
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) wreg[s][nt] = wp[(size_t)g * 256 + nt * 64];
     }
     int g = 0;
 
-    // zero rows of both planes
-    for (int id = tid; id < 2 * 16 * PRS / 16; id += 256) {
-        const int plane = id / (16 * PRS / 16), off = id % (16 * PRS / 16);
-        *reinterpret_cast<uint4 *>(lds + plane * PLANE + ZROW * PRS + off * 16) = make_uint4(0, 0, 0, 0);
-    }
+    // zero the whole image once: the halo rows are never written again, the pixel rows are overwritten by every chunk
+    for (int id = tid; id < 2 * a.plane / 16; id += 256) *reinterpret_cast<uint4 *>(lds + id * 16) = make_uint4(0, 0, 0, 0);
 
     // The 12 (pixel row, 16-byte piece) slots this thread copies, for staging and for the epilogue alike: slot i is tile
     // row (tid >> 3) + 32 i, piece tid & 7.  po[i] = byte offset of that slot in a [pixels][ld] activation tensor
-    // (x, y and the residual share ld), or -1 for a padding row; 32-bit offsets on a uniform base keep the twelve
-    // addresses in twelve registers.
+    // (x, y and the residual share ld), or -1 for a padding row (32-bit offsets on a uniform base keep the twelve
+    // addresses in twelve registers); ls[i] = where the piece goes in the halo image.
     const int piece = tid & 7;
-    int po[12];
+    int po[12], ls[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         const int row = (tid >> 3) + i * 32;
         const int mt = row >> 4, b = (int)(((unsigned)mt * a.inv_tpb) >> 16), q = (mt - b * a.tpb) * 16 + (row & 15);
+        const int yy = (int)(((unsigned)q * a.inv_w) >> 16), xx = q - yy * a.w_;
         po[i] = (b < a.bpw && board0 + b < a.boards && q < a.hw) ? (((board0 + b) * a.hw + q) * a.ld + piece * 8) * 2 : -1;
+        ls[i] = (b * a.rpb + (yy + 1) * a.pitch + xx + 1) * PRS + (piece >> 2) * a.plane + (piece & 3) * 16;
     }
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.x), 0, a.bytes, 0x00020000);
-    const int stage_lds = (piece >> 2) * PLANE + (tid >> 3) * PRS + (piece & 3) * 16;  // + i * 32 * PRS
 
-    // Validity of (tile row, tap) as bitmasks over this wave's 12 tiles: bit i of okmask[tap] says that, for this lane's
-    // row of tile 12*wr + i, the tap lands on the board.  Computed once, so a tap costs 3 VALU per tile in the k-loop.
-    unsigned okmask[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // Centre-tap LDS address of this lane's fragment row for each of the wave's 12 tiles (plane kq & 1, 16-byte piece
+    // kq >> 1 of the k-step); a lane without a pixel (padding row, missing board) reads pixel (0, 0) of board 0 — its
+    // outputs are never stored.
+    int T0[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
         const int mt = wr * MTW + i;
         const int b = (int)(((unsigned)mt * a.inv_tpb) >> 16), t = mt - b * a.tpb, q = t * 16 + fr;
-        const unsigned valid = b < a.bpw && board0 + b < a.boards && q < a.hw;
+        const bool valid = b < a.bpw && board0 + b < a.boards && q < a.hw;
         const int yy = (int)(((unsigned)q * a.inv_w) >> 16), xx = q - yy * a.w_;
-        const unsigned ym[3] = {(unsigned)(yy >= 1), 1u, (unsigned)(yy <= a.h - 2)};
-        const unsigned xm[3] = {(unsigned)(xx >= 1), 1u, (unsigned)(xx <= a.w_ - 2)};
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) okmask[tap] |= (valid & ym[tap / 3] & xm[tap % 3]) << i;
+        const int row = valid ? b * a.rpb + (yy + 1) * a.pitch + xx + 1 : a.pitch + 1;
+        T0[i] = row * PRS + (kq & 1) * a.plane + (kq >> 1) * 16;
     }
 
-    f32x4 acc[2][MTW];
+    f32x4 acc[NTW][MTW];
     {
-        const int oc = nquarter * OCW + wo * 32 + kq * 4;
+        const int oc = nquarter * OCW + kq * 4;
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
+        for (int nt = 0; nt < NTW; nt++) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + oc + nt * 16);
 #pragma unroll
             for (int i = 0; i < MTW; i++) acc[nt][i] = b;
         }
     }
 
-    // fragment address pieces that do not depend on the tap: plane (kq & 1), 16-byte piece (kq >> 1) of the k-step,
-    // first row of this wave's row half
-    const int lane_off = (kq & 1) * PLANE + (kq >> 1) * 16 + wr * MTW * 16 * PRS;
-
-    // LDS address of this lane's fragment row per tile for one tap (pixel shifted by the tap, or a zero row)
-    // (frow is fr behind an optimisation barrier inside the chunk loop: the rows are the same for every chunk, and the
-    // compiler would otherwise hoist all 9 x 12 of them out of the loop and spill them)
-    auto tap_rows = [&](int tap, int lo, int hi, int frow, int (&T)[MTW]) {
-        const int shift = (tap / 3 - 1) * a.w_ + (tap % 3 - 1);
-        unsigned ok = okmask[tap];
-        asm volatile("" : "+v"(ok));  // same reason: 108 hoisted lane masks would not fit the SGPR file
-        const int shifted = (frow + shift) * PRS + lane_off;                                    // + i * 16 * PRS per tile
-        const int zero = (ZROW + ((frow + shift) & 15)) * PRS + (kq & 1) * PLANE + (kq >> 1) * 16;  // same slot pattern
+    // LDS address of this lane's fragment row per tile for one tap: a constant row offset in the halo image.
+    // (pitch_prs is a.pitch * PRS behind an optimisation barrier inside the chunk loop: the rows are the same for every
+    // chunk, and the compiler would otherwise hoist all 9 x 12 of them out of the loop and spill them)
+    auto tap_rows = [&](int tap, int lo, int hi, int pitch_prs, int (&T)[MTW]) {
+        const int off = (tap / 3 - 1) * pitch_prs + (tap % 3 - 1) * PRS;
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             if (i < lo || i >= hi) continue;
-            T[i] = ((ok >> i) & 1) ? shifted + i * 16 * PRS : zero;
+            T[i] = T0[i] + off;
         }
     };
 
@@ -180,29 +194,30 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         __syncthreads();  // everyone is done reading the previous chunk
         KZ_STAMP(2 + chunk * 4);
         {
-            // 12 pieces per thread, all in flight at once (the fragment registers are dead here); a padding row's offset
-            // is out of the descriptor's range and reads as zeros
+            // 12 pieces per thread, all in flight at once (the fragment registers are dead here)
             u32x4 v[12];
 #pragma unroll
             for (int i = 0; i < 12; i++)
                 v[i] = (a.ablate & 1) ? u32x4{0, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], chunk * CH * 2, 0);
 #pragma unroll
-            for (int i = 0; i < 12; i++) *reinterpret_cast<u32x4 *>(lds + stage_lds + i * 32 * PRS) = v[i];
+            for (int i = 0; i < 12; i++)
+                if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + ls[i]) = v[i];  // never into the halo
         }
         KZ_STAMP(3 + chunk * 4);
         __syncthreads();
         KZ_STAMP(4 + chunk * 4);
 
-        // Two half-steps per k-step: the MFMAs of tiles 0..5 run while the fragments of tiles 6..11 are read, and
-        // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (same workgroup or
-        // the CU's second workgroup) fills whatever latency is left.
+        // Two half-steps per k-step: the MFMAs of tiles 0..2 run while the fragments of tiles 3..5 are read, and
+        // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (the CU's second
+        // workgroup) fills whatever latency is left.
+        constexpr int HT = MTW / 2;
         int T[MTW];
-        h16x8 bfA[MTW / 2], bfB[MTW / 2];
-        int frow = fr;
-        asm volatile("" : "+v"(frow));
-        tap_rows(0, 0, MTW, frow, T);
+        h16x8 bfA[HT], bfB[HT] = {};
+        int pitch_prs = a.pitch * PRS;
+        asm volatile("" : "+s"(pitch_prs));
+        tap_rows(0, 0, MTW, pitch_prs, T);
 #pragma unroll
-        for (int i = 0; i < MTW / 2; i++) bfA[i] = *reinterpret_cast<const h16x8 *>(lds + T[i]);
+        for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i]);
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int next_tap = tap < 8 ? tap + 1 : 8;
@@ -210,51 +225,47 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
             for (int ks = 0; ks < 2; ks++) {
                 const int stage = (tap * 2 + ks) % PF;
                 // ---- half 1 ----
+#ifndef KZ_BC_NO_DSREAD  // (timing experiments: a build without the fragment reads)
 #pragma unroll
-                for (int i = 0; i < MTW / 2; i++)
-                    bfB[i] = *reinterpret_cast<const h16x8 *>(lds + T[MTW / 2 + i] + ks * 32);
-                h16x8 af[2];
-                af[0] = *reinterpret_cast<const h16x8 *>(&wreg[stage][0]);
-                af[1] = *reinterpret_cast<const h16x8 *>(&wreg[stage][1]);
-                {
-                    const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
-                    wreg[stage][0] = wp[(size_t)gn * 256];
-                    wreg[stage][1] = wp[(size_t)gn * 256 + 64];
-                }
+                for (int i = 0; i < HT; i++) bfB[i] = lds_frag(T[HT + i] + ks * 32);
+#endif
+                h16x8 af[NTW];  // aliases of the ring stage (no copy: the stage is reloaded after this k-step's MFMAs)
 #pragma unroll
-                for (int i = 0; i < MTW / 2; i++) {
-                    acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfA[i], acc[0][i], 0, 0, 0);
-                    acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bfA[i], acc[1][i], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
+                for (int nt = 0; nt < NTW; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
 #pragma unroll
-                for (int i = 0; i < MTW / 2 - 2; i++) {
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 2, 0);
+                for (int i = 0; i < HT; i++)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++)
+                        acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfA[i], acc[nt][i], 0, 0, 0);
+                // all three reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
+                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- half 2 ----
-                // T is updated in place for the next tap: rows 0..5 are dead after the last half-2 read of this tap,
-                // rows 6..11 after the half-1 read above
-                if (ks == 1) tap_rows(next_tap, 0, MTW / 2, frow, T);
+                // T is updated in place for the next tap: rows 0..2 are dead after the last half-2 read of this tap,
+                // rows 3..5 after the half-1 read above
+                if (ks == 1) tap_rows(next_tap, 0, HT, pitch_prs, T);
+#ifndef KZ_BC_NO_DSREAD
 #pragma unroll
-                for (int i = 0; i < MTW / 2; i++)
-                    bfA[i] = *reinterpret_cast<const h16x8 *>(lds + T[i] + (ks < 1 ? (ks + 1) * 32 : 0));
-                if (ks == 1) tap_rows(next_tap, MTW / 2, MTW, frow, T);
+                for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i] + (ks < 1 ? (ks + 1) * 32 : 0));
+#endif
+                if (ks == 1) tap_rows(next_tap, HT, MTW, pitch_prs, T);
 #pragma unroll
-                for (int i = 0; i < MTW / 2; i++) {
-                    acc[0][MTW / 2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bfB[i], acc[0][MTW / 2 + i], 0, 0, 0);
-                    acc[1][MTW / 2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bfB[i], acc[1][MTW / 2 + i], 0, 0, 0);
+                for (int i = 0; i < HT; i++)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++)
+                        acc[nt][HT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[i], acc[nt][HT + i], 0, 0, 0);
+                // all three reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
+                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef KZ_BC_NO_WLOAD  // (timing experiments: a build without the weight stream)
+                {   // this stage's fragments have been issued to the MFMAs: refill it for k-step g + PF
+                    const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)gn * 256 + nt * 64];
                 }
-#pragma unroll
-                for (int i = 0; i < MTW / 2; i++) {
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
-                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
@@ -265,8 +276,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
     // Staged through LDS (the image is dead now) so that HBM sees whole 128-byte lines (this workgroup's 64 output
     // channels of a pixel) instead of 8-byte pieces: O[row][64 oc] f16, row stride 144 B.
-    constexpr int ORS = OCW * 2 + 16;
-    static_assert(ROWS * ORS <= LDS_BYTES, "output tile fits the image buffer");
     __syncthreads();  // every wave is done with the last chunk's fragments
     KZ_STAMP(18);
     const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
@@ -280,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         __syncthreads();
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-        const int ocl = wo * 32 + nt * 16 + kq * 4;  // within this workgroup's 64 channels
+    for (int nt = 0; nt < NTW; nt++) {
+        const int ocl = nt * 16 + kq * 4;  // within this workgroup's 64 channels
         f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.post_scale) {
             ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nquarter * OCW + ocl);
@@ -317,20 +326,38 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 
 }  // namespace
 
+namespace {
+// halo image geometry: boards per workgroup limited by the 24 tiles and by 40 KB per plane (two workgroups per CU)
+struct Geometry {
+    int tpb, bpw, pitch, rpb, plane, lds_bytes;
+};
+Geometry geometry(int h, int w) {
+    Geometry g{};
+    g.tpb = (h * w + 15) / 16;
+    g.pitch = w + 1;
+    g.rpb = (h + 2) * g.pitch + 1;
+    const int by_tiles = g.tpb <= MT ? MT / g.tpb : 0, by_lds = (LDS_MAX / 2 / PRS) / g.rpb;
+    g.bpw = by_tiles < by_lds ? by_tiles : by_lds;
+    g.plane = (g.bpw * g.rpb * PRS + 255) / 256 * 256;
+    g.lds_bytes = 2 * g.plane > ROWS * ORS ? 2 * g.plane : ROWS * ORS;  // the epilogue reuses it for the output tile
+    return g;
+}
+}  // namespace
+
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout) {
-    const int hw = h * w, tpb = (hw + 15) / 16;
-    return dtype == 1 && cin % CH == 0 && cout % OCW == 0 && tpb <= MT && w <= 32 && h <= 32;
+    return dtype == 1 && cin % CH == 0 && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 &&
+           geometry(h, w).bpw >= 1;
 }
 
 int board_conv_workgroups(int boards, int h, int w, int cout) {
-    const int tpb = (h * w + 15) / 16, bpw = tpb <= MT ? MT / tpb : 1;
-    return ((boards + bpw - 1) / bpw) * (cout / OCW);
+    const int bpw = geometry(h, w).bpw;
+    return bpw ? ((boards + bpw - 1) / bpw) * (cout / OCW) : 0;
 }
 
 size_t board_conv_weight_elems(int cin, int cout) { return (size_t)9 * cin * cout; }
 
-// OIHW f32 (BN folded) -> [n_quarter][chunk][tap][ks 2][oc half 2][nt 2][lane 64][8] f16: element j of lane (fr, kq) is
-// W[oc = 64*n_quarter + 32*half + 16*nt + fr][channel = 64*chunk + 32*(kq&1) + 16*ks + 8*(kq>>1) + j][tap]
+// OIHW f32 (BN folded) -> [n_quarter][chunk][tap][ks 2][nt 4][lane 64][8] f16: element j of lane (fr, kq) is
+// W[oc = 64*n_quarter + 16*nt + fr][channel = 64*chunk + 32*(kq&1) + 16*ks + 8*(kq>>1) + j][tap]
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst) {
     const int chunks = cin / CH, quarters = cout / OCW;
     size_t o = 0;
@@ -338,18 +365,17 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
         for (int chunk = 0; chunk < chunks; chunk++)
             for (int tap = 0; tap < 9; tap++)
                 for (int ks = 0; ks < 2; ks++)
-                    for (int half = 0; half < 2; half++)
-                        for (int nt = 0; nt < 2; nt++)
-                            for (int lane = 0; lane < 64; lane++)
-                                for (int j = 0; j < 8; j++) {
-                                    const int kq = lane >> 4;
-                                    const int oc = OCW * nq + 32 * half + 16 * nt + (lane & 15);
-                                    const int ch = CH * chunk + 32 * (kq & 1) + 16 * ks + 8 * (kq >> 1) + j;
-                                    const _Float16 hv = (_Float16)oihw[((size_t)oc * cin + ch) * 9 + tap];
-                                    uint16_t bits;
-                                    __builtin_memcpy(&bits, &hv, 2);
-                                    dst[o++] = bits;
-                                }
+                    for (int nt = 0; nt < NTW; nt++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int j = 0; j < 8; j++) {
+                                const int kq = lane >> 4;
+                                const int oc = OCW * nq + 16 * nt + (lane & 15);
+                                const int ch = CH * chunk + 32 * (kq & 1) + 16 * ks + 8 * (kq >> 1) + j;
+                                const _Float16 hv = (_Float16)oihw[((size_t)oc * cin + ch) * 9 + tap];
+                                uint16_t bits;
+                                __builtin_memcpy(&bits, &hv, 2);
+                                dst[o++] = bits;
+                            }
 }
 
 void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
@@ -367,8 +393,12 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.h = t.h;
     d.w_ = t.w;
     d.hw = t.h * t.w;
-    d.tpb = (d.hw + 15) / 16;
-    d.bpw = MT / d.tpb;
+    const Geometry geo = geometry(t.h, t.w);
+    d.tpb = geo.tpb;
+    d.bpw = geo.bpw;
+    d.pitch = geo.pitch;
+    d.rpb = geo.rpb;
+    d.plane = geo.plane;
     d.cin = t.cin;
     d.relu = t.relu;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
@@ -381,7 +411,7 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done_mask >> (dev & 63)) & 1)) {
-        (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done_mask |= 1ull << (dev & 63);
     }
     const int grid = ((d.groups + 7) / 8) * 8 * d.nq;
@@ -395,7 +425,10 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
 #else
     d.stamps = nullptr;
 #endif
-    kz_board_conv_f16<<<grid, 256, LDS_BYTES, stream>>>(d);
+    // KZ_BC_LDS_MIN (timing experiments only): a larger allocation forces one workgroup per CU
+    static const int lds_min = getenv("KZ_BC_LDS_MIN") ? atoi(getenv("KZ_BC_LDS_MIN")) : 0;
+    const int lds_bytes = geo.lds_bytes > lds_min ? geo.lds_bytes : (lds_min < 160 * 1024 ? lds_min : 160 * 1024);
+    kz_board_conv_f16<<<grid, 256, lds_bytes, stream>>>(d);
 #ifdef KZ_BC_STAMPS
     if (launches++ == 20 && getenv("KZ_BC_STAMP_FILE")) {
         (void)hipStreamSynchronize(stream);
