@@ -394,6 +394,63 @@ __device__ __forceinline__ float dot_row(const T *__restrict__ x, const float *_
     return acc;
 }
 
+// NF 1x1-conv filters over all pixel rows of one board, coalesced: a wave-instruction reads 64/G whole pixel rows
+// (G = 16-byte pieces per row, a power of two <= 64; lane = (row, piece)), every lane multiplies its piece with its
+// slice of the filters and the G lanes of a row add up by butterfly; U row groups in flight per wave.  emit(p, sums) runs
+// on one lane per pixel row.  (One thread walking a 512-byte row on its own — dot_row per (filter, pixel) — costs 10x
+// the time at Go size: each lane of a wave then reads a different row.)  Call with all 256 threads of the workgroup.
+template <typename T>
+__device__ __forceinline__ bool rows_coalescable(int ld) {
+    const int G = ld / Elem<T>::EPL;
+    return G <= 64 && (G & (G - 1)) == 0;
+}
+template <typename T, int NF, typename Emit>
+__device__ __forceinline__ void rows_dot(const T *__restrict__ xb, int ld, int hw, int c, const float *__restrict__ w,
+                                         Emit emit) {
+    constexpr int EPL = Elem<T>::EPL, U = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = ld / EPL, R = 64 / G, r = lane / G, piece = lane % G;
+    float wf[NF][EPL];
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            const int ch = piece * EPL + j;
+            wf[f][j] = ch < c ? w[(size_t)f * c + ch] : 0.0f;
+        }
+    for (int p0 = wave * R; p0 < hw; p0 += 4 * R * U) {
+        float xv[U][EPL];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = p0 + u * 4 * R + r;
+            const T *src = xb + (size_t)(p < hw ? p : 0) * ld + piece * EPL;
+#pragma unroll
+            for (int h = 0; h < EPL / 4; h++) {
+                float t[4];
+                load4<T>(src + h * 4, t);
+#pragma unroll
+                for (int j = 0; j < 4; j++) xv[u][h * 4 + j] = t[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int p = p0 + u * 4 * R + r;
+            float sum[NF];
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                float t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) t += xv[u][j] * wf[f][j];
+                sum[f] = t;
+            }
+            for (int off = G >> 1; off > 0; off >>= 1)
+#pragma unroll
+                for (int f = 0; f < NF; f++) sum[f] += __shfl_xor(sum[f], off, 64);
+            if (piece == 0 && p < hw) emit(p, sum);
+        }
+    }
+}
+
 struct ScalarHeadDev {
     const void *x;
     int ldx, batch, hw, c, hc, hs;
@@ -409,10 +466,18 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const T *xb = static_cast<const T *>(a.x) + (size_t)b * a.hw * a.ldx;
 
-    for (int o = tid; o < a.hc * a.hw; o += 256) {
-        const int ch = o / a.hw, p = o % a.hw;
-        const float v = dot_row<T>(xb + (size_t)p * a.ldx, a.w0 + (size_t)ch * a.c, a.c) + a.b0[ch];
-        act[o] = fmaxf(v, 0.0f);
+    if (a.hc == 4 && rows_coalescable<T>(a.ldx)) {
+        const float bias[4] = {a.b0[0], a.b0[1], a.b0[2], a.b0[3]};
+        rows_dot<T, 4>(xb, a.ldx, a.hw, a.c, a.w0, [&](int p, const float(&sum)[4]) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) act[ch * a.hw + p] = fmaxf(sum[ch] + bias[ch], 0.0f);
+        });
+    } else {
+        for (int o = tid; o < a.hc * a.hw; o += 256) {
+            const int ch = o / a.hw, p = o % a.hw;
+            const float v = dot_row<T>(xb + (size_t)p * a.ldx, a.w0 + (size_t)ch * a.c, a.c) + a.b0[ch];
+            act[o] = fmaxf(v, 0.0f);
+        }
     }
     __syncthreads();
     const int n_in = a.hc * a.hw;
@@ -452,6 +517,12 @@ __global__ __launch_bounds__(256) void kz_policy_conv(PolicyConvDev a) {
     const T *yb = static_cast<const T *>(a.y) + (size_t)b * a.hw * a.ldy;
     float *pol = a.policy + (size_t)b * a.policy_len;
     const int n_out = a.pc * a.hw;
+    if (a.pc == 1 && gridDim.y == 1 && rows_coalescable<T>(a.ldy)) {  // one filter (the Go conv head): coalesced rows
+        const float bias = a.b[0];
+        rows_dot<T, 1>(yb, a.ldy, a.hw, a.c, a.w, [&](int p, const float(&sum)[1]) { pol[p] = sum[0] + bias; });
+        for (int o = n_out + threadIdx.x; o < n_out + a.zero_tail; o += 256) pol[o] = 0.0f;
+        return;
+    }
     for (int o = blockIdx.y * 256 + threadIdx.x; o < n_out + a.zero_tail; o += gridDim.y * 256) {
         if (o >= n_out) {
             pol[o] = 0.0f;  // AtaxxConvPolicyHead: the pass logit is a constant zero column (post_act.py:106-110)
@@ -466,6 +537,7 @@ void launch_policy_conv(int dtype, const PolicyConvArgs &a, hipStream_t stream) 
     PolicyConvDev d{a.y, a.ldy, a.batch, a.hw, a.c, a.pc, a.w, a.b, a.policy, a.policy_len, a.zero_tail};
     int gy = (a.pc * a.hw + a.zero_tail + 255) / 256;
     if (gy > 8) gy = 8;
+    if (a.pc == 1) gy = 1;  // one workgroup per board walks the rows together
     dim3 grid(a.batch, gy);
     if (dtype == 0) kz_policy_conv<float><<<grid, 256, 0, stream>>>(d);
     else kz_policy_conv<h16><<<grid, 256, 0, stream>>>(d);
@@ -484,7 +556,12 @@ __global__ __launch_bounds__(256) void kz_policy_extra(PolicyExtraDev a) {
     extern __shared__ __attribute__((aligned(16))) float sh[];  // [hw]
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const T *xb = static_cast<const T *>(a.x) + (size_t)b * a.hw * a.ldx;
-    for (int p = tid; p < a.hw; p += 256) sh[p] = dot_row<T>(xb + (size_t)p * a.ldx, a.wc, a.c) + a.bc[0];
+    if (rows_coalescable<T>(a.ldx)) {
+        const float bias = a.bc[0];
+        rows_dot<T, 1>(xb, a.ldx, a.hw, a.c, a.wc, [&](int p, const float(&sum)[1]) { sh[p] = sum[0] + bias; });
+    } else {
+        for (int p = tid; p < a.hw; p += 256) sh[p] = dot_row<T>(xb + (size_t)p * a.ldx, a.wc, a.c) + a.bc[0];
+    }
     __syncthreads();
     for (int j = wave; j < a.extra; j += 4) {
         float acc = 0.0f;
