@@ -106,6 +106,13 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     // XCD-aware order: consecutive workgroup ids go to consecutive XCDs, so id = (slot, xcd); the nq channel quarters of
     // a board group take consecutive slots of one XCD
     KZ_STAMP(0);
+#ifdef KZ_BC_STAMPS
+    if (lane == 0) {  // where this workgroup ran: HW_ID, XCC_ID, LDS_ALLOC
+        a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 29] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+        a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 30] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+        a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 31] = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);
+    }
+#endif
     // Two workgroups share a CU.  Left alone they run in lockstep — same work, MFMA pipe shared 50/50, so both stage,
     // both multiply, both store at the same time and nothing overlaps.  Giving ONE of them issue priority (the one
     // whose LDS allocation starts at 0) lets it run its k-loops at full rate and reach its staging/epilogue phases

@@ -18,3 +18,28 @@ for i in range(1, 21):
 # start times: how WGs are spread
 st = np.sort(d[:, 0, 0] - t0)
 print("start-time quantiles:", [int(np.percentile(st, q)) for q in (0, 25, 50, 75, 100)])
+
+# ---- dispatch gaps: consecutive workgroups on the same (XCC, SE, CU, LDS slot) ----
+hw = d[:, 0, 29]
+xcc = d[:, 0, 30] & 0xF
+ldsb = d[:, 0, 31] & 0xFF
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 0x1
+se = (hw >> 13) & 0x7
+key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+slot = (ldsb != 0).astype(np.int64)
+import collections
+groups = collections.defaultdict(list)
+for i in range(d.shape[0]):
+    groups[(int(key[i]), int(slot[i]))].append((int(d[i, :, 0].min()), int(d[i, :, 20].max())))
+gaps, per = [], []
+for k, v in groups.items():
+    v.sort()
+    per.append(len(v))
+    for (s0, e0), (s1, e1) in zip(v, v[1:]):
+        gaps.append(s1 - e0)
+if gaps:
+    gaps = np.array(gaps)
+    print("CU slots seen:", len(groups), "workgroups per slot mean:", np.mean(per))
+    print("gap between consecutive workgroups on a CU slot: mean %.0f p10 %.0f p50 %.0f p90 %.0f" %
+          (gaps.mean(), np.percentile(gaps, 10), np.percentile(gaps, 50), np.percentile(gaps, 90)))
