@@ -22,6 +22,9 @@
 //               image is read from HBM once and from that XCD's L2 by the others.
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 #include <type_traits>
 
@@ -87,12 +90,13 @@ struct BoardConvDev {
     h16 *y;             // [boards*hw][ld]
     int bytes;          // size of each of those tensors: boards * hw * ld * 2 (< 2^31)
     int ld, boards, h, w_, hw, tpb, bpw, cin, relu, groups, nq;
+    const int *rowmap;             // [384] tile row -> board << 20 | pixel << 10 | image row, or -1 (padding row)
+    const unsigned short *halo;   // [n_halo] image rows that are halo (zeroed once per workgroup)
+    int n_halo;
     int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
-    unsigned inv_w;    // ceil(65536 / w): q / w == (q * inv_w) >> 16 for q < 512, w <= 32
     unsigned long long *stamps;  // diagnostic build only
     int ablate;        // timing experiments only (KZ_BC_ABLATE): 1 no staging loads, 2 no residual/output traffic,
                        // 16 no issue priority
-    unsigned inv_tpb;  // ceil(65536 / tpb): mt / tpb == (mt * inv_tpb) >> 16 for mt < 24
 };
 
 __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
@@ -128,6 +132,14 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const int chunks = a.cin / CH;
     const int total_ksteps = chunks * KPC;
 
+    // host-built tile-row map (no divisions here), fetched first so that its latency hides behind the ring fill and
+    // the halo clear: the 12 (pixel row, piece) slots this thread copies and the 6 fragment rows of this lane
+    int emap[12], emapT[MTW];
+#pragma unroll
+    for (int i = 0; i < 12; i++) emap[i] = a.rowmap[(tid >> 3) + i * 32];
+#pragma unroll
+    for (int i = 0; i < MTW; i++) emapT[i] = a.rowmap[(wr * MTW + i) * 16 + fr];
+
     // weight ring: k-step g of this (layer, quarter): 4 KB = [nt 4][lane] x 16 B, the same for the four waves
     const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + lane;
     uint4 wreg[PF][NTW];
@@ -139,9 +151,15 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     }
     int g = 0;
 
-    // zero the whole image once: the halo rows are never written again, the pixel rows are overwritten by every chunk
-    for (int id = tid; id < 2 * a.plane / 16; id += 256) *reinterpret_cast<uint4 *>(lds + id * 16) = make_uint4(0, 0, 0, 0);
+    KZ_STAMP(21);
+    // zero the halo rows once (10 sixteen-byte pieces per row: 5 per plane); they are never written again, and the
+    // pixel rows are overwritten by every chunk
+    for (int id = tid; id < a.n_halo * 10; id += 256) {
+        const int k = (int)(((unsigned)id * 6554u) >> 16), pc = id - k * 10;  // id / 10 for id < 16384
+        *reinterpret_cast<uint4 *>(lds + (pc >= 5 ? a.plane + (pc - 5) * 16 : pc * 16) + a.halo[k] * PRS) = make_uint4(0, 0, 0, 0);
+    }
 
+    KZ_STAMP(22);
     // The 12 (pixel row, 16-byte piece) slots this thread copies, for staging and for the epilogue alike: slot i is tile
     // row (tid >> 3) + 32 i, piece tid & 7.  po[i] = byte offset of that slot in a [pixels][ld] activation tensor
     // (x, y and the residual share ld), or -1 for a padding row (32-bit offsets on a uniform base keep the twelve
@@ -150,13 +168,14 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     int po[12], ls[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        const int row = (tid >> 3) + i * 32;
-        const int mt = row >> 4, b = (int)(((unsigned)mt * a.inv_tpb) >> 16), q = (mt - b * a.tpb) * 16 + (row & 15);
-        const int yy = (int)(((unsigned)q * a.inv_w) >> 16), xx = q - yy * a.w_;
-        po[i] = (b < a.bpw && board0 + b < a.boards && q < a.hw) ? (((board0 + b) * a.hw + q) * a.ld + piece * 8) * 2 : -1;
-        ls[i] = (b * a.rpb + (yy + 1) * a.pitch + xx + 1) * PRS + (piece >> 2) * a.plane + (piece & 3) * 16;
+        const int e = emap[i];
+        const int b = e >> 20, q = (e >> 10) & 1023;
+        const bool ok = e >= 0 && board0 + b < a.boards;
+        po[i] = ok ? (((board0 + b) * a.hw + q) * a.ld + piece * 8) * 2 : -1;
+        ls[i] = (e & 1023) * PRS + (piece >> 2) * a.plane + (piece & 3) * 16;
     }
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.x), 0, a.bytes, 0x00020000);
+    KZ_STAMP(23);
 
     // Centre-tap LDS address of this lane's fragment row for each of the wave's 12 tiles (plane kq & 1, 16-byte piece
     // kq >> 1 of the k-step); a lane without a pixel (padding row, missing board) reads pixel (0, 0) of board 0 — its
@@ -164,14 +183,13 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     int T0[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
-        const int mt = wr * MTW + i;
-        const int b = (int)(((unsigned)mt * a.inv_tpb) >> 16), t = mt - b * a.tpb, q = t * 16 + fr;
-        const bool valid = b < a.bpw && board0 + b < a.boards && q < a.hw;
-        const int yy = (int)(((unsigned)q * a.inv_w) >> 16), xx = q - yy * a.w_;
-        const int row = valid ? b * a.rpb + (yy + 1) * a.pitch + xx + 1 : a.pitch + 1;
+        const int e = emapT[i];
+        const bool valid = e >= 0 && board0 + (e >> 20) < a.boards;
+        const int row = valid ? (e & 1023) : a.pitch + 1;
         T0[i] = row * PRS + (kq & 1) * a.plane + (kq >> 1) * 16;
     }
 
+    KZ_STAMP(24);
     f32x4 acc[NTW][MTW];
     {
         const int oc = nquarter * OCW + kq * 4;
@@ -281,20 +299,28 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     }
 
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
-    // Staged through LDS (the image is dead now) so that HBM sees whole 128-byte lines (this workgroup's 64 output
-    // channels of a pixel) instead of 8-byte pieces: O[row][64 oc] f16, row stride 144 B.
+    // The residual comes straight into registers in the accumulators' layout (8 bytes = this lane's 4 channels of a
+    // pixel row; the loads fly while the waves meet at the barrier); the result is staged through LDS (the image is
+    // dead now) so that HBM sees whole 128-byte lines (this workgroup's 64 output channels of a pixel) instead of
+    // 8-byte pieces: O[row][64 oc] f16, row stride 144 B.
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const bool with_res = a.res && !(a.ablate & 2);
+    u32x2 resv[NTW][MTW];
+    if (with_res) {
+        const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.res), 0, a.bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MTW; i++) {
+            const int e = emapT[i];
+            const bool valid = e >= 0 && board0 + (e >> 20) < a.boards;
+            const int off = valid ? (((board0 + (e >> 20)) * a.hw + ((e >> 10) & 1023)) * a.ld + kq * 4) * 2 : -1;
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++)
+                resv[nt][i] = __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, (nquarter * OCW + nt * 16) * 2, 0);
+        }
+    }
     __syncthreads();  // every wave is done with the last chunk's fragments
     KZ_STAMP(18);
     const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
-    if (a.res && !(a.ablate & 2)) {      // residual tile, coalesced: 12 sixteen-byte pieces per thread
-        const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.res), 0, a.bytes, 0x00020000);
-        u32x4 v[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, po[i], nquarter * OCW * 2, 0);
-#pragma unroll
-        for (int i = 0; i < 12; i++) *reinterpret_cast<u32x4 *>(lds + out_lds + i * 32 * ORS) = v[i];
-        __syncthreads();
-    }
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
         const int ocl = nt * 16 + kq * 4;  // within this workgroup's 64 channels
@@ -311,8 +337,8 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
             }
-            if (a.res && !(a.ablate & 2)) {
-                const h16x4 r = *reinterpret_cast<const h16x4 *>(slot);
+            if (with_res) {
+                const h16x4 r = __builtin_bit_cast(h16x4, resv[nt][i]);
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] += (float)r[j];  // added in f32, AFTER the ReLU (post_act.py:227-228)
             }
@@ -385,6 +411,41 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
                             }
 }
 
+namespace {
+// per (device, board size): the tile-row map and the halo-row list, built once
+struct Tables {
+    int *rowmap = nullptr;
+    unsigned short *halo = nullptr;
+    int n_halo = 0;
+};
+std::mutex g_tables_mutex;
+std::map<std::tuple<int, int, int>, Tables> g_tables;
+
+const Tables &tables_for(int dev, int h, int w) {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    auto key = std::make_tuple(dev, h, w);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return it->second;
+    const Geometry g = geometry(h, w);
+    std::vector<int> rowmap(ROWS, -1);
+    for (int r = 0; r < ROWS; r++) {
+        const int mt = r / 16, b = mt / g.tpb, q = (mt - b * g.tpb) * 16 + r % 16;
+        if (b < g.bpw && q < h * w) rowmap[r] = b << 20 | q << 10 | (b * g.rpb + (q / w + 1) * g.pitch + q % w + 1);
+    }
+    std::vector<unsigned short> halo;
+    for (int b = 0; b < g.bpw; b++)
+        for (int idx = 0; idx < g.rpb; idx++)
+            if (idx < g.pitch || idx >= (h + 1) * g.pitch || idx % g.pitch == 0) halo.push_back((unsigned short)(b * g.rpb + idx));
+    Tables t;
+    t.n_halo = (int)halo.size();
+    (void)hipMalloc((void **)&t.rowmap, rowmap.size() * sizeof(int));
+    (void)hipMalloc((void **)&t.halo, halo.size() * sizeof(unsigned short));
+    (void)hipMemcpy(t.rowmap, rowmap.data(), rowmap.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(t.halo, halo.data(), halo.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+    return g_tables.emplace(key, t).first->second;
+}
+}  // namespace
+
 void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     BoardConvDev d;
     d.x = static_cast<const h16 *>(t.x);
@@ -408,8 +469,6 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.plane = geo.plane;
     d.cin = t.cin;
     d.relu = t.relu;
-    d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
-    d.inv_tpb = (65536u + (unsigned)d.tpb - 1) / (unsigned)d.tpb;
     static const int ablate = getenv("KZ_BC_ABLATE") ? atoi(getenv("KZ_BC_ABLATE")) : 0;
     d.ablate = ablate;
     d.groups = (t.boards + d.bpw - 1) / d.bpw;
@@ -417,6 +476,10 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    const Tables &tab = tables_for(dev, t.h, t.w);
+    d.rowmap = tab.rowmap;
+    d.halo = tab.halo;
+    d.n_halo = tab.n_halo;
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done_mask |= 1ull << (dev & 63);

@@ -43,3 +43,13 @@ if gaps:
     print("CU slots seen:", len(groups), "workgroups per slot mean:", np.mean(per))
     print("gap between consecutive workgroups on a CU slot: mean %.0f p10 %.0f p50 %.0f p90 %.0f" %
           (gaps.mean(), np.percentile(gaps, 10), np.percentile(gaps, 50), np.percentile(gaps, 90)))
+
+# ---- finer set-up stamps (21..24), when present ----
+if (d[:, :, 21] > 0).all():
+    pn = ["start->ring issued", "zero fill", "slot table", "T0"]
+    seq = [0, 21, 22, 23, 24]
+    for k in range(4):
+        seg = d[:, :, seq[k + 1]] - d[:, :, seq[k]]
+        print(f"  set-up: {pn[k]:20s} mean {seg.mean():7.0f}")
+    seg = d[:, :, 1] - d[:, :, 24]
+    print(f"  set-up: {'acc init':20s} mean {seg.mean():7.0f}")
