@@ -41,8 +41,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int MT = 24;                 // 16-row tiles per workgroup
-constexpr int MTW = MT / 4;            // tiles per wave (row quarter)
-constexpr int NTW = 4;                 // 16-channel output tiles per wave: all 64 channels of the workgroup
+#ifndef KZ_BC_NTW
+#define KZ_BC_NTW 4
+#endif
+constexpr int NTW = KZ_BC_NTW;         // 16-channel output tiles per wave: 4 = all 64 channels of the workgroup x a
+                                       // row quarter (6 tiles); 2 = 32 channels x a row half (12 tiles)
+constexpr int MTW = MT / NTW;          // tiles per wave (there are NTW row groups)
 constexpr int ROWS = MT * 16;          // 384
 constexpr int OCW = 64;                // output channels per workgroup
 constexpr int CH = 64;                 // input channels per staged chunk
@@ -50,7 +54,10 @@ constexpr int PRS = 32 * 2 + 16;       // plane row stride: 32 channels + 16 B p
 constexpr int LDS_MAX = 80 * 1024;     // two workgroups per CU
 constexpr int ORS = OCW * 2 + 16;      // row stride of the epilogue's output tile
 constexpr int KPC = 18;                // k-steps (32 channels of one tap) per chunk: 9 taps x 2
-constexpr int PF = 3;                  // weight ring depth in k-steps (a k-step is 24 MFMAs = 384 cycles per wave)
+#ifndef KZ_BC_PF
+#define KZ_BC_PF 3
+#endif
+constexpr int PF = KZ_BC_PF;           // weight ring depth in k-steps (a k-step is 24 MFMAs = 384 cycles per wave)
 static_assert(KPC % PF == 0, "ring stage of a k-step must not depend on the chunk");
 
 // fragment read from an integer LDS byte address (the dynamic LDS block starts at 0; going through the `lds` symbol
@@ -103,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave;  // row quarter: a wave owns 6 tiles x all 64 output channels, so an activation fragment
-                          // feeds 4 MFMAs (LDS bandwidth was the k-loop's co-bottleneck at 2) and a weight fragment 6
+    // wave = (output-channel group wo) x (row group wr): an activation fragment feeds NTW MFMAs, a weight fragment MTW
+    const int wo = wave % (4 / NTW), wr = wave / (4 / NTW);
     const int lane = tid & 63;
     const int fr = lane & 15, kq = lane >> 4;
     // XCD-aware order: consecutive workgroup ids go to consecutive XCDs, so id = (slot, xcd); the nq channel quarters of
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     for (int s = 0; s < PF; s++) {
         const int g = s < total_ksteps ? s : total_ksteps - 1;
 #pragma unroll
-        for (int nt = 0; nt < NTW; nt++) wreg[s][nt] = wp[(size_t)g * 256 + nt * 64];
+        for (int nt = 0; nt < NTW; nt++) wreg[s][nt] = wp[(size_t)g * 256 + (wo * NTW + nt) * 64];
     }
     int g = 0;
 
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     KZ_STAMP(24);
     f32x4 acc[NTW][MTW];
     {
-        const int oc = nquarter * OCW + kq * 4;
+        const int oc = nquarter * OCW + wo * NTW * 16 + kq * 4;
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + oc + nt * 16);
@@ -243,6 +250,28 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         tap_rows(0, 0, MTW, pitch_prs, T);
 #pragma unroll
         for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i]);
+#ifdef KZ_BC_SIMPLE  // debugging aid: the same k-loop without the half-step software pipelining
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            tap_rows(tap, 0, MTW, pitch_prs, T);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int stage = (tap * 2 + ks) % PF;
+#pragma unroll
+                for (int i = 0; i < MTW; i++) {
+                    const h16x8 bf = lds_frag(T[i] + ks * 32);
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++)
+                        acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h16x8 *>(&wreg[stage][nt]),
+                                                                            bf, acc[nt][i], 0, 0, 0);
+                }
+                const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)gn * 256 + (wo * NTW + nt) * 64];
+                g++;
+            }
+        }
+#else
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int next_tap = tap < 8 ? tap + 1 : 8;
@@ -288,13 +317,14 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                 {   // this stage's fragments have been issued to the MFMAs: refill it for k-step g + PF
                     const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
 #pragma unroll
-                    for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)gn * 256 + nt * 64];
+                    for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)gn * 256 + (wo * NTW + nt) * 64];
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
         }
+#endif
         KZ_STAMP(5 + chunk * 4);
     }
 
@@ -315,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
             const int off = valid ? (((board0 + (e >> 20)) * a.hw + ((e >> 10) & 1023)) * a.ld + kq * 4) * 2 : -1;
 #pragma unroll
             for (int nt = 0; nt < NTW; nt++)
-                resv[nt][i] = __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, (nquarter * OCW + nt * 16) * 2, 0);
+                resv[nt][i] = __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, (nquarter * OCW + (wo * NTW + nt) * 16) * 2, 0);
         }
     }
     __syncthreads();  // every wave is done with the last chunk's fragments
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
-        const int ocl = nt * 16 + kq * 4;  // within this workgroup's 64 channels
+        const int ocl = (wo * NTW + nt) * 16 + kq * 4;  // within this workgroup's 64 channels
         f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.post_scale) {
             ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nquarter * OCW + ocl);
@@ -398,7 +428,7 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
         for (int chunk = 0; chunk < chunks; chunk++)
             for (int tap = 0; tap < 9; tap++)
                 for (int ks = 0; ks < 2; ks++)
-                    for (int nt = 0; nt < NTW; nt++)
+                    for (int nt = 0; nt < OCW / 16; nt++)
                         for (int lane = 0; lane < 64; lane++)
                             for (int j = 0; j < 8; j++) {
                                 const int kq = lane >> 4;
