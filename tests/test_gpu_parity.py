@@ -479,6 +479,34 @@ def test_board_conv_agrees_with_implicit_gemm(dev, game, channels, head, batch):
     assert np.abs(sg - s).max() < F16_PATHS_ATOL and np.abs(pg - p).max() < F16_PATHS_ATOL
 
 
+@pytest.mark.parametrize("nb", ["1", "2"])
+def test_resident_f16_agrees_with_per_layer_paths(dev, nb):
+    """The one-launch chess kernel (1 and 2 boards per workgroup) against the per-layer implicit-GEMM path of the same
+    engine on a 2-block net: same operands and rounding points, so they agree to summation order — a bound 50x tighter
+    than the f16-vs-oracle tolerance."""
+    blob = synth.random_model("chess", 2, 256, "attention", seed=81)
+    bits, scalars_in = synth.random_boards("chess", 37, seed=82)
+    model = capi.Model(blob=blob)
+    os.environ["KZ_TOWER_NB"] = nb
+    try:
+        eng = capi.Engine(model, dev, 64, capi.KZ_DTYPE_F16)
+        s, p = eng.eval_packed(bits, scalars_in)
+    finally:
+        del os.environ["KZ_TOWER_NB"]
+    assert eng.tower_path == "tower_resident_f16+heads"
+    os.environ["KZ_FORCE_GENERIC"] = "1"
+    os.environ["KZ_NO_BOARD_CONV"] = "1"
+    try:
+        gen = capi.Engine(model, dev, 64, capi.KZ_DTYPE_F16)
+    finally:
+        del os.environ["KZ_FORCE_GENERIC"], os.environ["KZ_NO_BOARD_CONV"]
+    assert gen.tower_path == "conv_igemm_f16"
+    sg, pg = gen.eval_packed(bits, scalars_in)
+    ds, dp = np.abs(sg - s).max(), np.abs(pg - p).max()
+    print(f"resident (NB={nb}) vs implicit GEMM f16: max |d scalars| {ds:.2e}, max |d policy| {dp:.2e}")
+    assert ds < F16_PATHS_ATOL and dp < F16_PATHS_ATOL
+
+
 def test_profiling_reports_kernel_time(dev):
     blob = O.load_blob("ataxx7_4x64")
     net = O.OracleNet(blob)
