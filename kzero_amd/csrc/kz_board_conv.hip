@@ -22,9 +22,6 @@
 //               image is read from HBM once and from that XCD's L2 by the others.
 #include <cstdio>
 #include <cstdlib>
-#include <map>
-#include <mutex>
-#include <tuple>
 #include <vector>
 #include <type_traits>
 
@@ -441,40 +438,20 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
                             }
 }
 
-namespace {
-// per (device, board size): the tile-row map and the halo-row list, built once
-struct Tables {
-    int *rowmap = nullptr;
-    unsigned short *halo = nullptr;
-    int n_halo = 0;
-};
-std::mutex g_tables_mutex;
-std::map<std::tuple<int, int, int>, Tables> g_tables;
-
-const Tables &tables_for(int dev, int h, int w) {
-    std::lock_guard<std::mutex> lock(g_tables_mutex);
-    auto key = std::make_tuple(dev, h, w);
-    auto it = g_tables.find(key);
-    if (it != g_tables.end()) return it->second;
+// The tile-row map ([384]: board << 20 | pixel << 10 | image row, or -1 for a padding row) and the list of halo rows of a
+// workgroup's image; the engine uploads them next to the weights and passes them in BoardConvArgs.
+void board_conv_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo) {
     const Geometry g = geometry(h, w);
-    std::vector<int> rowmap(ROWS, -1);
+    rowmap.assign(ROWS, -1);
     for (int r = 0; r < ROWS; r++) {
         const int mt = r / 16, b = mt / g.tpb, q = (mt - b * g.tpb) * 16 + r % 16;
         if (b < g.bpw && q < h * w) rowmap[r] = b << 20 | q << 10 | (b * g.rpb + (q / w + 1) * g.pitch + q % w + 1);
     }
-    std::vector<unsigned short> halo;
+    halo.clear();
     for (int b = 0; b < g.bpw; b++)
         for (int idx = 0; idx < g.rpb; idx++)
             if (idx < g.pitch || idx >= (h + 1) * g.pitch || idx % g.pitch == 0) halo.push_back((unsigned short)(b * g.rpb + idx));
-    Tables t;
-    t.n_halo = (int)halo.size();
-    (void)hipMalloc((void **)&t.rowmap, rowmap.size() * sizeof(int));
-    (void)hipMalloc((void **)&t.halo, halo.size() * sizeof(unsigned short));
-    (void)hipMemcpy(t.rowmap, rowmap.data(), rowmap.size() * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMemcpy(t.halo, halo.data(), halo.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-    return g_tables.emplace(key, t).first->second;
 }
-}  // namespace
 
 void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     BoardConvDev d;
@@ -506,10 +483,9 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const Tables &tab = tables_for(dev, t.h, t.w);
-    d.rowmap = tab.rowmap;
-    d.halo = tab.halo;
-    d.n_halo = tab.n_halo;
+    d.rowmap = t.rowmap;
+    d.halo = t.halo;
+    d.n_halo = t.n_halo;
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done_mask |= 1ull << (dev & 63);

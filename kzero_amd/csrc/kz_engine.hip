@@ -175,6 +175,9 @@ struct DeviceWeights {
     }
 
     bool use_board_conv = false;
+    int *bc_rowmap = nullptr;  // kz_board_conv_f16's tile-row map and halo-row list for this board size
+    unsigned short *bc_halo = nullptr;
+    int bc_n_halo = 0;
     int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32) {
         resident32 = want_resident32;
         const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
@@ -224,6 +227,14 @@ struct DeviceWeights {
         } else {
             tower.resize(m.tower.size());
             const char *noboard = getenv("KZ_NO_BOARD_CONV");
+            if (use_board_conv && !(noboard && noboard[0] == '1')) {
+                std::vector<int> rowmap;
+                std::vector<unsigned short> halo;
+                kz::board_conv_tables(m.h, m.w, rowmap, halo);
+                bc_n_halo = (int)halo.size();
+                if (upload(rowmap.data(), rowmap.size() * sizeof(int), (void **)&bc_rowmap)) return 1;
+                if (upload(halo.data(), halo.size() * sizeof(unsigned short), (void **)&bc_halo)) return 1;
+            }
             for (size_t i = 0; i < m.tower.size(); i++) {
                 const bool board = use_board_conv && !(noboard && noboard[0] == '1') &&
                                    kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
@@ -401,6 +412,7 @@ struct kz_engine {
             b.post_scale = post ? wts->post_scale : nullptr;
             b.post_shift = post ? wts->post_shift : nullptr;
             b.boards = M / (h * wd); b.h = h; b.w = wd; b.cin = w.cin_p; b.cout = w.cout; b.relu = relu;
+            b.rowmap = wts->bc_rowmap; b.halo = wts->bc_halo; b.n_halo = wts->bc_n_halo;
             prof.begin("kz_board_conv_f16", stream);
             kz::launch_board_conv(b, stream);
             prof.end(stream);

@@ -2,6 +2,7 @@
 // All activations are NHWC with the channel dimension padded to a multiple of 32 ("Cp"): row = one board
 // square (pixel), columns = channels.  T is float (KZ_DTYPE_F32) or _Float16 (KZ_DTYPE_F16).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -107,11 +108,15 @@ struct BoardConvArgs {
     const void *res; // optional, [boards*h*w][ldy]
     void *y;
     int ldy, boards, h, w, cin, cout, relu;
+    const int *rowmap;            // board_conv_tables, uploaded by the caller
+    const unsigned short *halo;
+    int n_halo;
 };
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout);
 int board_conv_workgroups(int boards, int h, int w, int cout);  // grid size: 64 output channels per workgroup
 size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
+void board_conv_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo);
 void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);
 
 // ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----
