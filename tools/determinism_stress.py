@@ -1,0 +1,23 @@
+"""Race screen: every kernel path, many evaluations of the same batch, bitwise-identical outputs expected."""
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kzero_amd import capi, synth
+CASES = [("chess", 20, 256, "attention", 256, capi.KZ_DTYPE_F16, 200),
+         ("chess", 4, 256, "attention", 256, capi.KZ_DTYPE_F32, 50),
+         ("ataxx-7", 8, 128, "ataxx_conv", 256, capi.KZ_DTYPE_F32, 200),
+         ("go-19", 4, 256, "conv", 512, capi.KZ_DTYPE_F16, 50),
+         ("go-9", 4, 128, "conv", 512, capi.KZ_DTYPE_F16, 100)]
+bad = 0
+for game, depth, ch, head, batch, dtype, reps in CASES:
+    blob = synth.random_model(game, depth, ch, head, seed=9)
+    bits, sc = synth.random_boards(game, batch, seed=10)
+    engines = [capi.Engine(capi.Model(blob=blob), 0, batch, dtype) for _ in range(2)]
+    s0, p0 = engines[0].eval_packed(bits, sc)
+    n_bad = 0
+    for r in range(reps):
+        s, p = engines[r % 2].eval_packed(bits, sc)
+        if not (np.array_equal(s, s0) and np.array_equal(p, p0)):
+            n_bad += 1
+    print(f"{game} {depth}x{ch} {'f16' if dtype == capi.KZ_DTYPE_F16 else 'f32'} path={engines[0].tower_path}: {n_bad} of {reps} differ")
+    bad += n_bad
+sys.exit(1 if bad else 0)
