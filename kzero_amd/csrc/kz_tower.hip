@@ -16,6 +16,9 @@
 //    ds_write_b64.  im2col exists only as LDS addressing: a tap outside the board reads an all-zero row.
 //  * LDS image: row = pixel, 512 B of channels + 16 B pad (row stride 528 B), and a k-step's channel assignment is
 //    permuted so that every ds_read_b128 fragment read is bank-conflict-free (see frag_base below).
+//  * Two boards per workgroup: an MFMA pixel tile is line y of board 0 + line y of board 1, so the taps that fall off
+//    the top / bottom edge hit a WHOLE tile (dy = -1: tile 0, dy = +1: tile 7) and those MFMAs are not issued: 8.3 % of
+//    a direct convolution's multiply-adds are multiplications by the zero padding.
 //  * Heads (post_act.py:10-23, 115-141) run on the LDS-resident tower output: conv_under and conv_bulk are more passes
 //    of the same weight stream, q_from^T q_to is MFMA on LDS operands, the 1880-entry gather and the scalar head write
 //    the only HBM output of the launch (7.5 KB per board).
@@ -63,9 +66,20 @@ template <int NB>
 struct Layout {
     static constexpr int M = NB * 64;
     static constexpr int MT = M / 16;
+    // Tile -> pixel rows.  NB == 1: tile mt = board lines 2mt, 2mt+1.  NB == 2: tile mt = line mt of board 0 (lanes
+    // fr < 8) and line mt of board 1 (fr >= 8): a tap with dy = -1 then reads ONLY padding in tile 0 and dy = +1 only
+    // padding in tile 7, and those MFMAs are simply not issued — 6 of the 72 (tap, tile) pairs, 8.3 % of the direct
+    // convolution's multiply-adds are multiplications by the zero padding.
+    static constexpr bool LINE_TILES = NB == 2;
+    static constexpr int BPAD = LINE_TILES ? 128 : 0;   // board 1's image starts 8 sixteen-byte slots later, so that the
+                                                        // 16 rows of a line tile still fall on 16 different slots
+    static constexpr int BOARD = 64 * RS + BPAD;        // bytes from a board's image to the next one's
+    static constexpr int TS = LINE_TILES ? 8 * RS : 16 * RS;  // bytes from a tile's rows to the next tile's
+    static constexpr int IMG = NB * BOARD;
     static constexpr int X_OFF = 0;
-    static constexpr int Y_OFF = M * RS;
-    static constexpr int Z_OFF = 2 * M * RS;        // 16 all-zero rows (what a tap outside the board reads)
+    static constexpr int Y_OFF = IMG;
+    static constexpr int Z_OFF = 2 * IMG;           // 16 all-zero rows (what a tap outside the board reads)
+    static_assert(Z_OFF % 256 == 0, "zero rows keep the slot pattern of the image rows");
     static constexpr int S_OFF = Z_OFF + 16 * RS;   // stem input, rows of 64 B (32 channels)
     static constexpr int TOWER_BYTES = S_OFF + M * 64;
     // heads phase (the zero rows and the stem input are dead by then)
@@ -75,7 +89,9 @@ struct Layout {
     static constexpr int HEADS_BYTES = HID_OFF + NB * 32 * 4;
     static constexpr int LOG_OFF = Y_OFF;           // attention logits [NB][64][96] f32 (after q_from is consumed)
     static constexpr int BYTES = TOWER_BYTES > HEADS_BYTES ? TOWER_BYTES : HEADS_BYTES;
-    static_assert(NB * 64 * LOGIT_LD * 4 <= M * RS, "logits fit the Y region");
+    static_assert(NB * 64 * LOGIT_LD * 4 <= IMG, "logits fit the Y region");
+    // byte offset of pixel row p of board b within an image
+    static constexpr int row_off(int b, int p) { return b * BOARD + p * RS; }
     static_assert(BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -112,12 +128,14 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     int g = 0;  // global k-step index into the weight stream
     // take this k-step's fragments out of ring stage `stage` and refill the stage with k-step g + PF (clamped at the
     // end of the stream; the surplus loads are never used)
-    auto ring_take = [&](int stage, h16x8 (&af)[4]) {
+    auto ring_take = [&](int stage, h16x8 (&af)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
+#ifndef KZ_TW_NO_WLOAD  // (timing experiments: a build without the weight stream)
         const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) wreg[stage][nt] = wp[(size_t)gn * 1024 + nt * 64];
+#endif
     };
 
     // ---- zero rows and stem input ----
@@ -160,13 +178,13 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     // the weight prefetch ring once per layer.
     f32x4 acc[4][MT];
     f32x4 bias_next[4];
-    auto fetch_bias = [&](int row) {
+    auto fetch_bias = [&](int row) __attribute__((always_inline)) {
         const int l = row <= bias_rows ? row : bias_rows;
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
             bias_next[nt] = *reinterpret_cast<const f32x4 *>(a.bias + l * C + wave * 64 + nt * 16 + kq * 4);
     };
-    auto init_acc = [&]() {
+    auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
 #pragma unroll
@@ -189,21 +207,23 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     };
     auto to_h4 = [](f32x4 v) { return h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]}; };
 
-    // this lane's slice of the LDS image: pixel row fr of tile 0, channels [64*wave + 4*kq, +4) of oc-tile 0
-    const int epi_base = fr * RS + (wave * 64 + kq * 4) * 2;
+    // this lane's pixel row of tile 0 (byte offset in an image; tile mt is mt * L::TS further)
+    const int lane_row = L::LINE_TILES ? (fr >> 3) * L::BOARD + (fr & 7) * RS : fr * RS;
+    // this lane's slice of the LDS image: its pixel row of tile 0, channels [64*wave + 4*kq, +4) of oc-tile 0
+    const int epi_base = lane_row + (wave * 64 + kq * 4) * 2;
     // epilogue: [relu]; [+ residual X]; [final BN]; -> f16 -> LDS image at dst_off.  Flags are compile-time.
-    auto epilogue = [&](int dst_off, auto relu, auto residual, auto post) {
+    auto epilogue = [&](int dst_off, auto relu, auto residual, auto post) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
             h16x4 rx[MT];
             if constexpr (decltype(residual)::value) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
-                    rx[mt] = *reinterpret_cast<const h16x4 *>(lds + L::X_OFF + epi_base + mt * 16 * RS + nt * 32);
+                    rx[mt] = *reinterpret_cast<const h16x4 *>(lds + L::X_OFF + epi_base + mt * L::TS + nt * 32);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                const int off = epi_base + mt * 16 * RS + nt * 32;
+                const int off = epi_base + mt * L::TS + nt * 32;
                 f32x4 v = acc[nt][mt];
                 if constexpr (decltype(relu)::value) v = relu4(v);
                 if constexpr (decltype(residual)::value) {
@@ -218,9 +238,15 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     constexpr std::true_type YES{};
     constexpr std::false_type NO{};
 
-    // tap validity per lane: the pixel of tile row fr is (y = 2*(mt&3) + (fr>>3), x = fr&7); these four lane masks
-    // combined with the (wave-uniform) tap give the invalid lanes without any per-lane arithmetic
+    // tap validity per lane.  NB == 1: the pixel of tile row fr is (y = 2*(mt&3) + (fr>>3), x = fr&7); these four lane
+    // masks combined with the (wave-uniform) tap give the invalid lanes without any per-lane arithmetic.  Line tiles
+    // (NB == 2): (y = mt, x = fr&7): only the x masks are per lane, a tile outside the board in y is skipped whole.
     const bool x_is0 = (lane & 7) == 0, x_is7 = (lane & 7) == 7, yo_is0 = (lane & 8) == 0, yo_is1 = !yo_is0;
+    auto tap_ok = [&](int mt, int dy, int dx) __attribute__((always_inline)) {
+        const bool kill_x = (dx < 0 && x_is0) || (dx > 0 && x_is7);
+        if constexpr (L::LINE_TILES) return !(kill_x || (dy < 0 && mt == 0) || (dy > 0 && mt == MT - 1));
+        else return !(kill_x || ((mt & 3) == 0 && dy < 0 && yo_is0) || ((mt & 3) == 3 && dy > 0 && yo_is1));
+    };
 
     // ---- stem: 9 k-steps over the 32 (padded) input channels; conv + bias, no activation (post_act.py:205) ----
     fetch_bias(0);
@@ -234,12 +260,10 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
             const uint4 t = a.w_stem[((tap * 4 + wave) * 4 + nt) * 64 + lane];
             af[nt] = *reinterpret_cast<const h16x8 *>(&t);
         }
-        const bool kill_x = (dx < 0 && x_is0) || (dx > 0 && x_is7);
-        const bool kill_top = dy < 0 && yo_is0, kill_bot = dy > 0 && yo_is1;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const bool ok = !(kill_x || ((mt & 3) == 0 && kill_top) || ((mt & 3) == 3 && kill_bot));
-            const int p = mt * 16 + fr;
+            const bool ok = tap_ok(mt, dy, dx);
+            const int p = L::LINE_TILES ? (fr >> 3) * 64 + mt * 8 + (fr & 7) : mt * 16 + fr;  // row of the stem input
             const int off = ok ? L::S_OFF + (p + dy * 8 + dx) * 64 + kq * 16 : L::Z_OFF + kq * 16;  // stem: natural k
             const h16x8 bf = *reinterpret_cast<const h16x8 *>(lds + off);
 #pragma unroll
@@ -259,50 +283,59 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     // long as the weights are packed with the same assignment: tower_pack_weights.)  Lanes whose tap falls outside the
     // board read zero row (q & 15), which keeps the same slot pattern.
     const int kq_off = 256 * (kq & 1) + 128 * (kq >> 1);
-    const int frag_base = fr * RS + kq_off;
-    auto tap_rows = [&](int tap, int src_off, int (&T)[MT]) {
+    const int frag_base = lane_row + kq_off;
+    auto tap_rows = [&](int tap, int src_off, int (&T)[MT]) __attribute__((always_inline)) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const bool kill_x = (dx < 0 && x_is0) || (dx > 0 && x_is7);
-        const bool kill_top = dy < 0 && yo_is0, kill_bot = dy > 0 && yo_is1;
         const int shifted = frag_base + src_off + (dy * 8 + dx) * RS;
+        // zero row with the slot of the row it stands in for: consecutive line tiles are 8 slots apart, so even and odd
+        // tiles differ by 8 rows
         const int zrow = L::Z_OFF + ((fr + dy * 8 + dx) & 15) * RS + kq_off;
+        const int zrow_odd = L::LINE_TILES ? L::Z_OFF + ((fr + dy * 8 + dx + 8) & 15) * RS + kq_off : zrow;
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const bool ok = !(kill_x || ((mt & 3) == 0 && kill_top) || ((mt & 3) == 3 && kill_bot));
-            T[mt] = ok ? shifted + mt * 16 * RS : zrow;
-        }
+        for (int mt = 0; mt < MT; mt++) T[mt] = tap_ok(mt, dy, dx) ? shifted + mt * L::TS : ((mt & 1) ? zrow_odd : zrow);
     };
 
-    // acc += sum over taps [tap_lo, tap_hi) and all 256 input channels of W * image(src_off): 8 k-steps per tap
-    auto conv_pass = [&](int src_off, int tap_lo, int tap_hi) {
+    // One line of taps: acc += sum over taps (DY, dx in [dx_lo, dx_hi)) and all 256 input channels of W * image(src_off),
+    // 8 k-steps per tap.  On entry bf[0] holds the fragments of the first k-step; the last k-step prefetches the first
+    // fragments of tap `tap_after` (what runs next) for ALL tiles.  With line tiles the tiles that DY puts outside the
+    // board are left out: no fragment read, no MFMA.
+    h16x8 bf[2][MT];  // activation fragments, double buffered one k-step ahead
+    auto conv_line = [&](auto dy_tag, int src_off, int dx_lo, int dx_hi, int tap_after) __attribute__((always_inline)) {
+        constexpr int DY = decltype(dy_tag)::value;
+        constexpr int LO = L::LINE_TILES && DY < 0 ? 1 : 0, HI = L::LINE_TILES && DY > 0 ? MT - 1 : MT, NT_ = HI - LO;
         int T[MT], Tn[MT];
-        h16x8 bf[2][MT];  // activation fragments, double buffered one k-step ahead
-        tap_rows(tap_lo, src_off, T);
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) bf[0][mt] = *reinterpret_cast<const h16x8 *>(lds + T[mt]);
-        for (int tap = tap_lo; tap < tap_hi; tap++) {
-            tap_rows(tap + 1 < tap_hi ? tap + 1 : tap, src_off, Tn);
+        tap_rows((DY + 1) * 3 + dx_lo + 1, src_off, T);
+#pragma nounroll
+        for (int dx = dx_lo; dx < dx_hi; dx++) {
+            tap_rows(dx + 1 < dx_hi ? (DY + 1) * 3 + dx + 2 : tap_after, src_off, Tn);
 #pragma unroll
             for (int ch = 0; ch < 8; ch++) {
                 const int stage = ch & (PF - 1), cur = ch & 1, nxt = cur ^ 1;
-                // next k-step's activation fragments: LDS -> registers (after the last tap this re-reads that tap,
-                // harmless and branch-free)
+                // next k-step's activation fragments: LDS -> registers
+#ifndef KZ_TW_NO_DSREAD  // (timing experiments: a build without the fragment reads)
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-                    bf[nxt][mt] = ch < 7 ? *reinterpret_cast<const h16x8 *>(lds + T[mt] + (ch + 1) * 16)
-                                         : *reinterpret_cast<const h16x8 *>(lds + Tn[mt]);
+                for (int mt = 0; mt < MT; mt++) {
+                    if (ch < 7) {
+                        if (mt >= LO && mt < HI) bf[nxt][mt] = *reinterpret_cast<const h16x8 *>(lds + T[mt] + (ch + 1) * 16);
+                    } else {
+                        bf[nxt][mt] = *reinterpret_cast<const h16x8 *>(lds + Tn[mt]);
+                    }
+                }
+#endif
                 // this k-step's weight fragments were loaded PF k-steps ago
                 h16x8 af[4];
                 ring_take(stage, af);
-                // 4 x MT MFMAs on independent accumulators
+                // 4 x NT_ MFMAs on independent accumulators
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++)
+                for (int mt = LO; mt < HI; mt++)
 #pragma unroll
                     for (int nt = 0; nt < 4; nt++)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[cur][mt], acc[nt][mt], 0, 0, 0);
                 // issue order: every memory instruction rides in the shadow of one MFMA — first the 4 ring refills,
-                // then the MT LDS fragment reads, then the remaining MFMAs back to back.  (Same-box A/B: +0.5 % over a
+                // then the LDS fragment reads, then the remaining MFMAs back to back.  (Same-box A/B: +0.5 % over a
                 // 2:1 interleave with the LDS reads first, +3 % over the compiler's own order.)
+                constexpr int NR_LAST = MT;
+                const int nr = ch < 7 ? NT_ : NR_LAST;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
@@ -310,16 +343,41 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 }
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+                    if (i < nr) {
+                        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+                    }
                 }
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4 * MT - (MT + 4), 0);
+                if (ch < 7) __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4 * NT_ - (NT_ + 4), 0);
+                else __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4 * NT_ - (NR_LAST + 4), 0);
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) T[mt] = Tn[mt];
         }
+    };
+    constexpr std::integral_constant<int, -1> DY_UP{};
+    constexpr std::integral_constant<int, 0> DY_MID{};
+    constexpr std::integral_constant<int, 1> DY_DOWN{};
+    // first fragments of a pass that starts at `tap`
+    auto conv_prime = [&](int src_off, int tap) __attribute__((always_inline)) {
+        int T[MT];
+        tap_rows(tap, src_off, T);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) bf[0][mt] = *reinterpret_cast<const h16x8 *>(lds + T[mt]);
+    };
+    // all nine taps
+    auto conv_3x3 = [&](int src_off) __attribute__((always_inline)) {
+        conv_prime(src_off, 0);
+        conv_line(DY_UP, src_off, -1, 2, 3);
+        conv_line(DY_MID, src_off, -1, 2, 6);
+        conv_line(DY_DOWN, src_off, -1, 2, 8);
+    };
+    // the centre tap only (1x1 convolutions of the heads)
+    auto conv_1x1 = [&](int src_off) __attribute__((always_inline)) {
+        conv_prime(src_off, 4);
+        conv_line(DY_MID, src_off, 0, 1, 4);
     };
 
     // ---- the 2*depth 3x3 convolutions ----
@@ -335,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 post_t[nt] = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
             }
         }
-        conv_pass(is_b ? L::Y_OFF : L::X_OFF, 0, 9);
+        conv_3x3(is_b ? L::Y_OFF : L::X_OFF);
         if (!is_b) epilogue(L::Y_OFF, YES, NO, NO);
         else if (layer != layers) epilogue(L::X_OFF, YES, YES, NO);
         else epilogue(L::X_OFF, YES, YES, YES);
@@ -348,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
             const int p = id >> 5, c16 = id & 31;
             const int board = board0 + (p >> 6);
             if (board < a.batch) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(lds + L::X_OFF + p * RS + c16 * 16);
+                const uint4 v = *reinterpret_cast<const uint4 *>(lds + L::X_OFF + L::row_off(p >> 6, p & 63) + c16 * 16);
                 *reinterpret_cast<uint4 *>(a.y + ((size_t)board0 * 64 + p) * C + c16 * 8) = v;
             }
         }
@@ -361,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
             float *act = reinterpret_cast<float *>(lds + L::ACT_OFF);
             for (int o = tid; o < NB * 256; o += 256) {
                 const int b = o >> 8, c4 = (o >> 6) & 3, p = o & 63;
-                const unsigned char *row = lds + L::X_OFF + (b * 64 + p) * RS;
+                const unsigned char *row = lds + L::X_OFF + L::row_off(b, p);
                 const float *w = a.sh_w0 + c4 * C;
                 float s = a.sh_b0[c4];
 #pragma unroll 4
@@ -379,8 +437,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         // The host permutes its output channels to s-major (oc' = 256*s + q for original channel 3q + s) so that
         // under.reshape(Q, 24)[q][8s + x] (post_act.py:134) is contiguous in q: row (b*8+x), bytes [512 s, 512 s + 512).
         {
-            const int urow = (NB == 2 ? (fr >> 3) * 64 : 0) + 56 + (fr & 7);
-            const int tb = L::X_OFF + urow * RS + kq_off;
+            const int tb = L::X_OFF + L::row_off(NB == 2 ? fr >> 3 : 0, 56 + (fr & 7)) + kq_off;
             for (int s = 0; s < 3; s++) {
                 f32x4 ua[4];
 #pragma unroll
@@ -408,13 +465,13 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         // ---- H3: conv_bulk channels [0, Q) = q_from: X -> Y
         init_acc();
         fetch_bias(layers + 5);
-        conv_pass(L::X_OFF, 4, 5);
+        conv_1x1(L::X_OFF);
         epilogue(L::Y_OFF, NO, NO, NO);
 
         // ---- H4: conv_bulk channels [Q, 2Q) = the 64 board squares of q_to: X -> X in place (every wave reads all of X
         // in its k-loop, so the writes wait for a barrier)
         init_acc();
-        conv_pass(L::X_OFF, 4, 5);
+        conv_1x1(L::X_OFF);
         __syncthreads();
         epilogue(L::X_OFF, NO, NO, NO);
         __syncthreads();
@@ -449,11 +506,11 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         {
             int ja[6], ia[IT];
 #pragma unroll
-            for (int jt = 0; jt < 4; jt++) ja[jt] = L::X_OFF + (hb * 64 + jt * 16 + fr) * RS + kq_off;
+            for (int jt = 0; jt < 4; jt++) ja[jt] = L::X_OFF + L::row_off(hb, jt * 16 + fr) + kq_off;
             ja[4] = L::U_OFF + (hb * 8 + (fr & 7)) * URS + (fr >> 3) * 512 + kq_off;  // t = fr: s = fr>>3 in {0,1}
             ja[5] = L::U_OFF + (hb * 8 + (fr & 7)) * URS + 2 * 512 + kq_off;          // t = 16 + fr: s = 2 (fr >= 8: pad)
 #pragma unroll
-            for (int ii = 0; ii < IT; ii++) ia[ii] = L::Y_OFF + (hb * 64 + (it0 + ii) * 16 + fr) * RS + kq_off;
+            for (int ii = 0; ii < IT; ii++) ia[ii] = L::Y_OFF + L::row_off(hb, (it0 + ii) * 16 + fr) + kq_off;
 #pragma unroll
             for (int ii = 0; ii < IT; ii++)
 #pragma unroll
