@@ -118,12 +118,13 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 
     // ---- weight stream: per k-step 16 KB = [wave 4][nt 4][lane 64] x 16 B; prime PF stages before anything else ----
     const uint4 *wp = a.w_tower + wave * 256 + lane;
+    auto wload = [&](int gk, int nt) __attribute__((always_inline)) { return wp[(size_t)gk * 1024 + nt * 64]; };
     uint4 wreg[PF][4];
 #pragma unroll
     for (int s = 0; s < PF; s++) {
         const int g = s < total_ksteps ? s : total_ksteps - 1;
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) wreg[s][nt] = wp[(size_t)g * 1024 + nt * 64];
+        for (int nt = 0; nt < 4; nt++) wreg[s][nt] = wload(g, nt);
     }
     int g = 0;  // global k-step index into the weight stream
     // take this k-step's fragments out of ring stage `stage` and refill the stage with k-step g + PF (clamped at the
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #ifndef KZ_TW_NO_WLOAD  // (timing experiments: a build without the weight stream)
         const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) wreg[stage][nt] = wp[(size_t)gn * 1024 + nt * 64];
+        for (int nt = 0; nt < 4; nt++) wreg[stage][nt] = wload(gn, nt);
 #endif
     };
 
