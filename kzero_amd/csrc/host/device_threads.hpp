@@ -23,14 +23,19 @@ struct StartupSettings {
     size_t gpu_threads_per_device = 2;
     size_t gpu_batch_size = 256;
     size_t search_batch_size = 16;
+    // not in the reference: batches each executor thread keeps in flight (1 = batched_executor_loop as it is;
+    // 2 = pipelined_executor_loop over the engine's two async slots)
+    size_t pipeline_depth = 1;
 };
 
 struct DeviceSizing {
     size_t concurrent_games, eval_job_count, job_buffer_size;
+    // a pipelined executor thread stands for `pipeline_depth` blocking ones
+    static size_t lanes(const StartupSettings &s) { return s.gpu_threads_per_device * (s.pipeline_depth ? s.pipeline_depth : 1); }
     explicit DeviceSizing(const StartupSettings &s)
-        : concurrent_games(ceil_div((s.gpu_threads_per_device + 1) * s.gpu_batch_size, s.search_batch_size)),  // :47
-          eval_job_count(s.gpu_batch_size / s.search_batch_size),                                              // :48
-          job_buffer_size(ceil_div(s.gpu_threads_per_device * s.gpu_batch_size, s.search_batch_size)) {}       // :55
+        : concurrent_games(ceil_div((lanes(s) + 1) * s.gpu_batch_size, s.search_batch_size)),  // :47
+          eval_job_count(s.gpu_batch_size / s.search_batch_size),                              // :48
+          job_buffer_size(ceil_div(lanes(s) * s.gpu_batch_size, s.search_batch_size)) {}       // :55
 };
 
 // Evals::new(real, potential, cached) (protocol.rs:52-72); `real`/s is the north-star metric (collector.rs:172-191)
@@ -71,17 +76,32 @@ std::unique_ptr<DeviceExecutors<B, M>> spawn_device_executors(int device, const 
         dev->graph_senders.push_back(gtx);
         dev->threads.emplace_back([=, srv = server, rx = std::move(grx)]() mutable {
             using Net = HipNetwork<B, M>;
-            batched_executor_loop<typename DeviceExecutors<B, M>::Graph, Net, B, ZeroEvaluation>(
-                gpu_batch_size, RunCondition::job_count(sizing.eval_job_count), std::move(rx), std::move(srv),
-                [=](typename DeviceExecutors<B, M>::Graph g) { return Net(mapper, std::move(g), gpu_batch_size, device, dtype); },
-                [=](Net &net, const B *x, size_t n) {
-                    auto y = net.evaluate_batch(x, n);
-                    if (counters) {
-                        counters->real += n;  // ExpandEvals(real = x.len(), potential = gpu_batch_size) (:113-115)
-                        counters->potential += gpu_batch_size;
-                    }
-                    return y;
-                });
+            using Graph = typename DeviceExecutors<B, M>::Graph;
+            auto load = [=](Graph g) { return Net(mapper, std::move(g), gpu_batch_size, device, dtype); };
+            auto count = [=](size_t n) {
+                if (counters) {
+                    counters->real += n;  // ExpandEvals(real = x.len(), potential = gpu_batch_size) (:113-115)
+                    counters->potential += gpu_batch_size;
+                }
+            };
+            const RunCondition cond = RunCondition::job_count(sizing.eval_job_count);
+            if (startup.pipeline_depth <= 1) {
+                batched_executor_loop<Graph, Net, B, ZeroEvaluation>(
+                    gpu_batch_size, cond, std::move(rx), std::move(srv), load, [=](Net &net, const B *x, size_t n) {
+                        auto y = net.evaluate_batch(x, n);
+                        count(n);
+                        return y;
+                    });
+            } else {
+                pipelined_executor_loop<Graph, Net, B, ZeroEvaluation>(
+                    gpu_batch_size, std::min(startup.pipeline_depth, Net::max_in_flight()), cond, std::move(rx),
+                    std::move(srv), load, [](Net &net, const B *x, size_t n) { net.submit_batch(x, n); },
+                    [=](Net &net) {
+                        auto y = net.wait_batch();
+                        count(y.size());
+                        return y;
+                    });
+            }
         });
     }
     return dev;

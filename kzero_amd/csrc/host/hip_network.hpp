@@ -44,6 +44,22 @@ class HipNetwork : public Network<B> {
     size_t max_batch_size_;
     std::vector<uint8_t> bits_;
     std::vector<float> scalars_in_, scalars_out_, policy_out_;
+    // asynchronous pair: the boards of every batch in flight (decode_output needs their legal moves), oldest first
+    std::vector<B> pending_boards_[KZ_ENGINE_SLOTS];
+    int next_slot_ = 0, oldest_slot_ = 0, in_flight_ = 0;
+
+    size_t encode_into_staging(const B *boards, size_t n) {
+        const size_t bool_count = input_bool_len(mapper_), bits_bytes = (bool_count + 7) / 8;
+        scalars_in_.clear();
+        BitBuffer buffer(bool_count);
+        for (size_t bi = 0; bi < n; bi++) {
+            buffer.clear();
+            mapper_.encode_input(buffer, scalars_in_, boards[bi]);
+            if (buffer.len() != bool_count) throw std::logic_error("mapper wrote the wrong number of bools");
+            std::copy(buffer.storage().begin(), buffer.storage().begin() + bits_bytes, bits_.begin() + bi * bits_bytes);
+        }
+        return bits_bytes;
+    }
 
   public:
     // cudnn.rs:29-43 (check_graph_shapes: common.rs:165-198)
@@ -64,7 +80,9 @@ class HipNetwork : public Network<B> {
     HipNetwork(HipNetwork &&o) noexcept
         : mapper_(o.mapper_), model_(std::move(o.model_)), engine_(o.engine_), max_batch_size_(o.max_batch_size_),
           bits_(std::move(o.bits_)), scalars_in_(std::move(o.scalars_in_)), scalars_out_(std::move(o.scalars_out_)),
-          policy_out_(std::move(o.policy_out_)) {
+          policy_out_(std::move(o.policy_out_)), next_slot_(o.next_slot_), oldest_slot_(o.oldest_slot_),
+          in_flight_(o.in_flight_) {
+        for (int i = 0; i < KZ_ENGINE_SLOTS; i++) pending_boards_[i] = std::move(o.pending_boards_[i]);
         o.engine_ = nullptr;
     }
     HipNetwork(const HipNetwork &) = delete;
@@ -76,18 +94,38 @@ class HipNetwork : public Network<B> {
     std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
         if (n > max_batch_size_) throw std::invalid_argument("batch_size <= max_batch_size");  // assert!, :58
         if (n == 0) return {};
-        const size_t bool_count = input_bool_len(mapper_), bits_bytes = (bool_count + 7) / 8;
-        scalars_in_.clear();
-        BitBuffer buffer(bool_count);
-        for (size_t bi = 0; bi < n; bi++) {
-            buffer.clear();
-            mapper_.encode_input(buffer, scalars_in_, boards[bi]);
-            if (buffer.len() != bool_count) throw std::logic_error("mapper wrote the wrong number of bools");
-            std::copy(buffer.storage().begin(), buffer.storage().begin() + bits_bytes, bits_.begin() + bi * bits_bytes);
-        }
+        if (in_flight_ != 0) throw std::logic_error("evaluate_batch while submitted batches are in flight");
+        const size_t bits_bytes = encode_into_staging(boards, n);
         kz_check(kz_engine_eval_packed(engine_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n, scalars_out_.data(),
                                        policy_out_.data()));
         return decode_output(mapper_, boards, n, scalars_out_.data(), policy_out_.data());
+    }
+
+    // ---- asynchronous pair for pipelined_executor_loop (kz_engine_submit_packed / kz_engine_wait) ----
+    static constexpr size_t max_in_flight() { return KZ_ENGINE_SLOTS; }
+    size_t batches_in_flight() const { return (size_t)in_flight_; }
+
+    // encode + hand the batch to the engine; returns while the GPU works.  `boards` is not retained.
+    void submit_batch(const B *boards, size_t n) {
+        if (n == 0 || n > max_batch_size_) throw std::invalid_argument("0 < batch_size <= max_batch_size");
+        if (in_flight_ == KZ_ENGINE_SLOTS) throw std::logic_error("every engine slot is in flight");
+        const size_t bits_bytes = encode_into_staging(boards, n);
+        // the engine copies bits and scalars to its pinned staging before this returns (include/kz_hip.h)
+        kz_check(kz_engine_submit_packed(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
+        pending_boards_[next_slot_].assign(boards, boards + n);
+        next_slot_ = (next_slot_ + 1) % KZ_ENGINE_SLOTS;
+        in_flight_++;
+    }
+
+    // results of the OLDEST submitted batch
+    std::vector<ZeroEvaluation> wait_batch() {
+        if (in_flight_ == 0) throw std::logic_error("wait_batch with nothing in flight");
+        const int slot = oldest_slot_;
+        kz_check(kz_engine_wait(engine_, slot, scalars_out_.data(), policy_out_.data()));
+        oldest_slot_ = (oldest_slot_ + 1) % KZ_ENGINE_SLOTS;
+        in_flight_--;
+        const std::vector<B> &boards = pending_boards_[slot];
+        return decode_output(mapper_, boards.data(), boards.size(), scalars_out_.data(), policy_out_.data());
     }
 };
 

@@ -165,6 +165,51 @@ int main(int argc, char **argv) {
     graph_senders.clear();
     for (auto &e : executors) e.join();
 
+    // 2b. ONE executor thread with two batches in flight (pipelined_executor_loop over kz_engine_submit_packed /
+    //     kz_engine_wait): same answers, replies in job order, hot swap with work in flight
+    {
+        // the asynchronous pair alone: two submits, two waits, oldest first
+        Net net(mapper, model_a, 8, 0, KZ_DTYPE_F32);
+        net.submit_batch(boards.data(), 3);
+        net.submit_batch(boards.data() + 3, boards.size() - 3);
+        CHECK(net.batches_in_flight() == 2);
+        bool threw = false;
+        try { net.submit_batch(boards.data(), 1); } catch (const std::logic_error &) { threw = true; }
+        CHECK(threw);  // both engine slots are out
+        auto y0 = net.wait_batch(), y1 = net.wait_batch();
+        CHECK(y0.size() == 3 && y1.size() == boards.size() - 3);
+        for (size_t i = 0; i < y0.size(); i++) CHECK(close_eval(y0[i], expect[i], 1e-4f));
+        for (size_t i = 0; i < y1.size(); i++) CHECK(close_eval(y1[i], expect[3 + i], 1e-4f));
+    }
+    {
+        auto [pclient, pserver] = job_pair<PackedBoard, ZeroEvaluation>(16);
+        auto [gtx, grx] = bounded<std::optional<std::shared_ptr<const HipModel>>>(1);
+        std::atomic<long> pevals{0};
+        std::thread exec([&, srv = std::move(pserver), rx = std::move(grx)]() mutable {
+            pipelined_executor_loop<std::shared_ptr<const HipModel>, Net, PackedBoard, ZeroEvaluation>(
+                16, 2, RunCondition::any(), std::move(rx), std::move(srv),
+                [&](std::shared_ptr<const HipModel> m) { return Net(mapper, std::move(m), 16, 0, KZ_DTYPE_F32); },
+                [](Net &net, const PackedBoard *x, size_t n) { net.submit_batch(x, n); },
+                [&](Net &net) {
+                    auto y = net.wait_batch();
+                    pevals += (long)y.size();
+                    return y;
+                });
+        });
+        gtx.send(model_a);
+        auto saved = client;
+        client = pclient;  // run_generators sends through `client`
+        CHECK(run_generators(boards, expect) == 0);
+        gtx.send(model_b);
+        std::this_thread::sleep_for(std::chrono::milliseconds(200));
+        CHECK(run_generators(boards_b, expect_b) == 0);
+        CHECK(pevals > 0);
+        client = saved;
+        pclient = JobClient<PackedBoard, ZeroEvaluation>();
+        gtx = Sender<std::optional<std::shared_ptr<const HipModel>>>();
+        exec.join();
+    }
+
     // 3. RandomSymmetryNetwork over HipNetwork on Ataxx positions: values are symmetric-invariant only for a trained
     //    net; what must hold exactly is that the wrapper un-maps the policy it got for the mapped board
     {

@@ -376,6 +376,127 @@ static void test_executor_exit_without_network() {
     CHECK(FakeNet::alive == 0);
 }
 
+// ---- pipelined_executor_loop: the same channel semantics with batches in flight ----
+// A fake asynchronous network: submit() queues the batch, a "device" delay passes, wait() hands back the OLDEST batch.
+struct FakeAsyncNet {
+    int id;
+    std::deque<std::pair<std::vector<int>, std::chrono::steady_clock::time_point>> q;
+    static std::atomic<int> alive, max_in_flight;
+    explicit FakeAsyncNet(int id) : id(id) { alive++; }
+    FakeAsyncNet(FakeAsyncNet &&o) noexcept : id(o.id), q(std::move(o.q)) { alive++; }
+    FakeAsyncNet(const FakeAsyncNet &) = delete;
+    ~FakeAsyncNet() {
+        if (!q.empty()) std::fprintf(stderr, "FAIL: network dropped with %zu batches in flight\n", q.size()), g_failed++;
+        alive--;
+    }
+    void submit(const int *x, size_t n) {
+        q.emplace_back(std::vector<int>(x, x + n), std::chrono::steady_clock::now() + std::chrono::milliseconds(2));
+        int cur = (int)q.size(), seen = max_in_flight.load();
+        while (cur > seen && !max_in_flight.compare_exchange_weak(seen, cur)) {}
+    }
+    std::vector<int> wait() {
+        auto [y, ready] = std::move(q.front());
+        q.pop_front();
+        std::this_thread::sleep_until(ready);
+        for (auto &v : y) v = v * 100 + id;
+        return y;
+    }
+};
+std::atomic<int> FakeAsyncNet::alive{0}, FakeAsyncNet::max_in_flight{0};
+
+static void test_pipelined_loop() {
+    auto [client, server] = job_pair<int, int>(16);
+    auto [gtx, grx] = bounded<std::optional<int>>(1);
+    Trace trace;
+    std::thread exec([&, srv = std::move(server), rx = std::move(grx)]() mutable {
+        pipelined_executor_loop<int, FakeAsyncNet, int, int>(
+            4, 2, RunCondition::any(), std::move(rx), std::move(srv), [](int g) { return FakeAsyncNet(g); },
+            [](FakeAsyncNet &n, const int *x, size_t len) { n.submit(x, len); }, [](FakeAsyncNet &n) { return n.wait(); },
+            &trace);
+    });
+    // no network yet: jobs wait in the channel
+    auto early = client.map({1, 2});
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    TryRecvError err;
+    CHECK(!early.try_recv(err));
+    gtx.send(7);
+    CHECK((*early.recv() == std::vector<int>{107, 207}));
+    // many clients with several requests outstanding each: replies in job order, each job answered exactly once, and
+    // the loop really keeps two batches in flight
+    std::vector<std::thread> gens;
+    std::atomic<int> wrong{0};
+    for (int t = 0; t < 4; t++)
+        gens.emplace_back([&, t, c = client] {
+            std::deque<std::pair<std::vector<int>, Receiver<std::vector<int>>>> out;
+            for (int i = 0; i < 200; i++) {
+                std::vector<int> x;
+                for (int k = 0; k <= (i + t) % 3; k++) x.push_back(t * 10000 + i * 4 + k);
+                out.emplace_back(x, c.map(x));
+                if (out.size() == 3 || i == 199) {
+                    while (!out.empty() && (out.size() == 3 || i == 199)) {
+                        auto y = out.front().second.recv();
+                        const auto &xs = out.front().first;
+                        if (!y || y->size() != xs.size()) wrong++;
+                        else
+                            for (size_t k = 0; k < xs.size(); k++)
+                                if ((*y)[k] != xs[k] * 100 + 7) wrong++;
+                        out.pop_front();
+                    }
+                }
+            }
+        });
+    for (auto &g : gens) g.join();
+    CHECK(wrong == 0);
+    CHECK(FakeAsyncNet::max_in_flight == 2);
+    for (size_t n : trace.batches) CHECK(n >= 1 && n <= 4);
+    // hot swap with work in flight: the old network answers what it was given, is dropped, then the new one is built
+    auto a = client.map({1, 2, 3, 4});
+    auto b = client.map({5, 6, 7, 8});
+    gtx.send(std::nullopt);
+    gtx.send(9);
+    auto ya = *a.recv(), yb = *b.recv();
+    CHECK(ya.size() == 4 && yb.size() == 4);
+    for (int v : ya) CHECK(v % 100 == 7 || v % 100 == 9);  // whichever network had it, one network per batch
+    CHECK((client.map_blocking({5, 6}) == std::vector<int>{509, 609}));
+    // disconnect with requests outstanding: everything queued is answered before the loop returns
+    auto c1 = client.map({11}), c2 = client.map({12, 13}), c3 = client.map({14});
+    client = JobClient<int, int>();
+    gtx = Sender<std::optional<int>>();
+    exec.join();
+    CHECK((*c1.recv() == std::vector<int>{1109}) && (*c2.recv() == std::vector<int>{1209, 1309}) &&
+          (*c3.recv() == std::vector<int>{1409}));
+    CHECK((trace.log == std::vector<std::string>{"load", "drop", "load"}));
+    CHECK(FakeAsyncNet::alive == 0);
+}
+
+// RunCondition::JobCount counts the jobs NOT yet handed to the network: with one batch in flight the next one still
+// waits for its own `count` jobs
+static void test_pipelined_job_count() {
+    auto [client, server] = job_pair<int, int>(16);
+    auto [gtx, grx] = bounded<std::optional<int>>(1);
+    Trace trace;
+    std::thread exec([&, srv = std::move(server), rx = std::move(grx)]() mutable {
+        pipelined_executor_loop<int, FakeAsyncNet, int, int>(
+            8, 2, RunCondition::job_count(2), std::move(rx), std::move(srv), [](int g) { return FakeAsyncNet(g); },
+            [](FakeAsyncNet &n, const int *x, size_t len) { n.submit(x, len); }, [](FakeAsyncNet &n) { return n.wait(); },
+            &trace);
+    });
+    gtx.send(1);
+    TryRecvError err;
+    auto a = client.map({1});
+    std::this_thread::sleep_for(std::chrono::milliseconds(30));
+    CHECK(!a.try_recv(err));  // one job < JobCount(2)
+    auto b = client.map({2, 3});
+    CHECK((*a.recv() == std::vector<int>{101}) && (*b.recv() == std::vector<int>{201, 301}));
+    auto c = client.map({4});
+    std::this_thread::sleep_for(std::chrono::milliseconds(30));
+    CHECK(!c.try_recv(err));  // again only one job pending
+    client = JobClient<int, int>();
+    exec.join();
+    CHECK((*c.recv() == std::vector<int>{401}));
+    CHECK((trace.batches == std::vector<size_t>{3, 1}));
+}
+
 // ---- symmetry: D4 tables of the reference + RandomSymmetryNetwork un-mapping ----
 struct CoordNet : Network<AtaxxSymBoard> {  // policy weight of a move depends on where it lands on the evaluated board
     size_t max_batch_size() const override { return 64; }
@@ -459,6 +580,8 @@ int main(int argc, char **argv) {
     std::fputs("loop\n", stderr); test_executor_loop();
     std::fputs("job_count\n", stderr); test_executor_job_count();
     std::fputs("exit\n", stderr); test_executor_exit_without_network();
+    std::fputs("pipelined\n", stderr); test_pipelined_loop();
+    std::fputs("pipelined job_count\n", stderr); test_pipelined_job_count();
     std::fputs("symmetry\n", stderr); test_symmetry(golden);
     if (g_failed) {
         std::fprintf(stderr, "%d check(s) failed\n", g_failed);
