@@ -11,6 +11,7 @@
 //!
 //! NOT compiled in this repository's CI (no cargo in the build image); written against the cited signatures.
 
+use std::collections::VecDeque;
 use std::borrow::Borrow;
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
 use std::fmt::{Debug, Formatter};
@@ -62,7 +63,19 @@ extern "C" {
         scalars_out: *mut f32,
         policy_out: *mut f32,
     ) -> c_int;
+    // asynchronous pair, slot in [0, KZ_ENGINE_SLOTS): inputs are copied to pinned staging before submit returns
+    fn kz_engine_submit_packed(
+        engine: *mut c_void,
+        slot: c_int,
+        bits: *const u8,
+        bits_stride: usize,
+        scalars_in: *const f32,
+        batch: c_int,
+    ) -> c_int;
+    fn kz_engine_wait(engine: *mut c_void, slot: c_int, scalars_out: *mut f32, policy_out: *mut f32) -> c_int;
 }
+
+pub const KZ_ENGINE_SLOTS: usize = 2;
 
 /// The reference panics on every executor error (`unwrap()` cudnn.rs:70,78); keep that behaviour.
 fn check(rc: c_int) {
@@ -117,6 +130,9 @@ pub struct HipNetwork<B: Board, M: BoardMapper<B>> {
     scalars_in: Vec<f32>,
     scalars_out: Vec<f32>,
     policy_out: Vec<f32>,
+    /// boards of the batches in flight, oldest first (decode_output needs their available moves)
+    pending: VecDeque<(usize, Vec<B>)>,
+    next_slot: usize,
     ph: PhantomData<B>,
 }
 
@@ -149,8 +165,58 @@ impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
             scalars_out: vec![0.0; max_batch_size * 5],
             policy_out: vec![0.0; max_batch_size * mapper.policy_len()],
             _model: model,
+            pending: VecDeque::new(),
+            next_slot: 0,
             ph: PhantomData,
         }
+    }
+
+    /// packed encode: exactly what BinaryOutput stores per position (binary_output.rs:210-256)
+    fn encode_into_staging(&mut self, boards: &[impl Borrow<B>]) -> usize {
+        let bool_count = self.mapper.input_bool_len();
+        let bits_bytes = (bool_count + 7) / 8;
+        self.scalars_in.clear();
+        let mut buffer = BitBuffer::new(bool_count);
+        for (bi, board) in boards.iter().enumerate() {
+            buffer.clear();
+            self.mapper.encode_input(&mut buffer, &mut self.scalars_in, board.borrow());
+            assert_eq!(bool_count, buffer.len());
+            self.bits[bi * bits_bytes..(bi + 1) * bits_bytes].copy_from_slice(buffer.storage());
+        }
+        assert_eq!(self.scalars_in.len(), boards.len() * self.mapper.input_scalar_count());
+        bits_bytes
+    }
+
+    /// Asynchronous pair for `pipelined_executor_loop` (executor_pipelined.rs): encode, hand the batch to the engine
+    /// and return while the GPU works.  At most `KZ_ENGINE_SLOTS` batches in flight.
+    pub fn submit_batch(&mut self, boards: Vec<B>) {
+        assert!(!boards.is_empty() && boards.len() <= self.max_batch_size);
+        assert!(self.pending.len() < KZ_ENGINE_SLOTS, "every engine slot is in flight");
+        let bits_bytes = self.encode_into_staging(&boards);
+        let slot = self.next_slot;
+        check(unsafe {
+            kz_engine_submit_packed(
+                self.engine,
+                slot as c_int,
+                self.bits.as_ptr(),
+                bits_bytes,
+                self.scalars_in.as_ptr(),
+                boards.len() as c_int,
+            )
+        });
+        self.pending.push_back((slot, boards));
+        self.next_slot = (slot + 1) % KZ_ENGINE_SLOTS;
+    }
+
+    /// Results of the OLDEST submitted batch.
+    pub fn wait_batch(&mut self) -> Vec<ZeroEvaluation<'static>> {
+        let (slot, boards) = self.pending.pop_front().expect("wait_batch with nothing in flight");
+        check(unsafe {
+            kz_engine_wait(self.engine, slot as c_int, self.scalars_out.as_mut_ptr(), self.policy_out.as_mut_ptr())
+        });
+        let (batch_size, policy_len) = (boards.len(), self.mapper.policy_len());
+        let outputs = [&self.scalars_out[..batch_size * 5], &self.policy_out[..batch_size * policy_len]];
+        decode_output(self.mapper, &boards, &outputs)
     }
 }
 
@@ -172,18 +238,8 @@ impl<B: Board, M: BoardMapper<B>> Network<B> for HipNetwork<B, M> {
             return vec![];
         }
 
-        // packed encode: exactly what BinaryOutput stores per position (binary_output.rs:210-256)
-        let bool_count = self.mapper.input_bool_len();
-        let bits_bytes = (bool_count + 7) / 8;
-        self.scalars_in.clear();
-        let mut buffer = BitBuffer::new(bool_count);
-        for (bi, board) in boards.iter().enumerate() {
-            buffer.clear();
-            self.mapper.encode_input(&mut buffer, &mut self.scalars_in, board.borrow());
-            assert_eq!(bool_count, buffer.len());
-            self.bits[bi * bits_bytes..(bi + 1) * bits_bytes].copy_from_slice(buffer.storage());
-        }
-        assert_eq!(self.scalars_in.len(), batch_size * self.mapper.input_scalar_count());
+        assert!(self.pending.is_empty(), "evaluate_batch while submitted batches are in flight");
+        let bits_bytes = self.encode_into_staging(boards);
 
         check(unsafe {
             kz_engine_eval_packed(
