@@ -3,7 +3,9 @@
 // Game rules live in the ext `board-game` crate on the Rust side; this mirror defines the mappers over plain position
 // records that carry exactly what the mappers read (bitboards, counters, the list of available moves).
 #pragma once
+#include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
@@ -71,8 +73,78 @@ void encode_input_full(const M &m, std::vector<float> &result, const B &board) {
 // --------------------------------------------------------------------------------------------------------------
 // Chess (chess.rs:125-178).  The record holds what ChessStdMapper reads from board-game's ChessBoard.
 // --------------------------------------------------------------------------------------------------------------
+// A chess move as the mappers see it (the ext `chess` crate's ChessMove): squares are rank * 8 + file, A1 = 0.
+struct ChessMove {
+    enum Promotion : int8_t { None = 0, Queen = 1, Rook = 2, Bishop = 3, Knight = 4 };  // order of chess.rs:489
+    uint8_t from = 0, to = 0;
+    int8_t promotion = None;
+    bool operator==(const ChessMove &o) const { return from == o.from && to == o.to && promotion == o.promotion; }
+};
+
+// square_pov / move_pov (chess.rs:417-441): black sees the board with the ranks flipped; its own inverse
+inline uint8_t chess_square_pov(bool white_pov, uint8_t sq) { return white_pov ? sq : (uint8_t)((7 - sq / 8) * 8 + sq % 8); }
+inline ChessMove chess_move_pov(bool white_pov, ChessMove mv) {
+    return ChessMove{chess_square_pov(white_pov, mv.from), chess_square_pov(white_pov, mv.to), mv.promotion};
+}
+
+// generate_all_flat_moves_pov (chess.rs:459-507) and its inverse FLAT_MOVES_POV (chess.rs:180-195): the 1880 moves from
+// the point of view of the player making them — queen-like moves for every (from, to) in square order, the knight
+// moves, then the promotions from the seventh to the eighth rank, piece-major.
+struct ChessFlatMoves {
+    static constexpr size_t COUNT = 1880;  // FLAT_MOVE_COUNT
+    std::vector<ChessMove> index_to_mv;
+    int16_t mv_to_index[64][64][5];
+    ChessFlatMoves() {
+        auto push = [&](int from, int to, int promo) {
+            mv_to_index[from][to][promo] = (int16_t)index_to_mv.size();
+            index_to_mv.push_back(ChessMove{(uint8_t)from, (uint8_t)to, (int8_t)promo});
+        };
+        for (auto &a : mv_to_index)
+            for (auto &b : a)
+                for (auto &c : b) c = -1;
+        for (int from = 0; from < 64; from++)
+            for (int to = 0; to < 64; to++) {
+                const int df = from % 8 - to % 8, dr = from / 8 - to / 8;
+                if (((df == 0) != (dr == 0)) || (df != 0 && std::abs(df) == std::abs(dr))) push(from, to, 0);
+            }
+        for (int from = 0; from < 64; from++)
+            for (int to = 0; to < 64; to++) {
+                const int df = std::abs(from % 8 - to % 8), dr = std::abs(from / 8 - to / 8);
+                if ((df == 1 && dr == 2) || (df == 2 && dr == 1)) push(from, to, 0);
+            }
+        for (int piece = ChessMove::Queen; piece <= ChessMove::Knight; piece++)
+            for (int from_f = 0; from_f < 8; from_f++)
+                for (int to_f = 0; to_f < 8; to_f++)
+                    if (std::abs(from_f - to_f) <= 1) push(6 * 8 + from_f, 7 * 8 + to_f, piece);
+        if (index_to_mv.size() != COUNT) throw std::logic_error("flat chess move count");  // assert_eq!, :505
+    }
+    static const ChessFlatMoves &get() {
+        static const ChessFlatMoves table;
+        return table;
+    }
+};
+
+// ClassifiedPovMove::{from_move, to_channel} (chess.rs:299-346) for a POV move: 8 directions x 7 distances (clockwise
+// from N), 8 knight directions (clockwise from NNE), 3 x 3 under-promotions (direction-major; rook, bishop, knight).
+// A queen promotion classifies as the queen-like move it is.  -1: "Could not find move type" (the reference panics).
+inline int chess_conv_channel(ChessMove mv) {
+    static const int queen_dirs[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    static const int knight_deltas[8][2] = {{2, 1}, {1, 2}, {-1, 2}, {-2, 1}, {-2, -1}, {-1, -2}, {1, -2}, {2, -1}};
+    const int dr = mv.to / 8 - mv.from / 8, df = mv.to % 8 - mv.from % 8;
+    const int sr = (dr > 0) - (dr < 0), sf = (df > 0) - (df < 0);
+    if (mv.promotion >= ChessMove::Rook) return 56 + 8 + (sf + 1) * 3 + (mv.promotion - ChessMove::Rook);
+    for (int d = 0; d < 8; d++)
+        if (queen_dirs[d][0] == sr && queen_dirs[d][1] == sf) {
+            const int dist = std::max(std::abs(dr), std::abs(df));
+            if (dr == sr * dist && df == sf * dist) return d * 7 + dist - 1;
+        }
+    for (int d = 0; d < 8; d++)
+        if (knight_deltas[d][0] == dr && knight_deltas[d][1] == df) return 56 + d;
+    return -1;
+}
+
 struct ChessPosition {
-    using Move = int32_t;  // flat policy index in [0, 1880) (chess.rs:197-217); move generation is ext
+    using Move = ChessMove;  // move generation is ext (board-game crate): the caller supplies the available moves
     bool white_to_move = true;
     uint64_t pieces[2][6] = {};  // [color: 0 white, 1 black][pawn, knight, bishop, rook, queen, king], A1 = bit 0
     uint64_t en_passant = 0;     // bitboard with the en-passant square, or 0
@@ -89,7 +161,18 @@ struct ChessStdMapper {
     std::array<size_t, 3> input_bool_shape() const { return {13, 8, 8}; }  // :126-129
     size_t input_scalar_count() const { return 8; }                        // :131-134
     size_t policy_len() const { return 1880; }
-    size_t move_to_index(const ChessPosition &, int32_t mv) const { return (size_t)mv; }
+    // chess.rs:202-217: the index of the POV move in the flat list; an unknown move panics in the reference
+    size_t move_to_index(const ChessPosition &b, ChessMove mv) const {
+        const ChessMove pov = chess_move_pov(b.white_to_move, mv);
+        const int index = pov.promotion >= 0 && pov.promotion <= ChessMove::Knight && pov.from < 64 && pov.to < 64
+                              ? ChessFlatMoves::get().mv_to_index[pov.from][pov.to][pov.promotion]
+                              : -1;
+        if (index < 0) throw std::invalid_argument("chess move not found in flat moves");
+        return (size_t)index;
+    }
+    ChessMove index_to_move(const ChessPosition &b, size_t index) const {
+        return chess_move_pov(b.white_to_move, ChessFlatMoves::get().index_to_mv.at(index));
+    }
     void encode_input(BitBuffer &bools, std::vector<float> &scalars, const ChessPosition &b) const {  // :136-170
         const int pov = b.white_to_move ? 0 : 1, other = 1 - pov;
         scalars.push_back(pov == 0 ? 1.0f : 0.0f);  // absolute colour of the side to move (:144-146)
@@ -109,6 +192,17 @@ struct ChessStdMapper {
 // --------------------------------------------------------------------------------------------------------------
 // Ataxx (ataxx.rs:8-116).  Tiles are indexed densely: i = y*size + x.
 // --------------------------------------------------------------------------------------------------------------
+// ChessLegacyConvPolicyMapper (chess.rs:219-247): policy [73, 8, 8], index = channel * 64 + POV source square
+struct ChessLegacyConvPolicyMapper {
+    size_t policy_len() const { return 73 * 64; }
+    size_t move_to_index(const ChessPosition &b, ChessMove mv) const {
+        const ChessMove pov = chess_move_pov(b.white_to_move, mv);
+        const int channel = chess_conv_channel(pov);
+        if (channel < 0) throw std::invalid_argument("could not find move type");
+        return (size_t)channel * 64 + pov.from;
+    }
+};
+
 struct AtaxxMove {
     enum Kind { Pass, Copy, Jump } kind = Pass;
     int from_x = 0, from_y = 0, to_x = 0, to_y = 0;
@@ -204,6 +298,22 @@ struct GoStdMapper {
     size_t input_scalar_count() const { return 6; }  // :57-62
     size_t policy_len() const { return 1 + (size_t)max_size * max_size; }
     size_t move_to_index(const GoPosition &, int32_t mv) const { return (size_t)mv; }
+    // go.rs:26-43: pass = 0, Place(tile) = 1 + tile.to_flat(max_size) = 1 + y * max_size + x, and back
+    struct Move {
+        bool pass;
+        int x, y;
+    };
+    size_t move_to_index(Move mv) const {
+        if (mv.pass) return 0;
+        if (mv.x < 0 || mv.y < 0 || mv.x >= max_size || mv.y >= max_size) throw std::invalid_argument("tile outside max_size");
+        return 1 + (size_t)mv.y * max_size + mv.x;
+    }
+    Move index_to_move(size_t index) const {
+        if (index == 0) return Move{true, 0, 0};
+        const size_t tile = index - 1;
+        if (tile >= (size_t)max_size * max_size) throw std::invalid_argument("tile_index < max_area");  // assert!, :39
+        return Move{false, (int)(tile % max_size), (int)(tile / max_size)};
+    }
     void encode_input(BitBuffer &bools, std::vector<float> &scalars, const GoPosition &b) const {  // :64-113
         const int area = max_size * max_size;
         auto exists = [&](int i) { return i % max_size < b.size && i / max_size < b.size; };

@@ -684,3 +684,89 @@ KZO_EXPORT int kzo_decode_output(const float *scalars, const float *policy_logit
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Chess policy indexing (rust/kz-core/src/mapping/chess.rs:180-507): what decode_output calls for every available move.
+ * A move is (from, to, promotion): squares are rank * 8 + file with A1 = 0; promotion 0 = none, 1 = queen, 2 = rook,
+ * 3 = bishop, 4 = knight (the order of the flat list's promotion block, chess.rs:489-500).
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* generate_all_flat_moves_pov (chess.rs:459-507): queen-like moves for every (from, to) in square order, then the
+ * knight moves, then the promotions from the seventh to the eighth rank, piece-major.  out[i] = {from, to, promotion}. */
+KZO_EXPORT int kzo_chess_flat_moves(int *out /* [1880][3] */) {
+    int n = 0;
+    for (int from = 0; from < 64; from++)
+        for (int to = 0; to < 64; to++) {
+            int df = from % 8 - to % 8, dr = from / 8 - to / 8;
+            if (((df == 0) ^ (dr == 0)) || (df != 0 && abs(df) == abs(dr))) {
+                out[n * 3] = from, out[n * 3 + 1] = to, out[n * 3 + 2] = 0;
+                n++;
+            }
+        }
+    for (int from = 0; from < 64; from++)
+        for (int to = 0; to < 64; to++) {
+            int df = abs(from % 8 - to % 8), dr = abs(from / 8 - to / 8);
+            if ((df == 1 && dr == 2) || (df == 2 && dr == 1)) {
+                out[n * 3] = from, out[n * 3 + 1] = to, out[n * 3 + 2] = 0;
+                n++;
+            }
+        }
+    for (int piece = 1; piece <= 4; piece++)
+        for (int from_f = 0; from_f < 8; from_f++)
+            for (int to_f = 0; to_f < 8; to_f++)
+                if (abs(from_f - to_f) <= 1) {
+                    out[n * 3] = 6 * 8 + from_f, out[n * 3 + 1] = 7 * 8 + to_f, out[n * 3 + 2] = piece;
+                    n++;
+                }
+    return n; /* FLAT_MOVE_COUNT = 1880 (chess.rs:185, asserted :505) */
+}
+
+/* square_pov / move_pov (chess.rs:417-441): black sees the board with the ranks flipped */
+static int kzo_square_pov(int white_to_move, int sq) { return white_to_move ? sq : (7 - sq / 8) * 8 + sq % 8; }
+
+/* ChessStdMapper::move_to_index (chess.rs:202-210): the position of the POV move in the flat list, or -1 (the
+ * reference panics) when it is not one of the 1880 */
+KZO_EXPORT int kzo_chess_move_to_index(int white_to_move, int from, int to, int promotion) {
+    static int moves[1880 * 3], ready = 0;
+    if (!ready) {
+        kzo_chess_flat_moves(moves);
+        ready = 1;
+    }
+    const int f = kzo_square_pov(white_to_move, from), t = kzo_square_pov(white_to_move, to);
+    for (int i = 0; i < 1880; i++)
+        if (moves[i * 3] == f && moves[i * 3 + 1] == t && moves[i * 3 + 2] == promotion) return i;
+    return -1;
+}
+
+/* ChessLegacyConvPolicyMapper::move_to_index (chess.rs:224-236) over ClassifiedPovMove::{from_move, to_channel}
+ * (chess.rs:299-346): channel * 64 + from, channels = 8 directions x 7 distances, 8 knight directions, 3 x 3
+ * under-promotions (direction-major; pieces rook, bishop, knight).  A queen promotion is a plain queen-like move. */
+KZO_EXPORT int kzo_chess_conv_index(int white_to_move, int from, int to, int promotion) {
+    static const int queen_dirs[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    static const int knight_deltas[8][2] = {{2, 1}, {1, 2}, {-1, 2}, {-2, 1}, {-2, -1}, {-1, -2}, {1, -2}, {2, -1}};
+    const int f = kzo_square_pov(white_to_move, from), t = kzo_square_pov(white_to_move, to);
+    const int dr = t / 8 - f / 8, df = t % 8 - f % 8;
+    const int sr = (dr > 0) - (dr < 0), sf = (df > 0) - (df < 0);
+    int channel = -1;
+    if (promotion >= 2) { /* rook, bishop, knight */
+        channel = 56 + 8 + (sf + 1) * 3 + (promotion - 2);
+    } else {
+        for (int d = 0; d < 8 && channel < 0; d++)
+            if (queen_dirs[d][0] == sr && queen_dirs[d][1] == sf) {
+                const int dist = abs(dr) > abs(df) ? abs(dr) : abs(df);
+                if (dr == sr * dist && df == sf * dist) channel = d * 7 + dist - 1;
+            }
+        for (int d = 0; d < 8 && channel < 0; d++)
+            if (knight_deltas[d][0] == dr && knight_deltas[d][1] == df) channel = 56 + d;
+    }
+    if (channel < 0) return -1; /* "Could not find move type" (chess.rs:331) */
+    return channel * 64 + f;
+}
+
+/* The attention head's index of a POV move (rust/kz-misc/src/bin/write_chess_mapping.rs:51-66, the generator of
+ * python/lib/mapping/chess_flat_to_att.txt): from * 88 + (to, or 64 + 3 * file(to) + piece for a promotion with
+ * piece queen 0, rook 1, bishop 2, knight 3 ... as written there: file * 3 + p_i with p_i in 0..3). */
+KZO_EXPORT int kzo_chess_att_index(int from_pov, int to_pov, int promotion) {
+    const int att_to = promotion == 0 ? to_pov : 64 + (to_pov % 8) * 3 + (promotion - 1);
+    return from_pov * (64 + 8 * 3) + att_to;
+}

@@ -11,6 +11,7 @@
 #include <set>
 #include <sstream>
 #include <thread>
+#include <tuple>
 
 #include "../../kzero_amd/csrc/host/executor.hpp"
 #include "../../kzero_amd/csrc/host/mapping.hpp"
@@ -146,7 +147,84 @@ static void test_mappers() {
         CHECK(bools[2 * 81 + 0] && !bools[2 * 81 + 7] && !bools[2 * 81 + 7 * 9]);  // in-board plane
         CHECK(std::fabs(scalars[4] - 0.5f) < 1e-6f);
         CHECK(GoStdMapper(19, true).policy_len() == 362 && input_full_shape(GoStdMapper(19, true))[0] == 13);
+        // policy round trip (tests/mapper/mod.rs:37-72): pass = 0, tiles row-major after it
+        GoStdMapper g19(19, true);
+        for (size_t i = 0; i < g19.policy_len(); i++) CHECK(g19.move_to_index(g19.index_to_move(i)) == i);
+        CHECK(g19.index_to_move(0).pass && g19.move_to_index({false, 3, 2}) == 1 + 2 * 19 + 3);
+        CHECK(throws([&] { g19.index_to_move(362); }));
     }
+}
+
+// ---- chess policy indexing: chess.rs:180-507, pinned to the reference's own data ----
+//  * python/lib/mapping/chess_flat_to_move_input.txt / chess_flat_to_conv.txt / chess_flat_to_att.txt (written by
+//    rust/kz-misc/src/bin/write_chess_mapping.rs from generate_all_flat_moves_pov): every one of the 1880 flat moves,
+//    its conv-policy index and its attention index;
+//  * the (side, move) <-> conv index vectors of rust/kz-core/tests/mapper/chess/pairs.rs (oracle/gen_chess_pairs.py);
+//  * flat_gen (tests/mapper/chess/mod.rs:6-17): 1880 moves, no duplicates;
+//  * test_valid_policy_mapping (tests/mapper/mod.rs:37-72): index -> move -> index round trip for both colours.
+static void test_chess_policy(const std::string &golden) {
+    const auto &flat = ChessFlatMoves::get();
+    CHECK(flat.index_to_mv.size() == 1880);
+    std::set<std::tuple<int, int, int>> unique;
+    for (auto &m : flat.index_to_mv) unique.insert({m.from, m.to, m.promotion});
+    CHECK(unique.size() == 1880);
+
+    std::ifstream fin(golden + "/chess_flat_to_move_input.txt"), fconv(golden + "/chess_flat_to_conv.txt"),
+        fatt(golden + "/chess_flat_to_att.txt");
+    CHECK(fin.good() && fconv.good() && fatt.good());
+    ChessStdMapper std_mapper;
+    ChessLegacyConvPolicyMapper conv_mapper;
+    ChessPosition white, black;
+    black.white_to_move = false;
+    std::string line;
+    size_t rows = 0;
+    for (size_t i = 0; i < 1880 && std::getline(fin, line); i++, rows++) {
+        int v[8];
+        std::stringstream ss(line);
+        for (int k = 0; k < 8; k++) {
+            std::string cell;
+            std::getline(ss, cell, ',');
+            v[k] = std::atoi(cell.c_str());
+        }
+        const int promo = v[3] ? ChessMove::Queen : v[4] ? ChessMove::Rook : v[5] ? ChessMove::Bishop : v[6] ? ChessMove::Knight : ChessMove::None;
+        const ChessMove mv = flat.index_to_mv[i];
+        CHECK(mv.from == v[0] && mv.to == v[1] && mv.promotion == promo && (v[7] == 1) == (promo == ChessMove::None));
+        int conv = -1, att = -1;
+        fconv >> conv;
+        fatt >> att;
+        CHECK((int)conv_mapper.move_to_index(white, mv) == conv);
+        // write_chess_mapping.rs:51-66
+        const int att_to = mv.promotion == ChessMove::None ? mv.to : 64 + (mv.to % 8) * 3 + (mv.promotion - 1);
+        CHECK(mv.from * 88 + att_to == att);
+        // round trips: white sees the list as is, black with the ranks flipped
+        CHECK(std_mapper.move_to_index(white, mv) == i && std_mapper.index_to_move(white, i) == mv);
+        const ChessMove abs_black = std_mapper.index_to_move(black, i);
+        CHECK(abs_black.from == (7 - mv.from / 8) * 8 + mv.from % 8 && abs_black.to == (7 - mv.to / 8) * 8 + mv.to % 8);
+        CHECK(std_mapper.move_to_index(black, abs_black) == i);
+    }
+    CHECK(rows == 1880);
+    CHECK(throws([&] { std_mapper.move_to_index(white, ChessMove{0, 0, 0}); }));                  // a1a1: not a move
+    CHECK(throws([&] { std_mapper.move_to_index(white, ChessMove{8, 16, ChessMove::Queen}); }));  // a2a3=Q: not one either
+
+    std::ifstream pairs(golden + "/chess_conv_pairs.txt");
+    CHECK(pairs.good());
+    int side, from, to, promo, index, n_pairs = 0;
+    while (pairs >> side >> from >> to >> promo >> index) {
+        ChessPosition pos;
+        pos.white_to_move = side != 0;
+        CHECK((int)conv_mapper.move_to_index(pos, ChessMove{(uint8_t)from, (uint8_t)to, (int8_t)promo}) == index);
+        n_pairs++;
+    }
+    CHECK(n_pairs == 84);
+
+    // decode_output gathers the logits of the available moves through move_to_index (common.rs:77-86)
+    ChessPosition p;
+    p.moves = std::vector<ChessMove>{{12, 28, 0}, {6, 21, 0}};  // e2e4, g1f3
+    std::vector<float> scalars(5, 0.0f), logits(1880, 0.0f);
+    logits[std_mapper.move_to_index(p, {12, 28, 0})] = std::log(3.0f);
+    auto ev = decode_output(std_mapper, &p, 1, scalars.data(), logits.data());
+    CHECK(ev.size() == 1 && ev[0].policy.size() == 2);
+    CHECK(std::fabs(ev[0].policy[0] - 0.75f) < 1e-6f && std::fabs(ev[0].policy[1] - 0.25f) < 1e-6f);
 }
 
 // ---- network/common.rs:16-114 ----
@@ -575,6 +653,7 @@ int main(int argc, char **argv) {
     std::fputs("bitbuffer\n", stderr); test_bitbuffer();
     std::fputs("mappers\n", stderr); test_mappers();
     std::fputs("decode\n", stderr); test_decode();
+    std::fputs("chess policy\n", stderr); test_chess_policy(golden);
     std::fputs("job_channel\n", stderr); test_job_channel();
     std::fputs("state\n", stderr); test_executor_state();
     std::fputs("loop\n", stderr); test_executor_loop();

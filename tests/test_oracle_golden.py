@@ -115,3 +115,51 @@ def test_softmax_rejects_non_positive_sum():
     """common.rs:110: assert!(sum > 0.0) — NaN logits trip it."""
     v = np.array([np.nan, 1.0], np.float32)
     assert O.lib().kzo_softmax_in_place(v.ctypes.data, 2) != 0
+
+
+# ---- chess policy indexing (chess.rs:180-507): what decode_output calls for every available move ----
+def _chess_tables():
+    g = O.GOLDEN
+    rows = [[int(x) for x in line.strip().strip(",").split(",")] for line in open(os.path.join(g, "chess_flat_to_move_input.txt"))]
+    t = np.array(rows)
+    promo = np.where(t[:, 3] == 1, 1, np.where(t[:, 4] == 1, 2, np.where(t[:, 5] == 1, 3, np.where(t[:, 6] == 1, 4, 0))))
+    moves = np.stack([t[:, 0], t[:, 1], promo], axis=1)
+    conv = np.loadtxt(os.path.join(g, "chess_flat_to_conv.txt"), dtype=np.int64)
+    att = np.loadtxt(os.path.join(g, "chess_flat_to_att.txt"), dtype=np.int64)
+    return moves, conv, att
+
+
+def test_chess_flat_moves_match_the_reference_tables():
+    """generate_all_flat_moves_pov against the tables the reference's write_chess_mapping.rs wrote from it
+    (python/lib/mapping/chess_flat_to_{move_input,conv,att}.txt, copied as data): all 1880 moves, their conv-policy
+    index (ClassifiedPovMove) and their attention index; plus flat_gen's count / no-duplicates check."""
+    L = O.lib()
+    L.kzo_chess_flat_moves.argtypes = [C.c_void_p]
+    out = (C.c_int * (1880 * 3))()
+    assert L.kzo_chess_flat_moves(out) == 1880  # tests/mapper/chess/mod.rs:6-17
+    got = np.array(out).reshape(1880, 3)
+    assert len({tuple(r) for r in got.tolist()}) == 1880
+    moves, conv, att = _chess_tables()
+    assert (got == moves).all()
+    for i, (f, t, p) in enumerate(got.tolist()):
+        assert L.kzo_chess_conv_index(1, f, t, p) == conv[i]
+        assert L.kzo_chess_att_index(f, t, p) == att[i]
+        assert L.kzo_chess_move_to_index(1, f, t, p) == i
+        # black: the same POV move, ranks flipped (square_pov)
+        fb, tb = (7 - f // 8) * 8 + f % 8, (7 - t // 8) * 8 + t % 8
+        assert L.kzo_chess_move_to_index(0, fb, tb, p) == i
+        assert L.kzo_chess_conv_index(0, fb, tb, p) == conv[i]
+    assert L.kzo_chess_move_to_index(1, 0, 0, 0) == -1
+    # the attention gather table of the golden chess model is that same table
+    _, tensors = read_model(open(os.path.join(O.GOLDEN, "chess_2x32_att.kzm"), "rb").read())
+    assert (tensors["policy_head.FLAT_TO_ATT"].astype(np.int64) == att).all()
+
+
+def test_chess_conv_index_known_answers_of_the_reference_tests():
+    """The (side to move, move) <-> index vectors of rust/kz-core/tests/mapper/chess/pairs.rs:16-356."""
+    import json
+    L = O.lib()
+    rows = json.load(open(os.path.join(O.GOLDEN, "chess_conv_pairs.json")))
+    assert len(rows) == 84 and {r["case"] for r in rows} >= {"castles", "en_passant", "black_potential_promotions"}
+    for r in rows:
+        assert L.kzo_chess_conv_index(int(r["white_to_move"]), r["from"], r["to"], r["promotion"]) == r["conv_index"], r
