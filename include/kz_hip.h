@@ -109,6 +109,11 @@ int kz_engine_eval_packed_decoded(kz_engine *engine, const uint8_t *bits, size_t
 int kz_engine_submit_packed(kz_engine *engine, int slot, const uint8_t *bits, size_t bits_stride,
                             const float *scalars_in, int batch);
 int kz_engine_wait(kz_engine *engine, int slot, float *scalars_out, float *policy_out);
+/* Same wait without the copy: *scalars_out [batch*5] and *policy_out [batch*policy_len] point into the slot's pinned
+ * staging (library-owned) and stay valid until the next kz_engine_submit_packed on that slot or kz_engine_destroy —
+ * the lifetime of the `&[DTensor]` the reference's executor hands out until its next call (cudnn.rs:73-82).  Saves a
+ * 1.9 MB host copy per chess batch of 256 on the executor thread. */
+int kz_engine_wait_view(kz_engine *engine, int slot, const float **scalars_out, const float **policy_out);
 
 /* ---- device-resident evaluation (inputs and outputs already in HBM; used by bench.py and the parity tests) ----
  * Pointers are device pointers on the engine's device (kz_device_malloc).  Enqueues on the engine's stream and

@@ -51,6 +51,7 @@ SIGNATURES = {
                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "kz_engine_submit_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     "kz_engine_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "kz_engine_wait_view": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "kz_engine_enqueue_packed_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
                                                   C.c_void_p, C.c_void_p]),
     "kz_engine_enqueue_dense_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -222,6 +223,17 @@ class Engine:
         scalars = np.empty((batch, 5), np.float32)
         policy = np.empty((batch, self.model.info.policy_len), np.float32)
         check(load().kz_engine_wait(self._h, slot, scalars.ctypes.data, policy.ctypes.data))
+        return scalars, policy
+
+    def wait_view(self, slot: int, batch: int):
+        """Zero-copy wait: arrays over the slot's pinned staging, valid until the next submit on that slot."""
+        ps, pp = C.c_void_p(), C.c_void_p()
+        check(load().kz_engine_wait_view(self._h, slot, C.byref(ps), C.byref(pp)))
+        if batch == 0:
+            return np.empty((0, 5), np.float32), np.empty((0, self.model.info.policy_len), np.float32)
+        plen = self.model.info.policy_len
+        scalars = np.ctypeslib.as_array(C.cast(ps, C.POINTER(C.c_float)), shape=(batch, 5))
+        policy = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_float)), shape=(batch, plen))
         return scalars, policy
 
     def enqueue_packed_device(self, d_bits: DeviceBuffer, stride: int, d_scalars: DeviceBuffer, batch: int,

@@ -95,7 +95,7 @@ std::unique_ptr<DeviceExecutors<B, M>> spawn_device_executors(int device, const 
             } else {
                 pipelined_executor_loop<Graph, Net, B, ZeroEvaluation>(
                     gpu_batch_size, std::min(startup.pipeline_depth, Net::max_in_flight()), cond, std::move(rx),
-                    std::move(srv), load, [](Net &net, const B *x, size_t n) { net.submit_batch(x, n); },
+                    std::move(srv), load, [](Net &net, B *x, size_t n) { net.submit_batch(x, n); },
                     [=](Net &net) {
                         auto y = net.wait_batch();
                         count(y.size());

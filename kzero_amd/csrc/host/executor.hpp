@@ -90,6 +90,13 @@ class ExecutorState {
         return {x_.data() + head_ + submitted_, n};
     }
 
+    // pipelined loop: the same batch, mutable — the network may move the inputs out (they are only counted from
+    // here on: respond_batch never reads x_)
+    std::pair<X *, size_t> take_batch(size_t max_batch_size) {
+        auto [data, n] = get_batch(max_batch_size);
+        return {const_cast<X *>(data), n};
+    }
+
     // pipelined loop: the batch get_batch returned has been handed to the network; its results arrive later, in
     // submission order, through respond_batch
     void mark_submitted(size_t n) {
@@ -245,7 +252,8 @@ void batched_executor_loop(size_t max_batch_size, RunCondition run_condition, Re
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the same loop with up to `depth` batches in flight on ONE executor thread, for a network with an
-// asynchronous pair `submit(N&, X*, n)` / `wait(N&) -> vector<Y>` (results of the OLDEST submitted batch).  Channel
+// asynchronous pair `submit(N&, X*, n)` (may move the inputs out) / `wait(N&) -> vector<Y>` (results of the OLDEST
+// submitted batch).  Channel
 // semantics are those of batched_executor_loop: the same RunCondition, replies in job order, a new graph first drains
 // what is in flight on the old network, a disconnected job channel evaluates the remainder and returns.  What changes
 // is only when the thread blocks: while the GPU works on a batch the thread keeps collecting jobs and encodes and
@@ -265,7 +273,7 @@ void pipelined_executor_loop(size_t max_batch_size, size_t depth, RunCondition r
     std::deque<size_t> in_flight;  // batch sizes, oldest first
 
     auto submit_one = [&]() {
-        auto [data, n] = state.get_batch(max_batch_size);
+        auto [data, n] = state.take_batch(max_batch_size);
         if (events) events->on_eval(n);
         submit_batch(*network, data, n);
         state.mark_submitted(n);

@@ -2,6 +2,7 @@
 // kzero_amd/rust/hip.rs.  Same shape as `CudaNetwork` (rust/kz-core/src/network/cudnn.rs:18-88): encode every board
 // with the mapper, run the engine, decode the outputs.  Talks to the product only through the C ABI.
 #pragma once
+#include <iterator>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -43,7 +44,7 @@ class HipNetwork : public Network<B> {
     kz_engine *engine_ = nullptr;
     size_t max_batch_size_;
     std::vector<uint8_t> bits_;
-    std::vector<float> scalars_in_, scalars_out_, policy_out_;
+    std::vector<float> scalars_in_;
     // asynchronous pair: the boards of every batch in flight (decode_output needs their legal moves), oldest first
     std::vector<B> pending_boards_[KZ_ENGINE_SLOTS];
     int next_slot_ = 0, oldest_slot_ = 0, in_flight_ = 0;
@@ -74,14 +75,11 @@ class HipNetwork : public Network<B> {
         if ((size_t)info.policy_len != mapper_.policy_len()) throw std::invalid_argument("Wrong policy shape");
         kz_check(kz_engine_create(model_->get(), device, (int)max_batch_size, dtype, &engine_));
         bits_.resize(max_batch_size * (size_t)info.bits_bytes);
-        scalars_out_.resize(max_batch_size * 5);
-        policy_out_.resize(max_batch_size * (size_t)info.policy_len);
     }
     HipNetwork(HipNetwork &&o) noexcept
         : mapper_(o.mapper_), model_(std::move(o.model_)), engine_(o.engine_), max_batch_size_(o.max_batch_size_),
-          bits_(std::move(o.bits_)), scalars_in_(std::move(o.scalars_in_)), scalars_out_(std::move(o.scalars_out_)),
-          policy_out_(std::move(o.policy_out_)), next_slot_(o.next_slot_), oldest_slot_(o.oldest_slot_),
-          in_flight_(o.in_flight_) {
+          bits_(std::move(o.bits_)), scalars_in_(std::move(o.scalars_in_)), next_slot_(o.next_slot_),
+          oldest_slot_(o.oldest_slot_), in_flight_(o.in_flight_) {
         for (int i = 0; i < KZ_ENGINE_SLOTS; i++) pending_boards_[i] = std::move(o.pending_boards_[i]);
         o.engine_ = nullptr;
     }
@@ -96,23 +94,26 @@ class HipNetwork : public Network<B> {
         if (n == 0) return {};
         if (in_flight_ != 0) throw std::logic_error("evaluate_batch while submitted batches are in flight");
         const size_t bits_bytes = encode_into_staging(boards, n);
-        kz_check(kz_engine_eval_packed(engine_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n, scalars_out_.data(),
-                                       policy_out_.data()));
-        return decode_output(mapper_, boards, n, scalars_out_.data(), policy_out_.data());
+        // kz_engine_eval_packed without its copy into caller buffers: decode reads the pinned staging directly
+        const float *scalars = nullptr, *policy = nullptr;
+        kz_check(kz_engine_submit_packed(engine_, 0, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
+        kz_check(kz_engine_wait_view(engine_, 0, &scalars, &policy));
+        return decode_output(mapper_, boards, n, scalars, policy);
     }
 
     // ---- asynchronous pair for pipelined_executor_loop (kz_engine_submit_packed / kz_engine_wait) ----
     static constexpr size_t max_in_flight() { return KZ_ENGINE_SLOTS; }
     size_t batches_in_flight() const { return (size_t)in_flight_; }
 
-    // encode + hand the batch to the engine; returns while the GPU works.  `boards` is not retained.
-    void submit_batch(const B *boards, size_t n) {
+    // encode + hand the batch to the engine; returns while the GPU works.  The boards are MOVED out of `boards`
+    // (decode_output needs their available moves when the results come back); the pointer itself is not retained.
+    void submit_batch(B *boards, size_t n) {
         if (n == 0 || n > max_batch_size_) throw std::invalid_argument("0 < batch_size <= max_batch_size");
         if (in_flight_ == KZ_ENGINE_SLOTS) throw std::logic_error("every engine slot is in flight");
         const size_t bits_bytes = encode_into_staging(boards, n);
         // the engine copies bits and scalars to its pinned staging before this returns (include/kz_hip.h)
         kz_check(kz_engine_submit_packed(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
-        pending_boards_[next_slot_].assign(boards, boards + n);
+        pending_boards_[next_slot_].assign(std::make_move_iterator(boards), std::make_move_iterator(boards + n));
         next_slot_ = (next_slot_ + 1) % KZ_ENGINE_SLOTS;
         in_flight_++;
     }
@@ -121,11 +122,13 @@ class HipNetwork : public Network<B> {
     std::vector<ZeroEvaluation> wait_batch() {
         if (in_flight_ == 0) throw std::logic_error("wait_batch with nothing in flight");
         const int slot = oldest_slot_;
-        kz_check(kz_engine_wait(engine_, slot, scalars_out_.data(), policy_out_.data()));
+        // decode straight from the engine's pinned staging (valid until the next submit on this slot)
+        const float *scalars = nullptr, *policy = nullptr;
+        kz_check(kz_engine_wait_view(engine_, slot, &scalars, &policy));
         oldest_slot_ = (oldest_slot_ + 1) % KZ_ENGINE_SLOTS;
         in_flight_--;
         const std::vector<B> &boards = pending_boards_[slot];
-        return decode_output(mapper_, boards.data(), boards.size(), scalars_out_.data(), policy_out_.data());
+        return decode_output(mapper_, boards.data(), boards.size(), scalars, policy);
     }
 };
 

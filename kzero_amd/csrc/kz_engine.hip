@@ -865,6 +865,22 @@ KZ_API int kz_engine_wait(kz_engine *e, int slot, float *scalars_out, float *pol
     return 0;
 }
 
+KZ_API int kz_engine_wait_view(kz_engine *e, int slot, const float **scalars_out, const float **policy_out) {
+    if (!e) return fail("kz_engine_wait_view: null engine");
+    if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail("kz_engine_wait_view: bad slot");
+    if (!scalars_out || !policy_out) return fail("kz_engine_wait_view: null output");
+    kz_engine::Slot &s = e->slots[slot];
+    if (s.batch < 0) return fail("kz_engine_wait_view: nothing submitted on this slot");
+    const int batch = s.batch;
+    s.batch = -1;
+    *scalars_out = s.h_sout;
+    *policy_out = s.h_pol;
+    if (batch == 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(s.done));
+    return 0;
+}
+
 KZ_API int kz_engine_eval_packed(kz_engine *e, const uint8_t *bits, size_t bits_stride, const float *scalars_in,
                                  int batch, float *scalars_out, float *policy_out) {
     if (kz_engine_submit_packed(e, 0, bits, bits_stride, scalars_in, batch)) return 1;

@@ -170,11 +170,13 @@ int main(int argc, char **argv) {
     {
         // the asynchronous pair alone: two submits, two waits, oldest first
         Net net(mapper, model_a, 8, 0, KZ_DTYPE_F32);
-        net.submit_batch(boards.data(), 3);
-        net.submit_batch(boards.data() + 3, boards.size() - 3);
+        auto copy = boards;  // submit_batch moves the boards out
+        net.submit_batch(copy.data(), 3);
+        net.submit_batch(copy.data() + 3, copy.size() - 3);
         CHECK(net.batches_in_flight() == 2);
         bool threw = false;
-        try { net.submit_batch(boards.data(), 1); } catch (const std::logic_error &) { threw = true; }
+        auto one = boards;
+        try { net.submit_batch(one.data(), 1); } catch (const std::logic_error &) { threw = true; }
         CHECK(threw);  // both engine slots are out
         auto y0 = net.wait_batch(), y1 = net.wait_batch();
         CHECK(y0.size() == 3 && y1.size() == boards.size() - 3);
@@ -189,7 +191,7 @@ int main(int argc, char **argv) {
             pipelined_executor_loop<std::shared_ptr<const HipModel>, Net, PackedBoard, ZeroEvaluation>(
                 16, 2, RunCondition::any(), std::move(rx), std::move(srv),
                 [&](std::shared_ptr<const HipModel> m) { return Net(mapper, std::move(m), 16, 0, KZ_DTYPE_F32); },
-                [](Net &net, const PackedBoard *x, size_t n) { net.submit_batch(x, n); },
+                [](Net &net, PackedBoard *x, size_t n) { net.submit_batch(x, n); },
                 [&](Net &net) {
                     auto y = net.wait_batch();
                     pevals += (long)y.size();

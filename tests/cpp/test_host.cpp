@@ -489,7 +489,7 @@ static void test_pipelined_loop() {
     std::thread exec([&, srv = std::move(server), rx = std::move(grx)]() mutable {
         pipelined_executor_loop<int, FakeAsyncNet, int, int>(
             4, 2, RunCondition::any(), std::move(rx), std::move(srv), [](int g) { return FakeAsyncNet(g); },
-            [](FakeAsyncNet &n, const int *x, size_t len) { n.submit(x, len); }, [](FakeAsyncNet &n) { return n.wait(); },
+            [](FakeAsyncNet &n, int *x, size_t len) { n.submit(x, len); }, [](FakeAsyncNet &n) { return n.wait(); },
             &trace);
     });
     // no network yet: jobs wait in the channel
@@ -556,7 +556,7 @@ static void test_pipelined_job_count() {
     std::thread exec([&, srv = std::move(server), rx = std::move(grx)]() mutable {
         pipelined_executor_loop<int, FakeAsyncNet, int, int>(
             8, 2, RunCondition::job_count(2), std::move(rx), std::move(srv), [](int g) { return FakeAsyncNet(g); },
-            [](FakeAsyncNet &n, const int *x, size_t len) { n.submit(x, len); }, [](FakeAsyncNet &n) { return n.wait(); },
+            [](FakeAsyncNet &n, int *x, size_t len) { n.submit(x, len); }, [](FakeAsyncNet &n) { return n.wait(); },
             &trace);
     });
     gtx.send(1);

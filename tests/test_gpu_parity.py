@@ -213,6 +213,12 @@ def test_async_slots_and_shared_weights(dev):
     assert np.array_equal(s_c, s_a) and np.array_equal(p_c, p_a)
     with pytest.raises(capi.KzError, match="nothing submitted"):
         e1.wait(0, n0)
+    # the zero-copy wait hands out the slot's pinned staging: same numbers, valid until the slot is submitted again
+    n2 = e1.submit_packed(1, bits, scalars_in)
+    s_v, p_v = e1.wait_view(1, n2)
+    assert np.array_equal(s_v, s_a) and np.array_equal(p_v, p_a)
+    with pytest.raises(capi.KzError, match="nothing submitted"):
+        e1.wait_view(1, n2)
     e1.close()
     s_d, _ = e2.eval_packed(bits, scalars_in)  # weights stay alive while any engine uses them
     assert np.array_equal(s_d, s_a)
