@@ -114,6 +114,15 @@ int kz_engine_wait(kz_engine *engine, int slot, float *scalars_out, float *polic
  * the lifetime of the `&[DTensor]` the reference's executor hands out until its next call (cudnn.rs:73-82).  Saves a
  * 1.9 MB host copy per chess batch of 256 on the executor thread. */
 int kz_engine_wait_view(kz_engine *engine, int slot, const float **scalars_out, const float **policy_out);
+/* The asynchronous pair with decode_output on the device (kz_engine_eval_packed_decoded split in two): submit takes
+ * the CSR move lists of the batch (move_offsets [batch+1], move_indices = move_to_index of every available move),
+ * wait hands out views of the slot's pinned staging — values [batch*5] (value, win, draw, loss, moves_left) and the
+ * probabilities parallel to move_indices — valid until the next submit on that slot.  0.2 KB instead of 7.5 KB per
+ * chess evaluation cross PCIe and the executor thread does no softmax. */
+int kz_engine_submit_packed_decoded(kz_engine *engine, int slot, const uint8_t *bits, size_t bits_stride,
+                                    const float *scalars_in, int batch, const int64_t *move_offsets,
+                                    const int32_t *move_indices);
+int kz_engine_wait_decoded(kz_engine *engine, int slot, const float **values_out, const float **probs_out);
 
 /* ---- device-resident evaluation (inputs and outputs already in HBM; used by bench.py and the parity tests) ----
  * Pointers are device pointers on the engine's device (kz_device_malloc).  Enqueues on the engine's stream and

@@ -52,6 +52,9 @@ SIGNATURES = {
     "kz_engine_submit_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     "kz_engine_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kz_engine_wait_view": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "kz_engine_submit_packed_decoded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
+                                                  C.c_void_p, C.c_void_p]),
+    "kz_engine_wait_decoded": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "kz_engine_enqueue_packed_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
                                                   C.c_void_p, C.c_void_p]),
     "kz_engine_enqueue_dense_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -224,6 +227,27 @@ class Engine:
         policy = np.empty((batch, self.model.info.policy_len), np.float32)
         check(load().kz_engine_wait(self._h, slot, scalars.ctypes.data, policy.ctypes.data))
         return scalars, policy
+
+    def submit_packed_decoded(self, slot: int, bits: np.ndarray, scalars_in: np.ndarray, move_lists):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        scalars_in = np.ascontiguousarray(scalars_in, dtype=np.float32)
+        offsets = np.zeros(len(move_lists) + 1, np.int64)
+        offsets[1:] = np.cumsum([len(m) for m in move_lists])
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(m, np.int32) for m in move_lists]) if offsets[-1] else
+                                   np.zeros(0, np.int32))
+        check(load().kz_engine_submit_packed_decoded(self._h, slot, bits.ctypes.data, bits.shape[1],
+                                                     scalars_in.ctypes.data, bits.shape[0], offsets.ctypes.data,
+                                                     idx.ctypes.data))
+        return offsets
+
+    def wait_decoded(self, slot: int, offsets: np.ndarray):
+        """values [batch,5] and one probability array per board: copies of the slot's pinned staging."""
+        pv, pp = C.c_void_p(), C.c_void_p()
+        check(load().kz_engine_wait_decoded(self._h, slot, C.byref(pv), C.byref(pp)))
+        batch, total = len(offsets) - 1, int(offsets[-1])
+        values = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_float)), shape=(batch, 5)).copy() if batch else np.empty((0, 5), np.float32)
+        probs = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_float)), shape=(total,)).copy() if total else np.zeros(0, np.float32)
+        return values, [probs[offsets[i]:offsets[i + 1]] for i in range(batch)]
 
     def wait_view(self, slot: int, batch: int):
         """Zero-copy wait: arrays over the slot's pinned staging, valid until the next submit on that slot."""

@@ -26,6 +26,8 @@ struct StartupSettings {
     // not in the reference: batches each executor thread keeps in flight (1 = batched_executor_loop as it is;
     // 2 = pipelined_executor_loop over the engine's two async slots)
     size_t pipeline_depth = 1;
+    // not in the reference: decode_output on the GPU instead of on the executor thread
+    bool device_decode = false;
 };
 
 struct DeviceSizing {
@@ -77,7 +79,12 @@ std::unique_ptr<DeviceExecutors<B, M>> spawn_device_executors(int device, const 
         dev->threads.emplace_back([=, srv = server, rx = std::move(grx)]() mutable {
             using Net = HipNetwork<B, M>;
             using Graph = typename DeviceExecutors<B, M>::Graph;
-            auto load = [=](Graph g) { return Net(mapper, std::move(g), gpu_batch_size, device, dtype); };
+            const bool device_decode = startup.device_decode;
+            auto load = [=](Graph g) {
+                Net net(mapper, std::move(g), gpu_batch_size, device, dtype);
+                net.set_device_decode(device_decode);
+                return net;
+            };
             auto count = [=](size_t n) {
                 if (counters) {
                     counters->real += n;  // ExpandEvals(real = x.len(), potential = gpu_batch_size) (:113-115)

@@ -48,6 +48,39 @@ class HipNetwork : public Network<B> {
     // asynchronous pair: the boards of every batch in flight (decode_output needs their legal moves), oldest first
     std::vector<B> pending_boards_[KZ_ENGINE_SLOTS];
     int next_slot_ = 0, oldest_slot_ = 0, in_flight_ = 0;
+    // decode_output on the device (kz_engine_submit_packed_decoded / kz_engine_wait_decoded): the CSR move lists of
+    // the batches in flight
+    bool device_decode_ = false;
+    std::vector<int64_t> move_offsets_[KZ_ENGINE_SLOTS];
+    std::vector<int32_t> move_indices_;
+
+    // move_to_index of every available move of the batch, as CSR (common.rs:77-86 up to the gather)
+    void build_move_lists(const B *boards, size_t n, std::vector<int64_t> &offsets) {
+        const size_t policy_len = mapper_.policy_len();
+        offsets.assign(1, 0);
+        move_indices_.clear();
+        for (size_t bi = 0; bi < n; bi++) {
+            auto moves = boards[bi].available_moves();
+            if (moves)
+                for (const auto &mv : *moves) {
+                    const size_t index = mapper_.move_to_index(boards[bi], mv);
+                    if (index >= policy_len) throw std::out_of_range("move_to_index out of range");
+                    move_indices_.push_back((int32_t)index);
+                }
+            offsets.push_back((int64_t)move_indices_.size());
+        }
+    }
+    // values [n,5] (already tanh / softmax) + probabilities parallel to the move lists -> evaluations
+    static std::vector<ZeroEvaluation> assemble_decoded(size_t n, const std::vector<int64_t> &offsets, const float *values,
+                                                        const float *probs) {
+        std::vector<ZeroEvaluation> out(n);
+        for (size_t bi = 0; bi < n; bi++) {
+            const float *v = values + bi * 5;
+            out[bi].values = ZeroValuesPov{v[0], WDL{v[1], v[2], v[3]}, v[4]};
+            out[bi].policy.assign(probs + offsets[bi], probs + offsets[bi + 1]);
+        }
+        return out;
+    }
 
     size_t encode_into_staging(const B *boards, size_t n) {
         const size_t bool_count = input_bool_len(mapper_), bits_bytes = (bool_count + 7) / 8;
@@ -79,8 +112,11 @@ class HipNetwork : public Network<B> {
     HipNetwork(HipNetwork &&o) noexcept
         : mapper_(o.mapper_), model_(std::move(o.model_)), engine_(o.engine_), max_batch_size_(o.max_batch_size_),
           bits_(std::move(o.bits_)), scalars_in_(std::move(o.scalars_in_)), next_slot_(o.next_slot_),
-          oldest_slot_(o.oldest_slot_), in_flight_(o.in_flight_) {
-        for (int i = 0; i < KZ_ENGINE_SLOTS; i++) pending_boards_[i] = std::move(o.pending_boards_[i]);
+          oldest_slot_(o.oldest_slot_), in_flight_(o.in_flight_), device_decode_(o.device_decode_) {
+        for (int i = 0; i < KZ_ENGINE_SLOTS; i++) {
+            pending_boards_[i] = std::move(o.pending_boards_[i]);
+            move_offsets_[i] = std::move(o.move_offsets_[i]);
+        }
         o.engine_ = nullptr;
     }
     HipNetwork(const HipNetwork &) = delete;
@@ -88,12 +124,27 @@ class HipNetwork : public Network<B> {
 
     size_t max_batch_size() const override { return max_batch_size_; }
 
+    // true: decode_output runs on the GPU (legal-move gather + softmax, tanh, wdl); 0.2 KB instead of 7.5 KB per chess
+    // evaluation cross PCIe and this thread does no softmax.  Same results to f32 rounding (device expf/tanhf).
+    void set_device_decode(bool on) {
+        if (in_flight_ != 0) throw std::logic_error("set_device_decode while batches are in flight");
+        device_decode_ = on;
+    }
+
     // cudnn.rs:55-87
     std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
         if (n > max_batch_size_) throw std::invalid_argument("batch_size <= max_batch_size");  // assert!, :58
         if (n == 0) return {};
         if (in_flight_ != 0) throw std::logic_error("evaluate_batch while submitted batches are in flight");
         const size_t bits_bytes = encode_into_staging(boards, n);
+        if (device_decode_) {
+            build_move_lists(boards, n, move_offsets_[0]);
+            const float *values = nullptr, *probs = nullptr;
+            kz_check(kz_engine_submit_packed_decoded(engine_, 0, bits_.data(), bits_bytes, scalars_in_.data(), (int)n,
+                                                     move_offsets_[0].data(), move_indices_.data()));
+            kz_check(kz_engine_wait_decoded(engine_, 0, &values, &probs));
+            return assemble_decoded(n, move_offsets_[0], values, probs);
+        }
         // kz_engine_eval_packed without its copy into caller buffers: decode reads the pinned staging directly
         const float *scalars = nullptr, *policy = nullptr;
         kz_check(kz_engine_submit_packed(engine_, 0, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
@@ -111,9 +162,16 @@ class HipNetwork : public Network<B> {
         if (n == 0 || n > max_batch_size_) throw std::invalid_argument("0 < batch_size <= max_batch_size");
         if (in_flight_ == KZ_ENGINE_SLOTS) throw std::logic_error("every engine slot is in flight");
         const size_t bits_bytes = encode_into_staging(boards, n);
-        // the engine copies bits and scalars to its pinned staging before this returns (include/kz_hip.h)
-        kz_check(kz_engine_submit_packed(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
-        pending_boards_[next_slot_].assign(std::make_move_iterator(boards), std::make_move_iterator(boards + n));
+        // the engine copies its inputs to pinned staging before submit returns (include/kz_hip.h)
+        if (device_decode_) {
+            build_move_lists(boards, n, move_offsets_[next_slot_]);
+            kz_check(kz_engine_submit_packed_decoded(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(),
+                                                     (int)n, move_offsets_[next_slot_].data(), move_indices_.data()));
+            pending_boards_[next_slot_].clear();  // the move lists are all the decode needs
+        } else {
+            kz_check(kz_engine_submit_packed(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
+            pending_boards_[next_slot_].assign(std::make_move_iterator(boards), std::make_move_iterator(boards + n));
+        }
         next_slot_ = (next_slot_ + 1) % KZ_ENGINE_SLOTS;
         in_flight_++;
     }
@@ -122,11 +180,16 @@ class HipNetwork : public Network<B> {
     std::vector<ZeroEvaluation> wait_batch() {
         if (in_flight_ == 0) throw std::logic_error("wait_batch with nothing in flight");
         const int slot = oldest_slot_;
+        oldest_slot_ = (oldest_slot_ + 1) % KZ_ENGINE_SLOTS;
+        in_flight_--;
+        if (device_decode_) {
+            const float *values = nullptr, *probs = nullptr;
+            kz_check(kz_engine_wait_decoded(engine_, slot, &values, &probs));
+            return assemble_decoded(move_offsets_[slot].size() - 1, move_offsets_[slot], values, probs);
+        }
         // decode straight from the engine's pinned staging (valid until the next submit on this slot)
         const float *scalars = nullptr, *policy = nullptr;
         kz_check(kz_engine_wait_view(engine_, slot, &scalars, &policy));
-        oldest_slot_ = (oldest_slot_ + 1) % KZ_ENGINE_SLOTS;
-        in_flight_--;
         const std::vector<B> &boards = pending_boards_[slot];
         return decode_output(mapper_, boards.data(), boards.size(), scalars, policy);
     }

@@ -365,14 +365,15 @@ struct kz_engine {
         float *d_pol = nullptr, *h_pol = nullptr;
         hipEvent_t done = nullptr;
         int batch = -1;
+        // device-side decode (N2): CSR move lists, decoded values, probabilities, error flag; grown on demand
+        bool decoded = false;  // what is in flight was submitted with a move list
+        size_t move_cap = 0, moves = 0;
+        int64_t *d_moff = nullptr, *h_moff = nullptr;
+        int32_t *d_midx = nullptr, *h_midx = nullptr;
+        float *d_values = nullptr, *h_values = nullptr, *d_probs = nullptr, *h_probs = nullptr;
+        int *d_err = nullptr, *h_err = nullptr;
     } slots[KZ_ENGINE_SLOTS];
     float *d_dense = nullptr, *h_dense = nullptr;
-    // device-side decode (N2): CSR move lists, decoded values, probabilities, error flag; grown on demand
-    size_t move_cap = 0;
-    int64_t *d_moff = nullptr, *h_moff = nullptr;
-    int32_t *d_midx = nullptr, *h_midx = nullptr;
-    float *d_values = nullptr, *h_values = nullptr, *d_probs = nullptr, *h_probs = nullptr;
-    int *d_err = nullptr, *h_err = nullptr;
 
     // debugging
     bool keep = false;
@@ -853,7 +854,7 @@ KZ_API int kz_engine_wait(kz_engine *e, int slot, float *scalars_out, float *pol
     if (!e) return fail("kz_engine_wait: null engine");
     if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail("kz_engine_wait: bad slot");
     kz_engine::Slot &s = e->slots[slot];
-    if (s.batch < 0) return fail("kz_engine_wait: nothing submitted on this slot");
+    if (s.batch < 0 || s.decoded) return fail("kz_engine_wait: nothing submitted on this slot");
     const int batch = s.batch;
     s.batch = -1;
     if (batch == 0) return 0;
@@ -870,7 +871,7 @@ KZ_API int kz_engine_wait_view(kz_engine *e, int slot, const float **scalars_out
     if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail("kz_engine_wait_view: bad slot");
     if (!scalars_out || !policy_out) return fail("kz_engine_wait_view: null output");
     kz_engine::Slot &s = e->slots[slot];
-    if (s.batch < 0) return fail("kz_engine_wait_view: nothing submitted on this slot");
+    if (s.batch < 0 || s.decoded) return fail("kz_engine_wait_view: nothing submitted on this slot");
     const int batch = s.batch;
     s.batch = -1;
     *scalars_out = s.h_sout;
@@ -887,60 +888,107 @@ KZ_API int kz_engine_eval_packed(kz_engine *e, const uint8_t *bits, size_t bits_
     return kz_engine_wait(e, 0, scalars_out, policy_out);
 }
 
+KZ_API int kz_engine_submit_packed_decoded(kz_engine *e, int slot, const uint8_t *bits, size_t bits_stride,
+                                           const float *scalars_in, int batch, const int64_t *move_offsets,
+                                           const int32_t *move_indices) {
+    const char *fn = "kz_engine_submit_packed_decoded";
+    if (check_batch(e, batch, fn) || check_packed(e, fn)) return 1;
+    if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail(std::string(fn) + ": bad slot");
+    kz_engine::Slot &s = e->slots[slot];
+    if (s.batch >= 0) return fail(std::string(fn) + ": slot still in flight (call kz_engine_wait_decoded first)");
+    if (batch == 0) {
+        s.batch = 0;
+        s.decoded = true;
+        s.moves = 0;
+        return 0;
+    }
+    if (!bits || !move_offsets) return fail(std::string(fn) + ": null argument");
+    const Model &m = *e->model;
+    const size_t bits_bytes = (size_t)(m.n_bool * m.h * m.w + 7) / 8;
+    if (bits_stride < bits_bytes) return fail(std::string(fn) + ": bits_stride too small");
+    if (m.n_scalar && !scalars_in) return fail(std::string(fn) + ": null scalars");
+    if (move_offsets[0] != 0) return fail(std::string(fn) + ": move_offsets[0] must be 0");
+    for (int b = 0; b < batch; b++)
+        if (move_offsets[b + 1] < move_offsets[b]) return fail(std::string(fn) + ": move_offsets must be non-decreasing");
+    const size_t total = (size_t)move_offsets[batch];
+    if (total && !move_indices) return fail(std::string(fn) + ": null move list");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!s.d_moff) {
+        if (e->dmalloc((void **)&s.d_moff, (size_t)(e->max_batch + 1) * 8) || e->hmalloc((void **)&s.h_moff, (size_t)(e->max_batch + 1) * 8) ||
+            e->dmalloc((void **)&s.d_values, (size_t)e->max_batch * 20) || e->hmalloc((void **)&s.h_values, (size_t)e->max_batch * 20) ||
+            e->dmalloc((void **)&s.d_err, 16) || e->hmalloc((void **)&s.h_err, 16))
+            return 1;
+    }
+    if (total > s.move_cap) {  // the old (smaller) buffers stay on the engine's free list until it is destroyed
+        const size_t cap = std::max(total, std::max(s.move_cap * 2, (size_t)e->max_batch * 64));
+        if (e->dmalloc((void **)&s.d_midx, cap * 4) || e->hmalloc((void **)&s.h_midx, cap * 4) ||
+            e->dmalloc((void **)&s.d_probs, cap * 4) || e->hmalloc((void **)&s.h_probs, cap * 4))
+            return 1;
+        s.move_cap = cap;
+    }
+    for (int b = 0; b < batch; b++) memcpy(s.h_bits + b * bits_bytes, bits + b * bits_stride, bits_bytes);
+    if (m.n_scalar) memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
+    memcpy(s.h_moff, move_offsets, (size_t)(batch + 1) * 8);
+    if (total) memcpy(s.h_midx, move_indices, total * 4);
+    *s.h_err = 0;
+    struct StreamSwap {
+        kz_engine *e;
+        hipStream_t saved;
+        ~StreamSwap() { e->stream = saved; }
+    } swap{e, e->stream};
+    if (e->slot_stream[slot]) e->stream = e->slot_stream[slot];
+    HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_moff, s.h_moff, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, e->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(s.d_midx, s.h_midx, total * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(s.d_err, 0, 4, e->stream));
+    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout, s.d_pol)) return 1;
+    e->prof.begin("kz_decode_output", e->stream);
+    kz::launch_decode_output(s.d_sout, s.d_pol, batch, m.policy_len, s.d_moff, s.d_midx, s.d_values, s.d_probs, s.d_err,
+                             e->stream);
+    e->prof.end(e->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s.h_values, s.d_values, (size_t)batch * 20, hipMemcpyDeviceToHost, e->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(s.h_probs, s.d_probs, total * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(s.h_err, s.d_err, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipEventRecord(s.done, e->stream));
+    s.batch = batch;
+    s.decoded = true;
+    s.moves = total;
+    return 0;
+}
+
+KZ_API int kz_engine_wait_decoded(kz_engine *e, int slot, const float **values_out, const float **probs_out) {
+    if (!e) return fail("kz_engine_wait_decoded: null engine");
+    if (slot < 0 || slot >= KZ_ENGINE_SLOTS) return fail("kz_engine_wait_decoded: bad slot");
+    if (!values_out || !probs_out) return fail("kz_engine_wait_decoded: null output");
+    kz_engine::Slot &s = e->slots[slot];
+    if (s.batch < 0 || !s.decoded) return fail("kz_engine_wait_decoded: nothing submitted with a move list on this slot");
+    const int batch = s.batch;
+    s.batch = -1;
+    s.decoded = false;
+    *values_out = s.h_values;
+    *probs_out = s.h_probs;
+    if (batch == 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(s.done));
+    if (*s.h_err) return fail("kz_engine_wait_decoded: Softmax input sum must be strictly positive (or a move index is out of range)");
+    return 0;
+}
+
 KZ_API int kz_engine_eval_packed_decoded(kz_engine *e, const uint8_t *bits, size_t bits_stride, const float *scalars_in,
                                          int batch, const int64_t *move_offsets, const int32_t *move_indices,
                                          float *values_out, float *probs_out) {
     if (check_batch(e, batch, "kz_engine_eval_packed_decoded") || check_packed(e, "kz_engine_eval_packed_decoded")) return 1;
     if (batch == 0) return 0;
-    if (!bits || !move_offsets || !values_out) return fail("kz_engine_eval_packed_decoded: null argument");
-    const Model &m = *e->model;
-    const size_t bits_bytes = (size_t)(m.n_bool * m.h * m.w + 7) / 8;
-    if (bits_stride < bits_bytes) return fail("kz_engine_eval_packed_decoded: bits_stride too small");
-    if (m.n_scalar && !scalars_in) return fail("kz_engine_eval_packed_decoded: null scalars");
-    if (move_offsets[0] != 0) return fail("kz_engine_eval_packed_decoded: move_offsets[0] must be 0");
-    for (int b = 0; b < batch; b++)
-        if (move_offsets[b + 1] < move_offsets[b]) return fail("kz_engine_eval_packed_decoded: move_offsets must be non-decreasing");
-    const size_t total = (size_t)move_offsets[batch];
-    if (total && (!move_indices || !probs_out)) return fail("kz_engine_eval_packed_decoded: null move list");
-    kz_engine::Slot &s = e->slots[0];
-    if (s.batch >= 0) return fail("kz_engine_eval_packed_decoded: slot 0 still in flight");
-    HIP_TRY(hipSetDevice(e->device));
-    if (!e->d_moff) {
-        if (e->dmalloc((void **)&e->d_moff, (size_t)(e->max_batch + 1) * 8) || e->hmalloc((void **)&e->h_moff, (size_t)(e->max_batch + 1) * 8) ||
-            e->dmalloc((void **)&e->d_values, (size_t)e->max_batch * 20) || e->hmalloc((void **)&e->h_values, (size_t)e->max_batch * 20) ||
-            e->dmalloc((void **)&e->d_err, 16) || e->hmalloc((void **)&e->h_err, 16))
-            return 1;
-    }
-    if (total > e->move_cap) {  // the old (smaller) buffers stay on the engine's free list until it is destroyed
-        const size_t cap = std::max(total, std::max(e->move_cap * 2, (size_t)e->max_batch * 64));
-        if (e->dmalloc((void **)&e->d_midx, cap * 4) || e->hmalloc((void **)&e->h_midx, cap * 4) ||
-            e->dmalloc((void **)&e->d_probs, cap * 4) || e->hmalloc((void **)&e->h_probs, cap * 4))
-            return 1;
-        e->move_cap = cap;
-    }
-    for (int b = 0; b < batch; b++) memcpy(s.h_bits + b * bits_bytes, bits + b * bits_stride, bits_bytes);
-    if (m.n_scalar) memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
-    memcpy(e->h_moff, move_offsets, (size_t)(batch + 1) * 8);
-    if (total) memcpy(e->h_midx, move_indices, total * 4);
-    *e->h_err = 0;
-    HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_moff, e->h_moff, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, e->stream));
-    if (total) HIP_TRY(hipMemcpyAsync(e->d_midx, e->h_midx, total * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_err, 0, 4, e->stream));
-    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout, s.d_pol)) return 1;
-    e->prof.begin("kz_decode_output", e->stream);
-    kz::launch_decode_output(s.d_sout, s.d_pol, batch, m.policy_len, e->d_moff, e->d_midx, e->d_values, e->d_probs,
-                             e->d_err, e->stream);
-    e->prof.end(e->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_values, e->d_values, (size_t)batch * 20, hipMemcpyDeviceToHost, e->stream));
-    if (total) HIP_TRY(hipMemcpyAsync(e->h_probs, e->d_probs, total * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err, 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (*e->h_err) return fail("kz_engine_eval_packed_decoded: Softmax input sum must be strictly positive (or a move index is out of range)");
-    memcpy(values_out, e->h_values, (size_t)batch * 20);
-    if (total) memcpy(probs_out, e->h_probs, total * 4);
+    if (!values_out) return fail("kz_engine_eval_packed_decoded: null argument");
+    if (move_offsets && batch > 0 && move_offsets[batch] > 0 && !probs_out) return fail("kz_engine_eval_packed_decoded: null move list");
+    if (kz_engine_submit_packed_decoded(e, 0, bits, bits_stride, scalars_in, batch, move_offsets, move_indices)) return 1;
+    const float *values = nullptr, *probs = nullptr;
+    const size_t total = e->slots[0].moves;
+    if (kz_engine_wait_decoded(e, 0, &values, &probs)) return 1;
+    memcpy(values_out, values, (size_t)batch * 20);
+    if (total) memcpy(probs_out, probs, total * 4);
     return 0;
 }
 

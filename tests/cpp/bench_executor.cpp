@@ -3,7 +3,7 @@
 // Sized like the self-play server (rust/kz-selfplay/src/server/server_alphazero.rs:47-55) and counted like its
 // collector (`real` evals/s, collector.rs:172-191).  Not a test: a measurement of the host side next to bench.py.
 //
-//   bench_executor <model.kzm|onnx> <seconds> <gpu_threads> <generator_threads> [gpu_batch] [search_batch] [dtype] [depth]
+//   bench_executor <model.kzm|onnx> <seconds> <gpu_threads> <generator_threads> [gpu_batch] [search_batch] [dtype] [depth] [device_decode]
 //   depth = batches each executor thread keeps in flight (1 = batched_executor_loop, 2 = pipelined_executor_loop)
 #include <chrono>
 #include <cstdio>
@@ -27,6 +27,7 @@ int main(int argc, char **argv) {
     if (argc > 6) st.search_batch_size = (size_t)atoi(argv[6]);
     const int dtype = (argc > 7 && std::string(argv[7]) == "f32") ? KZ_DTYPE_F32 : KZ_DTYPE_F16;
     if (argc > 8) st.pipeline_depth = (size_t)atoi(argv[8]);
+    if (argc > 9) st.device_decode = atoi(argv[9]) != 0;
 
     auto model = std::make_shared<const HipModel>(argv[1]);
     const kz_model_info info = model->info;
@@ -81,9 +82,9 @@ int main(int argc, char **argv) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stop = true;
     std::printf("{\"evals_per_s\": %.1f, \"fill\": %.3f, \"gpu_threads\": %zu, \"generator_threads\": %d, "
-                "\"concurrent_games\": %zu, \"gpu_batch\": %zu, \"search_batch\": %zu, \"pipeline_depth\": %zu, \"seconds\": %.2f}\n",
+                "\"concurrent_games\": %zu, \"gpu_batch\": %zu, \"search_batch\": %zu, \"pipeline_depth\": %zu, \"device_decode\": %d, \"seconds\": %.2f}\n",
                 (r1 - r0) / dt, (double)(r1 - r0) / (double)(p1 - p0 ? p1 - p0 : 1), st.gpu_threads_per_device, generators,
-                sizing.concurrent_games, st.gpu_batch_size, st.search_batch_size, st.pipeline_depth, dt);
+                sizing.concurrent_games, st.gpu_batch_size, st.search_batch_size, st.pipeline_depth, (int)st.device_decode, dt);
     std::fflush(stdout);
     // generators block in recv(); the process exit tears everything down (the reference server has no clean stop
     // either: commander.rs:63-64)

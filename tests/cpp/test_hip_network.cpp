@@ -184,6 +184,21 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < y1.size(); i++) CHECK(close_eval(y1[i], expect[3 + i], 1e-4f));
     }
     {
+        // decode_output on the device: the same evaluations (device expf/tanhf: 1e-5), blocking and pipelined
+        Net net(mapper, model_a, 8, 0, KZ_DTYPE_F32);
+        net.set_device_decode(true);
+        auto y = net.evaluate_batch(boards.data(), boards.size());
+        CHECK(y.size() == boards.size());
+        for (size_t i = 0; i < y.size(); i++) CHECK(close_eval(y[i], expect[i], 1e-4f));
+        auto copy = boards;
+        net.submit_batch(copy.data(), 2);
+        net.submit_batch(copy.data() + 2, copy.size() - 2);
+        auto y0 = net.wait_batch(), y1 = net.wait_batch();
+        CHECK(y0.size() == 2 && y1.size() == boards.size() - 2);
+        for (size_t i = 0; i < y0.size(); i++) CHECK(close_eval(y0[i], expect[i], 1e-4f));
+        for (size_t i = 0; i < y1.size(); i++) CHECK(close_eval(y1[i], expect[2 + i], 1e-4f));
+    }
+    {
         auto [pclient, pserver] = job_pair<PackedBoard, ZeroEvaluation>(16);
         auto [gtx, grx] = bounded<std::optional<std::shared_ptr<const HipModel>>>(1);
         std::atomic<long> pevals{0};

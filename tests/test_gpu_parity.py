@@ -131,6 +131,27 @@ def test_device_side_decode_output(dev):
         eng.eval_packed_decoded(bits, scalars_in, [np.array([5, net.policy_len], np.int32), moves[1], moves[2]])
     v2, _ = eng.eval_packed_decoded(bits, scalars_in, moves)  # still usable afterwards
     assert np.array_equal(v, v2)
+    # the asynchronous pair with the decode on the device: two batches in flight, each with its own move lists
+    moves_b = [m[::-1].copy() for m in moves]
+    off_a = eng.submit_packed_decoded(0, bits, scalars_in, moves)
+    off_b = eng.submit_packed_decoded(1, bits, scalars_in, moves_b)
+    with pytest.raises(capi.KzError, match="in flight"):
+        eng.submit_packed_decoded(0, bits, scalars_in, moves)
+    with pytest.raises(capi.KzError, match="nothing submitted"):
+        eng.wait(1, len(bits))  # a decoded submission is collected with wait_decoded
+    v_b, probs_b = eng.wait_decoded(1, off_b)
+    v_a, probs_a = eng.wait_decoded(0, off_a)
+    assert np.array_equal(v_a, v) and np.array_equal(v_b, v)
+    for a, b, c in zip(probs_a, probs, probs_b):
+        assert np.array_equal(a, b)
+        np.testing.assert_allclose(c[::-1], b, rtol=1e-6, atol=1e-8)
+    with pytest.raises(capi.KzError, match="nothing submitted"):
+        eng.wait_decoded(0, off_a)
+    off_e = eng.submit_packed_decoded(0, bits, scalars_in, [np.array([net.policy_len], np.int32), moves[1], moves[2]])
+    with pytest.raises(capi.KzError, match="strictly positive"):
+        eng.wait_decoded(0, off_e)
+    s3, p3 = eng.eval_packed(bits, scalars_in)  # the slot is free again
+    assert np.array_equal(s3, s) and np.array_equal(p3, p)
 
 
 def test_replay_recorded_positions(dev, tmp_path):

@@ -10,7 +10,8 @@ g++ -std=c++17 -O2 -pthread tests/cpp/bench_executor.cpp -o tests/cpp/build/benc
 python3 -c "
 from kzero_amd.synth import random_model
 open('/tmp/chess20x256.kzm','wb').write(random_model('chess', 20, 256, 'attention'))"
-for cfg in "1 1" "2 1" "3 1" "4 1" "1 2" "2 2" "3 2"; do
+# gpu_threads, pipeline depth, decode_output on the device
+for cfg in "1 1 0" "2 1 0" "3 1 0" "4 1 0" "1 2 0" "2 2 0" "3 2 0" "1 2 1" "2 2 1" "2 1 1" "4 1 1"; do
   set -- $cfg
-  tests/cpp/build/bench_executor /tmp/chess20x256.kzm $SEC $1 ${GENERATORS:-6} 256 16 f16 $2
+  tests/cpp/build/bench_executor /tmp/chess20x256.kzm $SEC $1 ${GENERATORS:-6} 256 16 f16 $2 $3
 done
