@@ -30,7 +30,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=256, help="executor batch (gpu_batch_size)")
-    ap.add_argument("--engines", type=int, default=2, help="executor engines (streams) per GPU")
+    ap.add_argument("--engines", type=int, default=None,
+                    help="executor engines (streams) per GPU = gpu_threads_per_device; default: what fills the chip "
+                         "for the workload (chess 2: half-chip launches; ataxx 3: covers its separate head kernels; "
+                         "go 1: a launch per layer already fills the chip)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--workload", default="chess-20x256", choices=["chess-20x256", "ataxx-8x128", "go19-40x256"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -38,7 +41,10 @@ def parse_args():
                     help="diagnostic: feed host buffers through kz_engine_submit_packed/kz_engine_wait (PCIe-inclusive, "
                          "two slots per engine); never the configuration `value` is quoted on")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.engines is None:
+        args.engines = {"chess-20x256": 2, "ataxx-8x128": 3, "go19-40x256": 1}[args.workload]
+    return args
 
 
 WORKLOADS = {
