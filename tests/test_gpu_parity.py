@@ -4,10 +4,7 @@ Tolerances:
   f32 path: max |delta| <= 1e-4 on policy logits and the 5 scalars (BASELINE.json north_star / BASELINE.md §4).
   f16 path: 1e-4 is not attainable by construction (f16 storage of weights and activations, f32 accumulate: every
             layer rounds the residual stream to 11 bits).  Stated tolerance, per board and per output tensor:
-            max |delta| <= F16_REL * max(1, max |ref|)   with F16_REL = 3e-2
-# two f16 paths of this library against each other (measured <= 2e-4 on 2-block nets, <= 4e-3 after 41 convolutions)
-F16_PATHS_ATOL = 2e-3
-F16_PATHS_ATOL_DEEP = 2e-2
+            max |delta| <= F16_REL * max(1, max |ref|)   with F16_REL = 1e-2
             (measured: ~5e-3 RMS of the logit scale after 41 convolutions; the tests print the measured maximum).
 """
 import os
@@ -22,7 +19,7 @@ from tests import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 F32_ATOL = 1e-4
-F16_REL = 3e-2
+F16_REL = 1e-2
 # two f16 paths of this library against each other (measured <= 2e-4 on 2-block nets, <= 4e-3 after 41 convolutions)
 F16_PATHS_ATOL = 2e-3
 F16_PATHS_ATOL_DEEP = 2e-2
@@ -36,6 +33,7 @@ def assert_f32(actual, ref, what):
 def assert_f16(actual, ref, what):
     scale = np.maximum(1.0, np.abs(ref).max(axis=-1, keepdims=True))
     rel = (np.abs(actual - ref) / scale).max()
+    print(f"[f16] {what}: max |delta| / scale = {rel:.3e}")
     assert rel <= F16_REL, f"{what}: max |delta| / scale = {rel:.3e} > {F16_REL}"
     return rel
 
