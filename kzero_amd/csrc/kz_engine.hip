@@ -70,8 +70,8 @@ struct DeviceWeights {
     float *post_scale = nullptr, *post_shift = nullptr;
 
     // resident tower
-    bool resident = false, fused_heads = false, resident32 = false;
-    void *res32_w = nullptr;  // f32 resident launch: one packed weight stream
+    bool resident = false, fused_heads = false, resident32 = false, split16 = false;
+    void *res32_w = nullptr;  // f32 resident launch (exact f32, or split f16 pairs): one packed weight stream
     void *res_w_stem = nullptr, *res_w_tower = nullptr;
     float *res_bias = nullptr;
     int32_t *att_idx = nullptr;
@@ -178,8 +178,9 @@ struct DeviceWeights {
     int *bc_rowmap = nullptr;  // kz_board_conv_f16's tile-row map and halo-row list for this board size
     unsigned short *bc_halo = nullptr;
     int bc_n_halo = 0;
-    int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32) {
+    int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32, bool want_split16) {
         resident32 = want_resident32;
+        split16 = want_split16;
         const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
         HIP_TRY(hipSetDevice(device));
         resident = want_resident;
@@ -192,7 +193,19 @@ struct DeviceWeights {
         }
         if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
 
-        if (resident32) {
+        if (split16) {
+            // (hi, lo) f16 pairs in fragment order: 9 stem k-steps, then 72 per tower convolution, 32 KB each
+            std::vector<uint16_t> packed(kz::tower_split_weight_elems(m.depth));
+            const size_t stem_elems = (size_t)9 * 2 * 8192, layer_elems = (size_t)72 * 2 * 8192;
+            kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, true, packed.data());
+            for (int l = 0; l < 2 * m.depth; l++)
+                kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, false, packed.data() + stem_elems + layer_elems * l);
+            std::vector<float> bias((size_t)(1 + 2 * m.depth) * C);
+            for (int l = 0; l < 1 + 2 * m.depth; l++)
+                for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
+            if (upload(packed.data(), packed.size() * 2, &res32_w)) return 1;
+            if (upload_f32(bias, &res_bias)) return 1;
+        } else if (resident32) {
             std::vector<float> packed(kz::tower32_weight_elems(m.c_in, C, m.depth));
             const size_t stem_elems = (size_t)9 * ((m.c_in + 15) / 16) * 16 * C, layer_elems = (size_t)9 * C * C;
             kz::tower32_pack_weights(m.tower[0].w.data(), C, m.c_in, true, packed.data());
@@ -347,7 +360,7 @@ struct kz_engine {
         return 0;
     }
     std::vector<void *> allocs, pinned;
-    bool resident = false, fused_heads = false, resident32 = false;
+    bool resident = false, fused_heads = false, resident32 = false, split16 = false;
     std::string path;
 
     // activations
@@ -472,8 +485,9 @@ struct kz_engine {
             t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
             t.y = (float *)act[0]; t.ldy = cp; t.batch = batch; t.h = m.h; t.w = m.w; t.channels = m.channels;
             t.depth = m.depth;
-            prof.begin("kz_tower_resident_f32", stream);
-            kz::launch_tower32(t, stream);
+            prof.begin(split16 ? "kz_tower_resident_split" : "kz_tower_resident_f32", stream);
+            if (split16) kz::launch_tower_split(t, stream);
+            else kz::launch_tower32(t, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             tower_out = 0;
@@ -697,7 +711,11 @@ KZ_API void kz_engine_destroy(kz_engine *e) {
 KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, int dtype, kz_engine **out) {
     if (!model || !out) return fail("kz_engine_create: null argument");
     if (max_batch <= 0) return fail("kz_engine_create: max_batch must be positive");
-    if (dtype != KZ_DTYPE_F32 && dtype != KZ_DTYPE_F16) return fail("kz_engine_create: unknown dtype");
+    if (dtype != KZ_DTYPE_F32 && dtype != KZ_DTYPE_F16 && dtype != KZ_DTYPE_F32_SPLIT16)
+        return fail("kz_engine_create: unknown dtype");
+    // KZ_DTYPE_F32_SPLIT16 is the f32 engine with one kernel exchanged: everything below sees KZ_DTYPE_F32
+    const bool split16 = dtype == KZ_DTYPE_F32_SPLIT16;
+    if (split16) dtype = KZ_DTYPE_F32;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev)
@@ -732,15 +750,23 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     // exact-f32 resident launch (the per-layer activation taps of KZ_KEEP_ACTIVATIONS need the per-layer path)
     e->resident32 = kz::tower32_supported(dtype, m.h, m.w, m.channels, m.depth) && m.c_in <= e->cin_p &&
                     !(force && force[0] == '1') && !e->keep;
+    if (split16) {
+        if (!kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in) || e->cin_p != 32)
+            return fail("kz_engine_create: KZ_DTYPE_F32_SPLIT16 needs an 8x8 board with 256 tower channels and at most 32 "
+                        "input planes");
+        e->split16 = e->resident32 = true;  // same tensors in and out as the exact-f32 resident launch
+    }
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
+              : e->split16   ? "tower_resident_split16"
               : e->resident32 ? "tower_resident_f32"
               : board_conv   ? "board_conv_f16"
                              : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto key = std::make_tuple(model->m.get(), device, dtype, e->resident || e->resident32, e->fused_heads, board_conv);
+        auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0), e->resident || e->resident32,
+                                   e->fused_heads, board_conv);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) e->wts = it->second.lock();
         if (!e->wts) {
@@ -748,7 +774,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->device = device;
             w->dtype = dtype;
             w->use_board_conv = board_conv;
-            if (w->build(m, e->resident, e->fused_heads, e->resident32)) return 1;
+            if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16)) return 1;
             g_cache[key] = w;
             e->wts = w;
         }

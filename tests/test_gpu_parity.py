@@ -310,10 +310,22 @@ def test_config_c1_f32_vs_oracle_sample(dev, chess_full):
     pick = np.array([3, 100, 254])
     dense = O.encode_input_full(bits[pick], scalars_in[pick], net.n_scalar, net.n_bool, net.h, net.w)
     s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
-    eng = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F32)
+    model = capi.Model(blob=blob)
+    eng = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F32)
     s, p = eng.eval_packed(bits, scalars_in)
     assert_f32(s[pick], s_ref, "scalars")
     assert_f32(p[pick], p_ref, "policy")
+    # the same configuration through the split-f16 tower (three f16 MFMAs per product): the same 1e-4, all 256 boards
+    # against the exact-f32 launch and the sample against the oracle
+    split = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F32_SPLIT16)
+    assert split.tower_path == "tower_resident_split16"
+    s2, p2 = split.eval_packed(bits, scalars_in)
+    print(f"split16 20x256: vs oracle max |d| {max(np.abs(s2[pick] - s_ref).max(), np.abs(p2[pick] - p_ref).max()):.2e}; "
+          f"vs exact f32 {max(np.abs(s2 - s).max(), np.abs(p2 - p).max()):.2e}")
+    assert_f32(s2[pick], s_ref, "split16 scalars")
+    assert_f32(p2[pick], p_ref, "split16 policy")
+    assert_f32(s2, s, "split16 vs exact f32 scalars")
+    assert_f32(p2, p, "split16 vs exact f32 policy")
 
 
 def test_full_size_properties(dev, chess_full):
@@ -478,6 +490,36 @@ def test_resident_f32_tower_vs_oracle(dev, game, depth, channels, head, batches)
         sg, pg = gen.eval_packed(bits, scalars_in)
         assert_f32(sg, s, f"generic vs resident scalars b={batch}")
         assert_f32(pg, p, f"generic vs resident policy b={batch}")
+
+
+@pytest.mark.parametrize("depth,head,batches", [(1, "attention", (1, 3)), (3, "attention", (5, 17)), (2, "dense", (4,))])
+def test_split16_tower_vs_oracle(dev, depth, head, batches):
+    """KZ_DTYPE_F32_SPLIT16 (kz_tower_resident_split: (hi, lo) f16 pairs, three MFMAs per product): the SAME <= 1e-4
+    against the oracle as the exact-f32 path, which it also agrees with; shapes it does not take are refused."""
+    if head == "dense":
+        blob = O.load_blob("chess_2x32_dense_h")  # 32 channels: not a shape of the split kernel
+        with pytest.raises(capi.KzError, match="SPLIT16 needs"):
+            capi.Engine(capi.Model(blob=blob), dev, 4, capi.KZ_DTYPE_F32_SPLIT16)
+        return
+    blob = synth.random_model("chess", depth, 256, head, seed=81 + depth)
+    net = O.OracleNet(blob)
+    model = capi.Model(blob=blob)
+    eng = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32_SPLIT16)
+    assert eng.tower_path == "tower_resident_split16"
+    exact = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32)
+    assert exact.tower_path == "tower_resident_f32"
+    for batch in batches:
+        bits, scalars_in = synth.random_boards("chess", batch, seed=82 + batch)
+        dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+        s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+        s, p = eng.eval_packed(bits, scalars_in)
+        print(f"split16 depth {depth} b={batch}: max |d scalars| {np.abs(s - s_ref).max():.2e}, "
+              f"max |d policy| {np.abs(p - p_ref).max():.2e}")
+        assert_f32(s, s_ref, f"scalars b={batch}")
+        assert_f32(p, p_ref, f"policy b={batch}")
+        se, pe = exact.eval_packed(bits, scalars_in)
+        assert_f32(se, s, f"exact f32 vs split16 scalars b={batch}")
+        assert_f32(pe, p, f"exact f32 vs split16 policy b={batch}")
 
 
 @pytest.mark.parametrize("game,channels,head,batch", [
