@@ -195,8 +195,8 @@ struct DeviceWeights {
 
         if (split16) {
             // (hi, lo) f16 pairs in fragment order: 9 stem k-steps, then 72 per tower convolution, 32 KB each
-            std::vector<uint16_t> packed(kz::tower_split_weight_elems(m.depth));
-            const size_t stem_elems = (size_t)9 * 2 * 8192, layer_elems = (size_t)72 * 2 * 8192;
+            std::vector<uint16_t> packed(kz::tower_split_weight_elems(C, m.depth));
+            const size_t step_elems = (size_t)2 * C * 32, stem_elems = 9 * step_elems, layer_elems = (size_t)9 * (C / 32) * step_elems;
             kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, true, packed.data());
             for (int l = 0; l < 2 * m.depth; l++)
                 kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, false, packed.data() + stem_elems + layer_elems * l);
@@ -752,8 +752,8 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                     !(force && force[0] == '1') && !e->keep;
     if (split16) {
         if (!kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in) || e->cin_p != 32)
-            return fail("kz_engine_create: KZ_DTYPE_F32_SPLIT16 needs an 8x8 board with 256 tower channels and at most 32 "
-                        "input planes");
+            return fail("kz_engine_create: KZ_DTYPE_F32_SPLIT16 needs 256 tower channels on a board of at most 64 squares or "
+                        "128 channels on at most 96 squares, and at most 32 input planes");
         e->split16 = e->resident32 = true;  // same tensors in and out as the exact-f32 resident launch
     }
     e->path = e->fused_heads ? "tower_resident_f16+heads"

@@ -1,15 +1,16 @@
 // kz_tower_split.hip — board-resident ResTower with f32-EQUIVALENT results on the f16 matrix cores: every activation and
 // every weight is carried as a pair of f16 values (hi = f16(v), lo = f16(v - hi): 22 significant bits) and every product
 // is three MFMAs, hi*hi + hi*lo + lo*hi, accumulated in f32 (the lo*lo term is below 2^-22 of the product).  Same
-// organisation as the f16 launch (kz_tower.hip) at one board per workgroup: the residual stream X and the mid activation
+// organisation as the resident launches (kz_tower.hip, kz_tower_f32.hip): the residual stream X and the mid activation
 // Y live in LDS for the whole tower — as two images each, hi and lo — and the weights stream from L2 straight into MFMA
 // A-fragment registers, 32 KB per k-step (hi fragments, then lo fragments).
 //
 // Why: the exact-f32 launch (kz_tower_f32.hip, v_mfma_f32_16x16x4_f32) is bound by the f32 MFMA rate, 157 TFLOP/s; three
 // f16 MFMAs per product run at 2500 / 3 = 833 TFLOP/s.  The results agree with the CPU oracle within the same 1e-4 as
 // the exact-f32 path (tests/test_gpu_parity.py), which the plain f16 path cannot (it rounds the residual stream to 11
-// bits per layer).  8x8 boards, 256 channels; input and output are the f32 tensors of the f32 engine path, so the
-// encode kernel in front and the generic f32 head kernels behind are unchanged.
+// bits per layer).  Shapes of the exact-f32 launch (256 channels on <= 64 squares, 128 channels on <= 96); input and
+// output are the f32 tensors of the f32 engine path, so the encode kernel in front and the generic f32 head kernels
+// behind are unchanged.
 //
 // Arithmetic follows python/lib/model/post_act.py:201-239 with Conv+BN folded on the host (kz_model.cpp).
 #include <vector>
@@ -25,29 +26,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int C = 256;
-constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row (see kz_tower.hip)
-constexpr int KSTEPS = 72;      // 9 taps x 8 chunks of 32 channels
-constexpr int MT = 4;           // 16-pixel tiles of the board
-constexpr int PF = 4;           // weight ring depth in k-steps (a k-step is 48 MFMAs = 768 cycles)
-constexpr int IMG = 64 * RS;
-// hi block = [X][Y][16 all-zero rows], lo block = the same DELTA bytes later: one address array serves both images of a
-// pair (lo = hi + DELTA, zero rows included), and DELTA is a multiple of 256 B so the bank pattern is the same
-constexpr int XH = 0, YH = IMG, ZH = 2 * IMG, DELTA = 2 * IMG + 16 * RS;
-constexpr int XL = XH + DELTA, ZL = ZH + DELTA;
-static_assert(DELTA % 256 == 0 && ZH % 256 == 0, "slot pattern");
-constexpr int SH = 2 * DELTA, SL = SH + 64 * 64;  // stem input, rows of 64 B (32 channels)
-constexpr int LDS_BYTES = SL + 64 * 64;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int PF = 4;  // weight ring depth in k-steps
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
+// Shapes: C tower channels (256 or 128), NT tiles of 16 pixel rows per workgroup = floor(16 NT / hw) whole boards packed
+// densely (row r = board r / hw, pixel r % hw), as in kz_tower_f32.hip.  Chess: <256, 4> (one board); Ataxx 7x7 8x128:
+// <128, 7> (two boards); Go 9x9 at 128 channels: <128, 6>.
+template <int C, int NT>
+struct Geo {
+    static constexpr int ROWS = NT * 16;
+    static constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row: an odd number of 16-byte slots
+    static constexpr int IMG = ROWS * RS;
+    // hi block = [X][Y][16 all-zero rows], lo block = the same DELTA bytes later: one address array serves both images
+    // of a pair (lo = hi + DELTA, zero rows included); DELTA is a multiple of 256 B so the bank pattern is the same
+    static constexpr int XH = 0, YH = IMG, ZH = 2 * IMG;
+    static constexpr int DELTA = (2 * IMG + 16 * RS + 255) / 256 * 256;
+    static constexpr int SH = 2 * DELTA, SL = SH + ROWS * 64;  // stem input, rows of 64 B (32 channels)
+    static constexpr int LDS_BYTES = SL + ROWS * 64;
+    static constexpr int OT = C / 64;   // 16-channel output tiles per wave
+    static constexpr int G = C / 32;    // k-steps per tap
+    static constexpr int STEP = 2 * 4 * OT * 64;  // uint4 per k-step: [hi | lo][wave 4][ot][lane 64]
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(G % PF == 0, "ring stage of a k-step must not depend on the tap");
+};
+
 struct SplitDev {
-    const float *x0;    // encoded input [batch*64][ldx0] f32
-    const uint4 *w;     // k-steps of [hi | lo][wave 4][nt 4][lane 64] x 16 B: 9 stem k-steps, then 2*depth*72
-    const float *bias;  // [1 + 2*depth][256]
+    const float *x0;    // encoded input [batch*hw][ldx0] f32
+    const uint4 *w;     // k-steps of [hi | lo][wave 4][ot][lane 64] x 16 B: 9 stem k-steps, then 2*depth*9*C/32
+    const float *bias;  // [1 + 2*depth][C]
     const float *post_scale, *post_shift;
-    float *y;           // tower output [batch*64][ldy] f32
-    int ldx0, c_in, ldy, batch, depth;
+    float *y;           // tower output [batch*hw][ldy] f32
+    int ldx0, ldy, batch, depth, h, w_, hw, nb;
+    unsigned inv_w, inv_hw;  // ceil(65536 / w), ceil(65536 / hw): exact quotients for values < 512
 };
 
 __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
@@ -58,98 +68,110 @@ __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
     }
 }
 
+template <int C, int NT>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
+    using L = Geo<C, NT>;
+    constexpr int RS = L::RS, OT = L::OT, G = L::G, DELTA = L::DELTA, XH = L::XH, YH = L::YH, ZH = L::ZH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int fr = lane & 15, kq = lane >> 4;
-    const int board = blockIdx.x;
+    const int board0 = blockIdx.x * a.nb;
+    const int boards = min(a.nb, a.batch - board0);
+    const int rows_valid = boards * a.hw;
     const int layers = 2 * a.depth;
-    const int total_ksteps = layers * KSTEPS;  // of the ring: the 9 stem k-steps in front of them are read directly
+    const int total_ksteps = layers * 9 * G;  // of the ring: the 9 stem k-steps in front of them are read directly
 
     // ---- weight stream: prime PF stages (stage s = k-step g % PF) ----
-    const uint4 *wp_stem = a.w + wave * 256 + lane;
-    const uint4 *wp = wp_stem + (size_t)9 * 2048;
-    auto wload = [&](int gk, int part, int nt) __attribute__((always_inline)) {
-        return wp[(size_t)gk * 2048 + part * 1024 + nt * 64];
+    const uint4 *wp_stem = a.w + wave * OT * 64 + lane;
+    const uint4 *wp = wp_stem + (size_t)9 * L::STEP;
+    auto wload = [&](int gk, int part, int ot) __attribute__((always_inline)) {
+        return wp[(size_t)gk * L::STEP + part * (4 * OT * 64) + ot * 64];
     };
-    uint4 wreg[PF][2][4];
+    uint4 wreg[PF][2][OT];
 #pragma unroll
     for (int s = 0; s < PF; s++)
 #pragma unroll
         for (int part = 0; part < 2; part++)
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) wreg[s][part][nt] = wload(s < total_ksteps ? s : total_ksteps - 1, part, nt);
+            for (int ot = 0; ot < OT; ot++) wreg[s][part][ot] = wload(s < total_ksteps ? s : total_ksteps - 1, part, ot);
     int g = 0;
-    auto ring_take = [&](int stage, h16x8 (&ah)[4], h16x8 (&al)[4]) __attribute__((always_inline)) {
+    auto ring_take = [&](int stage, h16x8 (&ah)[OT], h16x8 (&al)[OT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            ah[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][0][nt]);
-            al[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][1][nt]);
+        for (int ot = 0; ot < OT; ot++) {
+            ah[ot] = *reinterpret_cast<const h16x8 *>(&wreg[stage][0][ot]);
+            al[ot] = *reinterpret_cast<const h16x8 *>(&wreg[stage][1][ot]);
         }
         const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
 #pragma unroll
         for (int part = 0; part < 2; part++)
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) wreg[stage][part][nt] = wload(gn, part, nt);
+            for (int ot = 0; ot < OT; ot++) wreg[stage][part][ot] = wload(gn, part, ot);
     };
 
-    // ---- zero rows and the stem input (f32 -> hi/lo, 32 channels per square) ----
+    // ---- zero rows and the stem input (f32 -> hi/lo, 32 channels per square; rows beyond the batch are zero) ----
     for (int id = tid; id < 16 * RS / 16; id += 256) {
         *reinterpret_cast<uint4 *>(lds + ZH + id * 16) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(lds + ZL + id * 16) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(lds + ZH + DELTA + id * 16) = make_uint4(0, 0, 0, 0);
     }
-    for (int id = tid; id < 64 * 8; id += 256) {  // (square, 4-channel piece)
+    for (int id = tid; id < L::ROWS * 8; id += 256) {  // (row, 4-channel piece)
         const int row = id >> 3, c4 = id & 7;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c4 * 4 < a.ldx0) v = *reinterpret_cast<const f32x4 *>(a.x0 + ((size_t)board * 64 + row) * a.ldx0 + c4 * 4);
+        if (row < rows_valid && c4 * 4 < a.ldx0)
+            v = *reinterpret_cast<const f32x4 *>(a.x0 + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
         h16x4 hi, lo;
         split4(v, hi, lo);
-        *reinterpret_cast<h16x4 *>(lds + SH + row * 64 + c4 * 8) = hi;
-        *reinterpret_cast<h16x4 *>(lds + SL + row * 64 + c4 * 8) = lo;
+        *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = hi;
+        *reinterpret_cast<h16x4 *>(lds + L::SL + row * 64 + c4 * 8) = lo;
+    }
+
+    // Validity of (tile row, tap) as bitmasks: bit nt of okmask[tap] says that for this lane's row of tile nt the tap
+    // lands on the same board
+    unsigned okmask[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int r = nt * 16 + fr;
+        const int b = (int)(((unsigned)r * a.inv_hw) >> 16), q = r - b * a.hw;
+        const unsigned valid = r < rows_valid;
+        const int yy = (int)(((unsigned)q * a.inv_w) >> 16), xx = q - yy * a.w_;
+        const unsigned ym[3] = {(unsigned)(yy >= 1), 1u, (unsigned)(yy <= a.h - 2)};
+        const unsigned xm[3] = {(unsigned)(xx >= 1), 1u, (unsigned)(xx <= a.w_ - 2)};
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) okmask[tap] |= (valid & ym[tap / 3] & xm[tap % 3]) << nt;
     }
     __syncthreads();
 
-    f32x4 acc[4][MT];
-    f32x4 bias_next[4];
+    f32x4 acc[OT][NT];
+    f32x4 bias_next[OT];
     auto fetch_bias = [&](int row) __attribute__((always_inline)) {
         const int l = row <= layers ? row : layers;
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-            bias_next[nt] = *reinterpret_cast<const f32x4 *>(a.bias + l * C + wave * 64 + nt * 16 + kq * 4);
+        for (int ot = 0; ot < OT; ot++)
+            bias_next[ot] = *reinterpret_cast<const f32x4 *>(a.bias + l * C + (wave * OT + ot) * 16 + kq * 4);
     };
     auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int ot = 0; ot < OT; ot++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[nt][mt] = bias_next[nt];
+            for (int nt = 0; nt < NT; nt++) acc[ot][nt] = bias_next[ot];
     };
-    f32x4 post_s[4], post_t[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) {
-        post_s[nt] = f32x4{1.f, 1.f, 1.f, 1.f};
-        post_t[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
 
     // three MFMAs per (output tile, pixel tile): hi*hi + hi*lo + lo*hi
-    auto mfma3 = [&](const h16x8 (&ah)[4], const h16x8 (&al)[4], const h16x8 (&bh)[MT], const h16x8 (&bl)[MT])
+    auto mfma3 = [&](const h16x8 (&ah)[OT], const h16x8 (&al)[OT], const h16x8 (&bh)[NT], const h16x8 (&bl)[NT])
                      __attribute__((always_inline)) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nt], bh[mt], acc[nt][mt], 0, 0, 0);
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt], bl[mt], acc[nt][mt], 0, 0, 0);
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt], bh[mt], acc[nt][mt], 0, 0, 0);
+            for (int ot = 0; ot < OT; ot++) {
+                acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ot], bh[nt], acc[ot][nt], 0, 0, 0);
+                acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ot], bl[nt], acc[ot][nt], 0, 0, 0);
+                acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ot], bh[nt], acc[ot][nt], 0, 0, 0);
             }
     };
-
-    // tap validity per lane: the pixel of tile row fr is (y = 2*mt + (fr>>3), x = fr&7)
-    const bool x_is0 = (lane & 7) == 0, x_is7 = (lane & 7) == 7, yo_is0 = (lane & 8) == 0, yo_is1 = !yo_is0;
-    auto tap_ok = [&](int mt, int dy, int dx) __attribute__((always_inline)) {
-        const bool kill_x = (dx < 0 && x_is0) || (dx > 0 && x_is7);
-        return !(kill_x || (mt == 0 && dy < 0 && yo_is0) || (mt == 3 && dy > 0 && yo_is1));
+    auto ok_of = [&](int tap) __attribute__((always_inline)) {
+        return tap == 0   ? okmask[0] : tap == 1 ? okmask[1] : tap == 2 ? okmask[2] : tap == 3 ? okmask[3]
+               : tap == 4 ? okmask[4] : tap == 5 ? okmask[5] : tap == 6 ? okmask[6] : tap == 7 ? okmask[7] : okmask[8];
     };
 
     // ---- stem: 9 k-steps over the 32 (padded) input channels; conv + bias, no activation (post_act.py:205) ----
@@ -158,42 +180,42 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     fetch_bias(1);
 #pragma nounroll
     for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        h16x8 ah[4], al[4], bh[MT], bl[MT];
+        const int shift = (tap / 3 - 1) * a.w_ + (tap % 3 - 1);
+        const unsigned ok = ok_of(tap);
+        h16x8 ah[OT], al[OT], bh[NT], bl[NT];
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            const uint4 th = wp_stem[(size_t)tap * 2048 + nt * 64], tl = wp_stem[(size_t)tap * 2048 + 1024 + nt * 64];
-            ah[nt] = *reinterpret_cast<const h16x8 *>(&th);
-            al[nt] = *reinterpret_cast<const h16x8 *>(&tl);
+        for (int ot = 0; ot < OT; ot++) {
+            const uint4 th = wp_stem[(size_t)tap * L::STEP + ot * 64], tl = wp_stem[(size_t)tap * L::STEP + 4 * OT * 64 + ot * 64];
+            ah[ot] = *reinterpret_cast<const h16x8 *>(&th);
+            al[ot] = *reinterpret_cast<const h16x8 *>(&tl);
         }
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const int p = mt * 16 + fr;
-            const bool ok = tap_ok(mt, dy, dx);
-            const int off = ok ? (p + dy * 8 + dx) * 64 + kq * 16 : -1;  // stem: natural k (channel = 8 kq + j)
-            bh[mt] = off >= 0 ? *reinterpret_cast<const h16x8 *>(lds + SH + off) : h16x8{};
-            bl[mt] = off >= 0 ? *reinterpret_cast<const h16x8 *>(lds + SL + off) : h16x8{};
+        for (int nt = 0; nt < NT; nt++) {
+            const int off = (nt * 16 + fr + shift) * 64 + kq * 16;  // stem: natural k (channel = 8 kq + j)
+            const bool valid = (ok >> nt) & 1;
+            bh[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + L::SH + off) : h16x8{};
+            bl[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + L::SL + off) : h16x8{};
         }
         mfma3(ah, al, bh, bl);
     }
 
     const int lane_row = fr * RS;
-    const int epi_base = lane_row + (wave * 64 + kq * 4) * 2;
-    // epilogue: [relu]; [+ residual X]; -> (hi, lo) -> the two LDS images at dst
+    const int epi_base = lane_row + ((wave * OT) * 16 + kq * 4) * 2;
+    // epilogue: [relu]; [+ residual X]; -> (hi, lo) -> the image pair at dst_h
     auto epilogue = [&](int dst_h, bool relu, bool residual) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int ot = 0; ot < OT; ot++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                const int off = epi_base + mt * 16 * RS + nt * 32;
-                f32x4 v = acc[nt][mt];
+            for (int nt = 0; nt < NT; nt++) {
+                const int off = epi_base + nt * 16 * RS + ot * 32;
+                f32x4 v = acc[ot][nt];
                 if (relu) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                 }
                 if (residual) {  // added in f32, AFTER the ReLU (post_act.py:227-228)
                     const h16x4 rh = *reinterpret_cast<const h16x4 *>(lds + XH + off);
-                    const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XL + off);
+                    const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] += (float)rh[j] + (float)rl[j];
                 }
@@ -206,59 +228,62 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     epilogue(XH, false, false);
     __syncthreads();
 
-    // ---- convolution passes over the LDS images (channel assignment of a k-step as in kz_tower.hip) ----
-    const int kq_off = 256 * (kq & 1) + 128 * (kq >> 1);
+    // ---- convolution passes over the LDS images.  Channel assignment of a k-step (as in kz_tower.hip): lane group kq
+    // reads the 16-byte piece at kq_off + 16 ch of the row, i.e. channels 8 ch + {0, C/2, C/4, 3C/4}[kq] + j; the weights
+    // are packed with the same assignment ----
+    const int kq_off = C * (kq & 1) + (C / 2) * (kq >> 1);
     const int frag_base = lane_row + kq_off;
-    // T[mt] = LDS address, in the hi block, of this lane's fragment row (pixel shifted by the tap) or of a zero row
-    auto tap_rows = [&](int tap, int src_h, int (&T)[MT]) __attribute__((always_inline)) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int shifted = src_h + frag_base + (dy * 8 + dx) * RS;
-        const int zrow = ZH + ((fr + dy * 8 + dx) & 15) * RS + kq_off;
+    // T[nt] = LDS address, in the hi block, of this lane's fragment row (pixel shifted by the tap) or of a zero row
+    auto tap_rows = [&](int tap, int src_h, int (&T)[NT]) __attribute__((always_inline)) {
+        const int shift = (tap / 3 - 1) * a.w_ + (tap % 3 - 1);
+        const unsigned ok = ok_of(tap);
+        const int shifted = src_h + frag_base + shift * RS;
+        const int zrow = ZH + ((fr + shift) & 15) * RS + kq_off;
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) T[mt] = tap_ok(mt, dy, dx) ? shifted + mt * 16 * RS : zrow;
+        for (int nt = 0; nt < NT; nt++) T[nt] = ((ok >> nt) & 1) ? shifted + nt * 16 * RS : zrow;
     };
     auto conv_3x3 = [&](int src_h) __attribute__((always_inline)) {
-        int T[MT], Tn[MT];
-        h16x8 bh[2][MT], bl[2][MT];
+        int T[NT], Tn[NT];
+        h16x8 bh[2][NT], bl[2][NT];
         tap_rows(0, src_h, T);
         auto rd = [&](int t, int extra) __attribute__((always_inline)) { return *reinterpret_cast<const h16x8 *>(lds + t + extra); };
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            bh[0][mt] = rd(T[mt], 0);
-            bl[0][mt] = rd(T[mt], DELTA);
+        for (int nt = 0; nt < NT; nt++) {
+            bh[0][nt] = rd(T[nt], 0);
+            bl[0][nt] = rd(T[nt], DELTA);
         }
 #pragma nounroll
         for (int tap = 0; tap < 9; tap++) {
             tap_rows(tap + 1 < 9 ? tap + 1 : tap, src_h, Tn);
 #pragma unroll
-            for (int ch = 0; ch < 8; ch++) {
+            for (int ch = 0; ch < G; ch++) {
                 const int stage = ch & (PF - 1), cur = ch & 1, nxt = cur ^ 1;
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    bh[nxt][mt] = ch < 7 ? rd(T[mt], (ch + 1) * 16) : rd(Tn[mt], 0);
-                    bl[nxt][mt] = ch < 7 ? rd(T[mt], DELTA + (ch + 1) * 16) : rd(Tn[mt], DELTA);
+                for (int nt = 0; nt < NT; nt++) {
+                    bh[nxt][nt] = ch < G - 1 ? rd(T[nt], (ch + 1) * 16) : rd(Tn[nt], 0);
+                    bl[nxt][nt] = ch < G - 1 ? rd(T[nt], DELTA + (ch + 1) * 16) : rd(Tn[nt], DELTA);
                 }
-                h16x8 ah[4], al[4];
+                h16x8 ah[OT], al[OT];
                 ring_take(stage, ah, al);
                 mfma3(ah, al, bh[cur], bl[cur]);
-                // every memory instruction in the shadow of an MFMA: the 8 ring refills, the 8 fragment reads, then
-                // the remaining MFMAs back to back
+                // every memory instruction in the shadow of an MFMA: the ring refills, the fragment reads, then the
+                // remaining MFMAs back to back
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
+                for (int i = 0; i < 2 * OT; i++) {
                     __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < 2 * MT; i++) {
+                for (int i = 0; i < 2 * NT; i++) {
                     __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 3 * 4 * MT - 8 - 2 * MT, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 3 * OT * NT - 2 * OT - 2 * NT, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) T[mt] = Tn[mt];
+            for (int nt = 0; nt < NT; nt++) T[nt] = Tn[nt];
         }
     };
 
@@ -267,14 +292,6 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         const bool is_b = (layer & 1) == 0;  // conv A: X -> Y; conv B: Y -> X (+ residual)
         init_acc();
         fetch_bias(layer + 1);
-        if (layer == layers) {
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                const int oc = wave * 64 + nt * 16 + kq * 4;
-                post_s[nt] = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-                post_t[nt] = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-            }
-        }
         conv_3x3(is_b ? YH : XH);
         if (!is_b) {
             epilogue(YH, true, false);
@@ -283,47 +300,80 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         } else {
             // last layer: ReLU, residual, final BN -> f32 rows of the tower output in global memory
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++)
+            for (int ot = 0; ot < OT; ot++) {
+                const int oc = (wave * OT + ot) * 16 + kq * 4;
+                const f32x4 ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
+                const f32x4 pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    const int off = epi_base + mt * 16 * RS + nt * 32;
-                    f32x4 v = acc[nt][mt];
+                for (int nt = 0; nt < NT; nt++) {
+                    const int off = epi_base + nt * 16 * RS + ot * 32;
+                    f32x4 v = acc[ot][nt];
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                     const h16x4 rh = *reinterpret_cast<const h16x4 *>(lds + XH + off);
-                    const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XL + off);
+                    const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] += (float)rh[j] + (float)rl[j];
-                    v = v * post_s[nt] + post_t[nt];
-                    *reinterpret_cast<f32x4 *>(a.y + ((size_t)board * 64 + mt * 16 + fr) * a.ldy + wave * 64 + nt * 16 + kq * 4) = v;
+                    v = v * ps + pt;
+                    const int r = nt * 16 + fr;
+                    if (r < rows_valid) *reinterpret_cast<f32x4 *>(a.y + ((size_t)board0 * a.hw + r) * a.ldy + oc) = v;
                 }
+            }
         }
         __syncthreads();
     }
 }
 
+int split_tiles_for(int hw, int channels) {
+    if (channels == 256) return hw <= 64 ? 4 : 0;
+    if (channels == 128) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
+    return 0;
+}
+
+template <int C, int NT>
+void launch(const SplitDev &d, int grid, hipStream_t stream) {
+    static thread_local unsigned long long done_mask = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((done_mask >> (dev & 63)) & 1)) {
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Geo<C, NT>::LDS_BYTES);
+        done_mask |= 1ull << (dev & 63);
+    }
+    kz_tower_resident_split<C, NT><<<grid, 256, Geo<C, NT>::LDS_BYTES, stream>>>(d);
+}
+
 }  // namespace
 
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in) {
-    return h == 8 && w == 8 && channels == C && depth >= 1 && c_in <= 32;
+    return depth >= 1 && c_in <= 32 && h >= 2 && w >= 2 && w <= 32 && split_tiles_for(h * w, channels) != 0;
 }
 
-size_t tower_split_weight_elems(int depth) { return ((size_t)9 + (size_t)2 * depth * KSTEPS) * 2 * 8192; }  // f16 elements
+int tower_split_boards_per_workgroup(int h, int w, int channels) {
+    const int nt = split_tiles_for(h * w, channels);
+    return nt ? nt * 16 / (h * w) : 0;
+}
 
-// OIHW f32 (BN folded) -> k-steps of [hi | lo][wave 4][nt 4][lane 64][8] f16; element j of lane (fr, kq) of (wave, nt) is
-// W[oc = 64*wave + 16*nt + fr][channel][tap], channel = 8*chunk + {0,128,64,192}[kq] + j for a tower layer (one k-step
-// per tap and chunk) and 8*kq + j for the stem (one k-step per tap, 32 padded input channels).
+size_t tower_split_weight_elems(int channels, int depth) {  // f16 elements
+    const size_t step = (size_t)2 * channels * 32;  // [hi | lo][channels][32]
+    return ((size_t)9 + (size_t)2 * depth * 9 * (channels / 32)) * step;
+}
+
+// OIHW f32 (BN folded) -> k-steps of [hi | lo][wave 4][ot C/64][lane 64][8] f16; element j of lane (fr, kq) of (wave, ot)
+// is W[oc = 16*(wave*C/64 + ot) + fr][channel][tap], channel = 8*chunk + {0, C/2, C/4, 3C/4}[kq] + j for a tower layer (one
+// k-step per tap and chunk of 32 channels) and 8*kq + j for the stem (one k-step per tap, 32 padded input channels).
 void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, uint16_t *dst) {
-    static const int kq_base[4] = {0, 128, 64, 192};
-    const int nchunk = stem ? 1 : 8;
+    const int kq_base[4] = {0, cout / 2, cout / 4, 3 * cout / 4};  // tower layers: cin == cout
+    const int nchunk = stem ? 1 : cin / 32, ot_n = cout / 64;
+    const size_t part = (size_t)cout * 32;  // f16 elements of the hi (or lo) half of a k-step
     for (int tap = 0; tap < 9; tap++)
         for (int chunk = 0; chunk < nchunk; chunk++) {
-            uint16_t *step = dst + ((size_t)tap * nchunk + chunk) * 2 * 8192;
+            uint16_t *step = dst + ((size_t)tap * nchunk + chunk) * 2 * part;
             for (int wave = 0; wave < 4; wave++)
-                for (int nt = 0; nt < 4; nt++)
+                for (int ot = 0; ot < ot_n; ot++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int j = 0; j < 8; j++) {
-                            const int oc = 64 * wave + 16 * nt + (lane & 15);
+                            const int oc = 16 * (wave * ot_n + ot) + (lane & 15);
                             const int kq = lane >> 4;
                             const int ch = stem ? 8 * kq + j : 8 * chunk + kq_base[kq] + j;
                             float v = 0.0f;
@@ -332,9 +382,9 @@ void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, u
                             uint16_t hb, lb;
                             __builtin_memcpy(&hb, &hi, 2);
                             __builtin_memcpy(&lb, &lo, 2);
-                            const size_t e = (((size_t)wave * 4 + nt) * 64 + lane) * 8 + j;
+                            const size_t e = (((size_t)wave * ot_n + ot) * 64 + lane) * 8 + j;
                             step[e] = hb;
-                            step[8192 + e] = lb;
+                            step[part + e] = lb;
                         }
         }
 }
@@ -343,7 +393,6 @@ void launch_tower_split(const Tower32Args &t, hipStream_t stream) {
     SplitDev d{};
     d.x0 = t.x0;
     d.ldx0 = t.ldx0;
-    d.c_in = t.c_in;
     d.w = static_cast<const uint4 *>(t.weights);
     d.bias = t.bias;
     d.post_scale = t.post_scale;
@@ -352,14 +401,18 @@ void launch_tower_split(const Tower32Args &t, hipStream_t stream) {
     d.ldy = t.ldy;
     d.batch = t.batch;
     d.depth = t.depth;
-    static thread_local unsigned long long done_mask = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((done_mask >> (dev & 63)) & 1)) {
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident_split, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        done_mask |= 1ull << (dev & 63);
-    }
-    kz_tower_resident_split<<<t.batch, 256, LDS_BYTES, stream>>>(d);
+    d.h = t.h;
+    d.w_ = t.w;
+    d.hw = t.h * t.w;
+    const int nt = split_tiles_for(d.hw, t.channels);
+    d.nb = nt * 16 / d.hw;
+    d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
+    d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
+    const int grid = (t.batch + d.nb - 1) / d.nb;
+    if (t.channels == 256) launch<256, 4>(d, grid, stream);
+    else if (nt == 7) launch<128, 7>(d, grid, stream);
+    else if (nt == 6) launch<128, 6>(d, grid, stream);
+    else launch<128, 4>(d, grid, stream);
 }
 
 }  // namespace kz

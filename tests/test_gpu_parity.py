@@ -492,16 +492,23 @@ def test_resident_f32_tower_vs_oracle(dev, game, depth, channels, head, batches)
         assert_f32(pg, p, f"generic vs resident policy b={batch}")
 
 
-@pytest.mark.parametrize("depth,head,batches", [(1, "attention", (1, 3)), (3, "attention", (5, 17)), (2, "dense", (4,))])
-def test_split16_tower_vs_oracle(dev, depth, head, batches):
+@pytest.mark.parametrize("game,depth,channels,head,batches", [
+    ("chess", 1, 256, "attention", (1, 3)),           # one board per workgroup
+    ("chess", 3, 256, "attention", (5, 17)),
+    ("ataxx-7", 8, 128, "ataxx_conv", (1, 2, 13)),    # BASELINE configs[1]'s network: two boards per workgroup, ragged
+    ("chess", 2, 128, "attention", (3,)),             # 128 channels on an 8x8 board
+    ("go-9", 2, 128, "conv", (3,)),                   # 81 pixels: six tiles
+    ("chess", 2, 32, "dense", (4,)),                  # not a shape of the kernel
+])
+def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     """KZ_DTYPE_F32_SPLIT16 (kz_tower_resident_split: (hi, lo) f16 pairs, three MFMAs per product): the SAME <= 1e-4
     against the oracle as the exact-f32 path, which it also agrees with; shapes it does not take are refused."""
     if head == "dense":
-        blob = O.load_blob("chess_2x32_dense_h")  # 32 channels: not a shape of the split kernel
+        blob = O.load_blob("chess_2x32_dense_h")  # 32 channels
         with pytest.raises(capi.KzError, match="SPLIT16 needs"):
             capi.Engine(capi.Model(blob=blob), dev, 4, capi.KZ_DTYPE_F32_SPLIT16)
         return
-    blob = synth.random_model("chess", depth, 256, head, seed=81 + depth)
+    blob = synth.random_model(game, depth, channels, head, seed=81 + depth)
     net = O.OracleNet(blob)
     model = capi.Model(blob=blob)
     eng = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32_SPLIT16)
@@ -509,11 +516,11 @@ def test_split16_tower_vs_oracle(dev, depth, head, batches):
     exact = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32)
     assert exact.tower_path == "tower_resident_f32"
     for batch in batches:
-        bits, scalars_in = synth.random_boards("chess", batch, seed=82 + batch)
+        bits, scalars_in = synth.random_boards(game, batch, seed=82 + batch)
         dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
         s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
         s, p = eng.eval_packed(bits, scalars_in)
-        print(f"split16 depth {depth} b={batch}: max |d scalars| {np.abs(s - s_ref).max():.2e}, "
+        print(f"split16 {game} {depth}x{channels} b={batch}: max |d scalars| {np.abs(s - s_ref).max():.2e}, "
               f"max |d policy| {np.abs(p - p_ref).max():.2e}")
         assert_f32(s, s_ref, f"scalars b={batch}")
         assert_f32(p, p_ref, f"policy b={batch}")
