@@ -60,6 +60,7 @@ struct DevConv {  // packed for kz_conv_igemm: [k*k][cout_p][cin_p] in T, bias f
     float *b = nullptr;
     int cin_p = 0, cout_p = 0, cout = 0, k = 1;
     void *bw = nullptr;  // instead of w: packed for kz_board_conv_f16 (3x3, f16, channels % 64 == 0)
+    void *sw = nullptr;  // in addition to w: (hi, lo) f16 pairs for kz_conv1x1_split (1x1 head convolutions, split16)
 };
 
 struct DeviceWeights {
@@ -137,6 +138,11 @@ struct DeviceWeights {
                 for (int t = 0; t < taps; t++)
                     flat[((size_t)t * d.cout_p + o) * d.cin_p + i] = cv.w[((size_t)o * cv.cin + i) * taps + t];
         if (upload_matrix(flat, taps * d.cout_p, d.cin_p, taps * d.cout_p, d.cin_p, &d.w)) return 1;
+        if (split16 && cv.k == 1 && kz::conv1x1_split_supported(d.cin_p, d.cout_p)) {
+            std::vector<uint16_t> packed(kz::conv1x1_split_weight_elems(d.cin_p, d.cout_p));
+            kz::conv1x1_split_pack_weights(cv.w.data(), cv.cout, cv.cin, d.cout_p, d.cin_p, packed.data());
+            if (upload(packed.data(), packed.size() * 2, &d.sw)) return 1;
+        }
         std::vector<float> b(d.cout_p, 0.0f);
         for (int o = 0; o < cv.cout; o++) b[o] = cv.b[o];
         return upload_f32(b, &d.b);
@@ -429,6 +435,17 @@ struct kz_engine {
             b.rowmap = wts->bc_rowmap; b.halo = wts->bc_halo; b.n_halo = wts->bc_n_halo;
             prof.begin("kz_board_conv_f16", stream);
             kz::launch_board_conv(b, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        if (w.sw && split16 && y && !res && !post && !y32 && ldx >= w.cin_p) {  // 1x1 head convolution behind the split tower
+            kz::Conv1x1SplitArgs c{};
+            c.x = (const float *)x; c.ldx = ldx; c.weights = w.sw; c.bias = w.b; c.y = (float *)y; c.ldy = ldy;
+            c.M = M; c.cin_p = w.cin_p; c.cout_p = w.cout_p; c.relu = relu;
+            c.group = group; c.src_group = src_group; c.src_off = src_off;
+            prof.begin("kz_conv1x1_split", stream);
+            kz::launch_conv1x1_split(c, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             return 0;

@@ -145,6 +145,21 @@ size_t tower_split_weight_elems(int channels, int depth);  // f16 elements
 void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, uint16_t *dst);
 void launch_tower_split(const Tower32Args &a, hipStream_t stream);
 
+// ---- 1x1 convolution in the same split arithmetic (the head convolutions behind the split tower), f32 in and out:
+// y[r][0..cout_p) = [relu](bias + W x[row(r)]), row(r) = (r / group) * src_group + src_off + r % group ----
+struct Conv1x1SplitArgs {
+    const float *x;
+    int ldx;
+    const void *weights;  // conv1x1_split_pack_weights
+    const float *bias;    // [cout_p]
+    float *y;
+    int ldy, M, cin_p, cout_p, relu, group, src_group, src_off;
+};
+bool conv1x1_split_supported(int cin_p, int cout_p);
+size_t conv1x1_split_weight_elems(int cin_p, int cout_p);
+void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, int cin_p, uint16_t *dst);
+void launch_conv1x1_split(const Conv1x1SplitArgs &a, hipStream_t stream);
+
 // ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----
 // Requirements: f16, h*w <= 64, channels == 256 (cp), any depth >= 1.
 struct TowerArgs {

@@ -343,6 +343,110 @@ void launch(const SplitDev &d, int grid, hipStream_t stream) {
     kz_tower_resident_split<C, NT><<<grid, 256, Geo<C, NT>::LDS_BYTES, stream>>>(d);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution (a GEMM over pixel rows) in the same split arithmetic, for the head convolutions behind the split
+// tower: y[r][oc] = bias[oc] + sum_c W[oc][c] * x[row(r)][c], f32 in and out.  A workgroup stages 64 rows of the f32
+// input as (hi, lo) images in LDS and runs passes of 64 * OT output channels over them (wave w: OT 16-channel tiles x the
+// four row tiles), the weights read from L2 in fragment order one 32-channel chunk ahead.
+struct Conv1x1SplitDev {
+    const float *x;
+    const uint4 *w;     // [pass][chunk cin/32][hi | lo][wave 4][ot OT][lane 64] x 16 B
+    const float *bias;  // [cout_p]
+    float *y;
+    int ldx, ldy, M, cin, cout_p, relu, group, src_group, src_off;
+};
+
+template <int OT>
+__global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int fr = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * 64;
+    const int RS = a.cin * 2 + 16, LO = 64 * RS;  // hi image, then lo image
+    const int chunks = a.cin / 32;
+
+    // stage 64 rows: f32 -> (hi, lo); rows beyond M are zero
+    const int pieces = a.cin / 4;
+    for (int id = tid; id < 64 * pieces; id += 256) {
+        const int r = id / pieces, c4 = id - r * pieces;
+        const int orow = row0 + r;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (orow < a.M) {
+            const int b = orow / a.group, q = orow - b * a.group;
+            v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)b * a.src_group + a.src_off + q) * a.ldx + c4 * 4);
+        }
+        h16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<h16x4 *>(lds + r * RS + c4 * 8) = hi;
+        *reinterpret_cast<h16x4 *>(lds + LO + r * RS + c4 * 8) = lo;
+    }
+    __syncthreads();
+
+    const int frag = fr * RS + kq * 16;  // natural k: chunk c covers channels [32 c, 32 c + 32), 8 per lane group
+    const int passes = a.cout_p / (64 * OT);
+    const size_t step = (size_t)2 * 4 * OT * 64;  // uint4 per (pass, chunk)
+    for (int pass = 0; pass < passes; pass++) {
+        const uint4 *wp = a.w + (size_t)pass * chunks * step + (wave * OT) * 64 + lane;
+        const int oc0 = pass * 64 * OT + wave * OT * 16 + kq * 4;
+        f32x4 acc[OT][4];
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + oc0 + ot * 16);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) acc[ot][mt] = b;
+        }
+        uint4 wh[2][OT], wl[2][OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++) {
+            wh[0][ot] = wp[ot * 64];
+            wl[0][ot] = wp[4 * OT * 64 + ot * 64];
+        }
+#pragma nounroll
+        for (int c = 0; c < chunks; c += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int cc = c + half;
+                if (cc < chunks) {
+                    const int cn = cc + 1 < chunks ? cc + 1 : cc;
+#pragma unroll
+                    for (int ot = 0; ot < OT; ot++) {
+                        wh[half ^ 1][ot] = wp[(size_t)cn * step + ot * 64];
+                        wl[half ^ 1][ot] = wp[(size_t)cn * step + 4 * OT * 64 + ot * 64];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) {
+                        const h16x8 bh = *reinterpret_cast<const h16x8 *>(lds + frag + mt * 16 * RS + cc * 64);
+                        const h16x8 bl = *reinterpret_cast<const h16x8 *>(lds + LO + frag + mt * 16 * RS + cc * 64);
+#pragma unroll
+                        for (int ot = 0; ot < OT; ot++) {
+                            const h16x8 ah = *reinterpret_cast<const h16x8 *>(&wh[half][ot]);
+                            const h16x8 al = *reinterpret_cast<const h16x8 *>(&wl[half][ot]);
+                            acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[ot][mt], 0, 0, 0);
+                            acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[ot][mt], 0, 0, 0);
+                            acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[ot][mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const int r = row0 + mt * 16 + fr;
+                f32x4 v = acc[ot][mt];
+                if (a.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+                }
+                if (r < a.M) *reinterpret_cast<f32x4 *>(a.y + (size_t)r * a.ldy + oc0 + ot * 16) = v;
+            }
+    }
+}
+
 }  // namespace
 
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in) {
@@ -413,6 +517,75 @@ void launch_tower_split(const Tower32Args &t, hipStream_t stream) {
     else if (nt == 7) launch<128, 7>(d, grid, stream);
     else if (nt == 6) launch<128, 6>(d, grid, stream);
     else launch<128, 4>(d, grid, stream);
+}
+
+// ---- 1x1 convolution in split arithmetic (head convolutions behind the split tower) ----
+static int conv1x1_split_ot(int cout_p) { return cout_p % 256 == 0 ? 4 : cout_p % 128 == 0 ? 2 : cout_p % 64 == 0 ? 1 : 0; }
+
+bool conv1x1_split_supported(int cin_p, int cout_p) {
+    return cin_p % 32 == 0 && cin_p >= 32 && cin_p <= 512 && conv1x1_split_ot(cout_p) != 0;
+}
+
+size_t conv1x1_split_weight_elems(int cin_p, int cout_p) { return (size_t)2 * cin_p * cout_p; }  // f16 elements
+
+// [cout_p][cin_p] f32 (zero padded) -> [pass][chunk][hi | lo][wave 4][ot][lane 64][8] f16: element j of lane (fr, kq) is
+// W[oc = 64*OT*pass + 16*(wave*OT + ot) + fr][channel = 32*chunk + 8*kq + j]
+void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, int cin_p, uint16_t *dst) {
+    const int ot_n = conv1x1_split_ot(cout_p), passes = cout_p / (64 * ot_n), chunks = cin_p / 32;
+    const size_t part = (size_t)4 * ot_n * 64 * 8;
+    for (int pass = 0; pass < passes; pass++)
+        for (int chunk = 0; chunk < chunks; chunk++) {
+            uint16_t *step = dst + ((size_t)pass * chunks + chunk) * 2 * part;
+            for (int wave = 0; wave < 4; wave++)
+                for (int ot = 0; ot < ot_n; ot++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const int oc = 64 * ot_n * pass + 16 * (wave * ot_n + ot) + (lane & 15);
+                            const int ch = 32 * chunk + 8 * (lane >> 4) + j;
+                            float v = 0.0f;
+                            if (oc < cout && ch < cin) v = w[(size_t)oc * cin + ch];
+                            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                            uint16_t hb, lb;
+                            __builtin_memcpy(&hb, &hi, 2);
+                            __builtin_memcpy(&lb, &lo, 2);
+                            const size_t e = (((size_t)wave * ot_n + ot) * 64 + lane) * 8 + j;
+                            step[e] = hb;
+                            step[part + e] = lb;
+                        }
+        }
+}
+
+void launch_conv1x1_split(const Conv1x1SplitArgs &t, hipStream_t stream) {
+    Conv1x1SplitDev d{};
+    d.x = t.x;
+    d.w = static_cast<const uint4 *>(t.weights);
+    d.bias = t.bias;
+    d.y = t.y;
+    d.ldx = t.ldx;
+    d.ldy = t.ldy;
+    d.M = t.M;
+    d.cin = t.cin_p;
+    d.cout_p = t.cout_p;
+    d.relu = t.relu;
+    d.group = t.group;
+    d.src_group = t.src_group;
+    d.src_off = t.src_off;
+    const int lds_bytes = 2 * 64 * (t.cin_p * 2 + 16);
+    const int grid = (t.M + 63) / 64;
+    const int ot = conv1x1_split_ot(t.cout_p);
+    auto go = [&](auto kernel) {
+        static thread_local unsigned long long done_mask = 0;  // per instantiation
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((done_mask >> (dev & 63)) & 1)) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done_mask |= 1ull << (dev & 63);
+        }
+        kernel<<<grid, 256, lds_bytes, stream>>>(d);
+    };
+    if (ot == 4) go(kz_conv1x1_split<4>);
+    else if (ot == 2) go(kz_conv1x1_split<2>);
+    else go(kz_conv1x1_split<1>);
 }
 
 }  // namespace kz
