@@ -44,6 +44,8 @@ pub struct KzModelInfo {
 
 pub const KZ_DTYPE_F32: c_int = 0;
 pub const KZ_DTYPE_F16: c_int = 1;
+/// f32 tensors and the same <= 1e-4 parity as KZ_DTYPE_F32, the tower's products as three f16 MFMAs on (hi, lo) pairs
+pub const KZ_DTYPE_F32_SPLIT16: c_int = 2;
 
 #[link(name = "kzhip")]
 extern "C" {
