@@ -6,7 +6,10 @@ CASES = [("chess", 20, 256, "attention", 256, capi.KZ_DTYPE_F16, 200),
          ("chess", 4, 256, "attention", 256, capi.KZ_DTYPE_F32, 50),
          ("ataxx-7", 8, 128, "ataxx_conv", 256, capi.KZ_DTYPE_F32, 200),
          ("go-19", 4, 256, "conv", 512, capi.KZ_DTYPE_F16, 50),
-         ("go-9", 4, 128, "conv", 512, capi.KZ_DTYPE_F16, 100)]
+         ("go-9", 4, 128, "conv", 512, capi.KZ_DTYPE_F16, 100),
+         ("chess", 4, 256, "attention", 255, capi.KZ_DTYPE_F32_SPLIT16, 100),
+         ("ataxx-7", 8, 128, "ataxx_conv", 255, capi.KZ_DTYPE_F32_SPLIT16, 200),
+         ("chess", 3, 256, "attention", 255, capi.KZ_DTYPE_F16, 200)]
 bad = 0
 for game, depth, ch, head, batch, dtype, reps in CASES:
     blob = synth.random_model(game, depth, ch, head, seed=9)
@@ -18,6 +21,6 @@ for game, depth, ch, head, batch, dtype, reps in CASES:
         s, p = engines[r % 2].eval_packed(bits, sc)
         if not (np.array_equal(s, s0) and np.array_equal(p, p0)):
             n_bad += 1
-    print(f"{game} {depth}x{ch} {'f16' if dtype == capi.KZ_DTYPE_F16 else 'f32'} path={engines[0].tower_path}: {n_bad} of {reps} differ")
+    print(f"{game} {depth}x{ch} { {capi.KZ_DTYPE_F16: 'f16', capi.KZ_DTYPE_F32: 'f32', capi.KZ_DTYPE_F32_SPLIT16: 'f32split16'}[dtype] } path={engines[0].tower_path}: {n_bad} of {reps} differ")
     bad += n_bad
 sys.exit(1 if bad else 0)
