@@ -16,7 +16,7 @@ using namespace kz::host;
 
 int main(int argc, char **argv) {
     if (argc < 5) {
-        std::fprintf(stderr, "usage: %s model seconds gpu_threads generator_threads [gpu_batch] [search_batch] [f16|f32]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s model seconds gpu_threads generator_threads [gpu_batch] [search_batch] [f16|f32|f32split16]\n", argv[0]);
         return 2;
     }
     const double seconds = atof(argv[2]);
@@ -25,7 +25,8 @@ int main(int argc, char **argv) {
     const int generators = atoi(argv[4]);
     if (argc > 5) st.gpu_batch_size = (size_t)atoi(argv[5]);
     if (argc > 6) st.search_batch_size = (size_t)atoi(argv[6]);
-    const int dtype = (argc > 7 && std::string(argv[7]) == "f32") ? KZ_DTYPE_F32 : KZ_DTYPE_F16;
+    const std::string dtype_name = argc > 7 ? argv[7] : "f16";
+    const int dtype = dtype_name == "f32" ? KZ_DTYPE_F32 : dtype_name == "f32split16" ? KZ_DTYPE_F32_SPLIT16 : KZ_DTYPE_F16;
     if (argc > 8) st.pipeline_depth = (size_t)atoi(argv[8]);
     if (argc > 9) st.device_decode = atoi(argv[9]) != 0;
 
