@@ -135,7 +135,7 @@ def main():
         # round-robin over (engine, slot); wait for the slot's previous batch before reusing it
         e, slot = i % len(engines), (i // len(engines)) % capi.KZ_ENGINE_SLOTS
         if (e, slot) in inflight:
-            engines[e].wait(slot, inflight.pop((e, slot)))
+            engines[e].wait_view(slot, inflight.pop((e, slot)))  # zero-copy: the results stay in pinned staging
         inflight[(e, slot)] = engines[e].submit_packed(slot, bits, scalars_in)
 
     def step(i):
@@ -146,7 +146,7 @@ def main():
 
     def sync_all():
         for (e, slot), n in list(inflight.items()):
-            engines[e].wait(slot, n)
+            engines[e].wait_view(slot, n)
         inflight.clear()
         for e in engines:
             e.synchronize()
