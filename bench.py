@@ -163,7 +163,7 @@ def main():
     # dominant kernel, timed with HIP events on the engines' own streams over the timed region
     tower_path = engines[0].tower_path
     kname = {"tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
-             "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_split16": "kz_tower_resident_split",
+             "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_split16": "kz_tower_resident_split", "tower_resident_f16g": "kz_tower_resident_f16g",
              "board_conv_f16": "kz_board_conv_f16", "conv_igemm_f16": "kz_conv_igemm_f16",
              "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
     k_ms, k_n = 0.0, 0
@@ -189,7 +189,7 @@ def main():
     tower_flops = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
     if tower_path == "tower_resident_f16+heads":
         flops_per_launch = info.flops_per_eval * B  # one launch = tower + heads for one batch
-    elif tower_path in ("tower_resident_f16", "tower_resident_f32", "tower_resident_split16"):
+    elif tower_path in ("tower_resident_f16", "tower_resident_f32", "tower_resident_split16", "tower_resident_f16g"):
         flops_per_launch = tower_flops * B  # one launch = the whole tower for one batch
     elif tower_path == "board_conv_f16":
         # one launch per 3x3 tower convolution except the stem (which has too few input channels for this kernel)

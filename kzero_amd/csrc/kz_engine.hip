@@ -71,7 +71,7 @@ struct DeviceWeights {
     float *post_scale = nullptr, *post_shift = nullptr;
 
     // resident tower
-    bool resident = false, fused_heads = false, resident32 = false, split16 = false;
+    bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
     void *res32_w = nullptr;  // f32 resident launch (exact f32, or split f16 pairs): one packed weight stream
     void *res_w_stem = nullptr, *res_w_tower = nullptr;
     float *res_bias = nullptr;
@@ -184,9 +184,11 @@ struct DeviceWeights {
     int *bc_rowmap = nullptr;  // kz_board_conv_f16's tile-row map and halo-row list for this board size
     unsigned short *bc_halo = nullptr;
     int bc_n_halo = 0;
-    int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32, bool want_split16) {
+    int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32, bool want_split16,
+              bool want_pairs16) {
         resident32 = want_resident32;
         split16 = want_split16;
+        pairs16 = want_pairs16;  // kz_tower_resident_split without the lo halves: plain f16, generic shapes
         const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
         HIP_TRY(hipSetDevice(device));
         resident = want_resident;
@@ -199,13 +201,15 @@ struct DeviceWeights {
         }
         if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
 
-        if (split16) {
-            // (hi, lo) f16 pairs in fragment order: 9 stem k-steps, then 72 per tower convolution, 32 KB each
-            std::vector<uint16_t> packed(kz::tower_split_weight_elems(C, m.depth));
-            const size_t step_elems = (size_t)2 * C * 32, stem_elems = 9 * step_elems, layer_elems = (size_t)9 * (C / 32) * step_elems;
-            kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, true, packed.data());
+        if (split16 || pairs16) {
+            // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 stem k-steps, then 9*C/32 per convolution
+            std::vector<uint16_t> packed(kz::tower_split_weight_elems(C, m.depth, split16));
+            const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = 9 * step_elems,
+                         layer_elems = (size_t)9 * (C / 32) * step_elems;
+            kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, true, split16, packed.data());
             for (int l = 0; l < 2 * m.depth; l++)
-                kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, false, packed.data() + stem_elems + layer_elems * l);
+                kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, false, split16,
+                                             packed.data() + stem_elems + layer_elems * l);
             std::vector<float> bias((size_t)(1 + 2 * m.depth) * C);
             for (int l = 0; l < 1 + 2 * m.depth; l++)
                 for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
@@ -366,7 +370,7 @@ struct kz_engine {
         return 0;
     }
     std::vector<void *> allocs, pinned;
-    bool resident = false, fused_heads = false, resident32 = false, split16 = false;
+    bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
     std::string path;
 
     // activations
@@ -496,14 +500,15 @@ struct kz_engine {
             tower_out = 0;
             return 0;
         }
-        if (resident32) {
+        if (resident32 || pairs16) {
             kz::Tower32Args t{};
             t.x0 = (const float *)x_in; t.ldx0 = cin_p; t.c_in = m.c_in; t.weights = wts->res32_w; t.bias = wts->res_bias;
             t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
             t.y = (float *)act[0]; t.ldy = cp; t.batch = batch; t.h = m.h; t.w = m.w; t.channels = m.channels;
             t.depth = m.depth;
-            prof.begin(split16 ? "kz_tower_resident_split" : "kz_tower_resident_f32", stream);
+            prof.begin(split16 ? "kz_tower_resident_split" : pairs16 ? "kz_tower_resident_f16g" : "kz_tower_resident_f32", stream);
             if (split16) kz::launch_tower_split(t, stream);
+            else if (pairs16) kz::launch_tower_pairs(t, false, stream);  // f16 tensors behind the same pointers
             else kz::launch_tower32(t, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
@@ -758,7 +763,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                                                m.sh_fc0.out);
     const char *noboard = getenv("KZ_NO_BOARD_CONV");
     // the board-tile kernel needs enough workgroups to fill the chip (two per CU when it is busy)
-    const bool board_conv = !e->resident && !(noboard && noboard[0] == '1') && m.depth >= 1 &&
+    const bool board_conv_ok = !e->resident && !(noboard && noboard[0] == '1') && m.depth >= 1 &&
                             kz::board_conv_supported(dtype, m.h, m.w, m.channels, m.channels) &&
                             kz::board_conv_workgroups(max_batch, m.h, m.w, m.channels) >= 160 &&
                             (size_t)max_batch * m.h * m.w * m.channels * 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
@@ -773,16 +778,25 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                         "128 channels on at most 96 squares, and at most 32 input planes");
         e->split16 = e->resident32 = true;  // same tensors in and out as the exact-f32 resident launch
     }
+    // plain-f16 board-resident tower for the shapes the chess launch (kz_tower.hip) does not take: the split kernel
+    // without its lo halves
+    const char *nopairs = getenv("KZ_NO_RESIDENT_F16G");
+    e->pairs16 = dtype == KZ_DTYPE_F16 && !e->resident && !(force && force[0] == '1') && !e->keep &&
+                 !(nopairs && nopairs[0] == '1') && e->cin_p == 32 &&
+                 kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in);
+    const bool board_conv = board_conv_ok && !e->pairs16;
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
               : e->split16   ? "tower_resident_split16"
               : e->resident32 ? "tower_resident_f32"
+              : e->pairs16   ? "tower_resident_f16g"
               : board_conv   ? "board_conv_f16"
                              : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0), e->resident || e->resident32,
+        auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0),
+                                   e->resident || e->resident32,
                                    e->fused_heads, board_conv);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) e->wts = it->second.lock();
@@ -791,7 +805,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->device = device;
             w->dtype = dtype;
             w->use_board_conv = board_conv;
-            if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16)) return 1;
+            if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16, e->pairs16)) return 1;
             g_cache[key] = w;
             e->wts = w;
         }
@@ -803,7 +817,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         for (int i = 1; i < KZ_ENGINE_SLOTS; i++) HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[i], hipStreamNonBlocking));
     const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
     if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
-    const int nact = (e->resident || e->resident32) ? 1 : 3;
+    const int nact = (e->resident || e->resident32 || e->pairs16) ? 1 : 3;
     for (int i = 0; i < nact; i++)
         if (e->dmalloc(&e->act[i], rows * e->cp * e->esz)) return 1;
     // head temporaries

@@ -141,9 +141,12 @@ void launch_tower32(const Tower32Args &a, hipStream_t stream);
 // (f32 in/out), `weights` = tower_split_pack_weights stream: 9 stem k-steps, then 9*C/32 per tower convolution ----
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in);
 int tower_split_boards_per_workgroup(int h, int w, int channels);
-size_t tower_split_weight_elems(int channels, int depth);  // f16 elements
-void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, uint16_t *dst);
+size_t tower_split_weight_elems(int channels, int depth, bool split = true);  // f16 elements
+void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, bool split, uint16_t *dst);
 void launch_tower_split(const Tower32Args &a, hipStream_t stream);
+// the same launch without the lo halves (split = false): plain f16 arithmetic, x0 and y are f16 tensors behind the
+// float pointers of Tower32Args — the board-resident f16 tower for the shapes kz_tower.hip does not take
+void launch_tower_pairs(const Tower32Args &a, bool split, hipStream_t stream);
 
 // ---- 1x1 convolution in the same split arithmetic (the head convolutions behind the split tower), f32 in and out:
 // y[r][0..cout_p) = [relu](bias + W x[row(r)]), row(r) = (r / group) * src_group + src_off + r % group ----

@@ -32,7 +32,9 @@ constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 // Shapes: C tower channels (256 or 128), NT tiles of 16 pixel rows per workgroup = floor(16 NT / hw) whole boards packed
 // densely (row r = board r / hw, pixel r % hw), as in kz_tower_f32.hip.  Chess: <256, 4> (one board); Ataxx 7x7 8x128:
 // <128, 7> (two boards); Go 9x9 at 128 channels: <128, 6>.
-template <int C, int NT>
+// SPLIT = false is the same launch in plain f16 (one image per activation, one MFMA per product, f16 tensors in and out):
+// the board-resident f16 tower for the shapes kz_tower.hip does not cover (128 channels; boards other than 8x8).
+template <int C, int NT, bool SPLIT>
 struct Geo {
     static constexpr int ROWS = NT * 16;
     static constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row: an odd number of 16-byte slots
@@ -41,21 +43,22 @@ struct Geo {
     // of a pair (lo = hi + DELTA, zero rows included); DELTA is a multiple of 256 B so the bank pattern is the same
     static constexpr int XH = 0, YH = IMG, ZH = 2 * IMG;
     static constexpr int DELTA = (2 * IMG + 16 * RS + 255) / 256 * 256;
-    static constexpr int SH = 2 * DELTA, SL = SH + ROWS * 64;  // stem input, rows of 64 B (32 channels)
-    static constexpr int LDS_BYTES = SL + ROWS * 64;
+    static constexpr int PARTS = SPLIT ? 2 : 1;
+    static constexpr int SH = PARTS * DELTA, SL = SH + ROWS * 64;  // stem input, rows of 64 B (32 channels)
+    static constexpr int LDS_BYTES = SH + PARTS * ROWS * 64;
     static constexpr int OT = C / 64;   // 16-channel output tiles per wave
     static constexpr int G = C / 32;    // k-steps per tap
-    static constexpr int STEP = 2 * 4 * OT * 64;  // uint4 per k-step: [hi | lo][wave 4][ot][lane 64]
+    static constexpr int STEP = PARTS * 4 * OT * 64;  // uint4 per k-step: [hi | lo][wave 4][ot][lane 64]
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(G % PF == 0, "ring stage of a k-step must not depend on the tap");
 };
 
 struct SplitDev {
-    const float *x0;    // encoded input [batch*hw][ldx0] f32
+    const void *x0;     // encoded input [batch*hw][ldx0]: f32 (SPLIT) or f16
     const uint4 *w;     // k-steps of [hi | lo][wave 4][ot][lane 64] x 16 B: 9 stem k-steps, then 2*depth*9*C/32
     const float *bias;  // [1 + 2*depth][C]
     const float *post_scale, *post_shift;
-    float *y;           // tower output [batch*hw][ldy] f32
+    void *y;            // tower output [batch*hw][ldy]: f32 (SPLIT) or f16
     int ldx0, ldy, batch, depth, h, w_, hw, nb;
     unsigned inv_w, inv_hw;  // ceil(65536 / w), ceil(65536 / hw): exact quotients for values < 512
 };
@@ -68,9 +71,10 @@ __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
     }
 }
 
-template <int C, int NT>
+template <int C, int NT, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
-    using L = Geo<C, NT>;
+    using L = Geo<C, NT, SPLIT>;
+    constexpr int PARTS = L::PARTS;
     constexpr int RS = L::RS, OT = L::OT, G = L::G, DELTA = L::DELTA, XH = L::XH, YH = L::YH, ZH = L::ZH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -89,11 +93,11 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     auto wload = [&](int gk, int part, int ot) __attribute__((always_inline)) {
         return wp[(size_t)gk * L::STEP + part * (4 * OT * 64) + ot * 64];
     };
-    uint4 wreg[PF][2][OT];
+    uint4 wreg[PF][PARTS][OT];
 #pragma unroll
     for (int s = 0; s < PF; s++)
 #pragma unroll
-        for (int part = 0; part < 2; part++)
+        for (int part = 0; part < PARTS; part++)
 #pragma unroll
             for (int ot = 0; ot < OT; ot++) wreg[s][part][ot] = wload(s < total_ksteps ? s : total_ksteps - 1, part, ot);
     int g = 0;
@@ -101,11 +105,11 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) {
             ah[ot] = *reinterpret_cast<const h16x8 *>(&wreg[stage][0][ot]);
-            al[ot] = *reinterpret_cast<const h16x8 *>(&wreg[stage][1][ot]);
+            if constexpr (SPLIT) al[ot] = *reinterpret_cast<const h16x8 *>(&wreg[stage][PARTS - 1][ot]);
         }
         const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
 #pragma unroll
-        for (int part = 0; part < 2; part++)
+        for (int part = 0; part < PARTS; part++)
 #pragma unroll
             for (int ot = 0; ot < OT; ot++) wreg[stage][part][ot] = wload(gn, part, ot);
     };
@@ -113,17 +117,23 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     // ---- zero rows and the stem input (f32 -> hi/lo, 32 channels per square; rows beyond the batch are zero) ----
     for (int id = tid; id < 16 * RS / 16; id += 256) {
         *reinterpret_cast<uint4 *>(lds + ZH + id * 16) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(lds + ZH + DELTA + id * 16) = make_uint4(0, 0, 0, 0);
+        if constexpr (SPLIT) *reinterpret_cast<uint4 *>(lds + ZH + DELTA + id * 16) = make_uint4(0, 0, 0, 0);
     }
     for (int id = tid; id < L::ROWS * 8; id += 256) {  // (row, 4-channel piece)
         const int row = id >> 3, c4 = id & 7;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < rows_valid && c4 * 4 < a.ldx0)
-            v = *reinterpret_cast<const f32x4 *>(a.x0 + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
-        h16x4 hi, lo;
-        split4(v, hi, lo);
-        *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = hi;
-        *reinterpret_cast<h16x4 *>(lds + L::SL + row * 64 + c4 * 8) = lo;
+        const bool have = row < rows_valid && c4 * 4 < a.ldx0;
+        if constexpr (SPLIT) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (have) v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(a.x0) + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
+            h16x4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = hi;
+            *reinterpret_cast<h16x4 *>(lds + L::SL + row * 64 + c4 * 8) = lo;
+        } else {
+            h16x4 v = h16x4{};
+            if (have) v = *reinterpret_cast<const h16x4 *>(static_cast<const h16 *>(a.x0) + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
+            *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = v;
+        }
     }
 
     // Validity of (tile row, tap) as bitmasks: bit nt of okmask[tap] says that for this lane's row of tile nt the tap
@@ -164,8 +174,10 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int ot = 0; ot < OT; ot++) {
-                acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ot], bh[nt], acc[ot][nt], 0, 0, 0);
-                acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ot], bl[nt], acc[ot][nt], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ot], bh[nt], acc[ot][nt], 0, 0, 0);
+                    acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ot], bl[nt], acc[ot][nt], 0, 0, 0);
+                }
                 acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ot], bh[nt], acc[ot][nt], 0, 0, 0);
             }
     };
@@ -185,16 +197,19 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         h16x8 ah[OT], al[OT], bh[NT], bl[NT];
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) {
-            const uint4 th = wp_stem[(size_t)tap * L::STEP + ot * 64], tl = wp_stem[(size_t)tap * L::STEP + 4 * OT * 64 + ot * 64];
+            const uint4 th = wp_stem[(size_t)tap * L::STEP + ot * 64];
             ah[ot] = *reinterpret_cast<const h16x8 *>(&th);
-            al[ot] = *reinterpret_cast<const h16x8 *>(&tl);
+            if constexpr (SPLIT) {
+                const uint4 tl = wp_stem[(size_t)tap * L::STEP + 4 * OT * 64 + ot * 64];
+                al[ot] = *reinterpret_cast<const h16x8 *>(&tl);
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             const int off = (nt * 16 + fr + shift) * 64 + kq * 16;  // stem: natural k (channel = 8 kq + j)
             const bool valid = (ok >> nt) & 1;
             bh[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + L::SH + off) : h16x8{};
-            bl[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + L::SL + off) : h16x8{};
+            if constexpr (SPLIT) bl[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + L::SL + off) : h16x8{};
         }
         mfma3(ah, al, bh, bl);
     }
@@ -215,14 +230,22 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                 }
                 if (residual) {  // added in f32, AFTER the ReLU (post_act.py:227-228)
                     const h16x4 rh = *reinterpret_cast<const h16x4 *>(lds + XH + off);
-                    const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] += (float)rh[j] + (float)rl[j];
+                    for (int j = 0; j < 4; j++) v[j] += (float)rh[j];
+                    if constexpr (SPLIT) {
+                        const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] += (float)rl[j];
+                    }
                 }
-                h16x4 hi, lo;
-                split4(v, hi, lo);
-                *reinterpret_cast<h16x4 *>(lds + dst_h + off) = hi;
-                *reinterpret_cast<h16x4 *>(lds + dst_h + DELTA + off) = lo;
+                if constexpr (SPLIT) {
+                    h16x4 hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<h16x4 *>(lds + dst_h + off) = hi;
+                    *reinterpret_cast<h16x4 *>(lds + dst_h + DELTA + off) = lo;
+                } else {
+                    *reinterpret_cast<h16x4 *>(lds + dst_h + off) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                }
             }
     };
     epilogue(XH, false, false);
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             bh[0][nt] = rd(T[nt], 0);
-            bl[0][nt] = rd(T[nt], DELTA);
+            if constexpr (SPLIT) bl[0][nt] = rd(T[nt], DELTA);
         }
 #pragma nounroll
         for (int tap = 0; tap < 9; tap++) {
@@ -261,24 +284,26 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     bh[nxt][nt] = ch < G - 1 ? rd(T[nt], (ch + 1) * 16) : rd(Tn[nt], 0);
-                    bl[nxt][nt] = ch < G - 1 ? rd(T[nt], DELTA + (ch + 1) * 16) : rd(Tn[nt], DELTA);
+                    if constexpr (SPLIT) bl[nxt][nt] = ch < G - 1 ? rd(T[nt], DELTA + (ch + 1) * 16) : rd(Tn[nt], DELTA);
                 }
                 h16x8 ah[OT], al[OT];
                 ring_take(stage, ah, al);
                 mfma3(ah, al, bh[cur], bl[cur]);
                 // every memory instruction in the shadow of an MFMA: the ring refills, the fragment reads, then the
                 // remaining MFMAs back to back
+                constexpr int NMF = (SPLIT ? 3 : 1) * OT * NT, NVM = PARTS * OT, NDS = PARTS * NT;
+                constexpr int PAIRED = NVM + NDS < NMF ? NVM + NDS : NMF;  // memory instructions with an MFMA in front
 #pragma unroll
-                for (int i = 0; i < 2 * OT; i++) {
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+                for (int i = 0; i < NVM; i++) {
+                    if (i < PAIRED) __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < 2 * NT; i++) {
-                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+                for (int i = 0; i < NDS; i++) {
+                    if (NVM + i < PAIRED) __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 3 * OT * NT - 2 * OT - 2 * NT, 0);
+                if constexpr (NMF > PAIRED) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NMF - PAIRED, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
@@ -311,12 +336,20 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                     const h16x4 rh = *reinterpret_cast<const h16x4 *>(lds + XH + off);
-                    const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] += (float)rh[j] + (float)rl[j];
+                    for (int j = 0; j < 4; j++) v[j] += (float)rh[j];
+                    if constexpr (SPLIT) {
+                        const h16x4 rl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] += (float)rl[j];
+                    }
                     v = v * ps + pt;
                     const int r = nt * 16 + fr;
-                    if (r < rows_valid) *reinterpret_cast<f32x4 *>(a.y + ((size_t)board0 * a.hw + r) * a.ldy + oc) = v;
+                    const size_t o = ((size_t)board0 * a.hw + r) * a.ldy + oc;
+                    if (r < rows_valid) {
+                        if constexpr (SPLIT) *reinterpret_cast<f32x4 *>(static_cast<float *>(a.y) + o) = v;
+                        else *reinterpret_cast<h16x4 *>(static_cast<h16 *>(a.y) + o) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                    }
                 }
             }
         }
@@ -330,17 +363,17 @@ int split_tiles_for(int hw, int channels) {
     return 0;
 }
 
-template <int C, int NT>
+template <int C, int NT, bool SPLIT>
 void launch(const SplitDev &d, int grid, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done_mask >> (dev & 63)) & 1)) {
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Geo<C, NT>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Geo<C, NT, SPLIT>::LDS_BYTES);
         done_mask |= 1ull << (dev & 63);
     }
-    kz_tower_resident_split<C, NT><<<grid, 256, Geo<C, NT>::LDS_BYTES, stream>>>(d);
+    kz_tower_resident_split<C, NT, SPLIT><<<grid, 256, Geo<C, NT, SPLIT>::LDS_BYTES, stream>>>(d);
 }
 
 
@@ -458,21 +491,21 @@ int tower_split_boards_per_workgroup(int h, int w, int channels) {
     return nt ? nt * 16 / (h * w) : 0;
 }
 
-size_t tower_split_weight_elems(int channels, int depth) {  // f16 elements
-    const size_t step = (size_t)2 * channels * 32;  // [hi | lo][channels][32]
+size_t tower_split_weight_elems(int channels, int depth, bool split) {  // f16 elements
+    const size_t step = (size_t)(split ? 2 : 1) * channels * 32;  // [hi | lo][channels][32]
     return ((size_t)9 + (size_t)2 * depth * 9 * (channels / 32)) * step;
 }
 
 // OIHW f32 (BN folded) -> k-steps of [hi | lo][wave 4][ot C/64][lane 64][8] f16; element j of lane (fr, kq) of (wave, ot)
 // is W[oc = 16*(wave*C/64 + ot) + fr][channel][tap], channel = 8*chunk + {0, C/2, C/4, 3C/4}[kq] + j for a tower layer (one
 // k-step per tap and chunk of 32 channels) and 8*kq + j for the stem (one k-step per tap, 32 padded input channels).
-void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, uint16_t *dst) {
+void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, bool split, uint16_t *dst) {
     const int kq_base[4] = {0, cout / 2, cout / 4, 3 * cout / 4};  // tower layers: cin == cout
     const int nchunk = stem ? 1 : cin / 32, ot_n = cout / 64;
     const size_t part = (size_t)cout * 32;  // f16 elements of the hi (or lo) half of a k-step
     for (int tap = 0; tap < 9; tap++)
         for (int chunk = 0; chunk < nchunk; chunk++) {
-            uint16_t *step = dst + ((size_t)tap * nchunk + chunk) * 2 * part;
+            uint16_t *step = dst + ((size_t)tap * nchunk + chunk) * (split ? 2 : 1) * part;
             for (int wave = 0; wave < 4; wave++)
                 for (int ot = 0; ot < ot_n; ot++)
                     for (int lane = 0; lane < 64; lane++)
@@ -488,14 +521,16 @@ void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, u
                             __builtin_memcpy(&lb, &lo, 2);
                             const size_t e = (((size_t)wave * ot_n + ot) * 64 + lane) * 8 + j;
                             step[e] = hb;
-                            step[part + e] = lb;
+                            if (split) step[part + e] = lb;
                         }
         }
 }
 
-void launch_tower_split(const Tower32Args &t, hipStream_t stream) {
+void launch_tower_split(const Tower32Args &t, hipStream_t stream) { launch_tower_pairs(t, true, stream); }
+
+void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     SplitDev d{};
-    d.x0 = t.x0;
+    d.x0 = t.x0;  // (f16 tensors behind the same pointers when !split)
     d.ldx0 = t.ldx0;
     d.w = static_cast<const uint4 *>(t.weights);
     d.bias = t.bias;
@@ -513,10 +548,17 @@ void launch_tower_split(const Tower32Args &t, hipStream_t stream) {
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
     const int grid = (t.batch + d.nb - 1) / d.nb;
-    if (t.channels == 256) launch<256, 4>(d, grid, stream);
-    else if (nt == 7) launch<128, 7>(d, grid, stream);
-    else if (nt == 6) launch<128, 6>(d, grid, stream);
-    else launch<128, 4>(d, grid, stream);
+    if (split) {
+        if (t.channels == 256) launch<256, 4, true>(d, grid, stream);
+        else if (nt == 7) launch<128, 7, true>(d, grid, stream);
+        else if (nt == 6) launch<128, 6, true>(d, grid, stream);
+        else launch<128, 4, true>(d, grid, stream);
+    } else {
+        if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
+        else if (nt == 7) launch<128, 7, false>(d, grid, stream);
+        else if (nt == 6) launch<128, 6, false>(d, grid, stream);
+        else launch<128, 4, false>(d, grid, stream);
+    }
 }
 
 // ---- 1x1 convolution in split arithmetic (head convolutions behind the split tower) ----

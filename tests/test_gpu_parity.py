@@ -438,16 +438,21 @@ def test_board_conv_path_vs_oracle(dev, game, depth, batch):
     dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
     s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
     model = capi.Model(blob=blob)
-    eng = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
+    os.environ["KZ_NO_RESIDENT_F16G"] = "1"  # (small boards at 128 channels otherwise take the one-launch f16 tower)
+    try:
+        eng = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
+    finally:
+        del os.environ["KZ_NO_RESIDENT_F16G"]
     assert eng.tower_path == "board_conv_f16"
     s, p = eng.eval_packed(bits, scalars_in)
     assert_f16(s, s_ref, "scalars")
     assert_f16(p, p_ref, "policy")
     os.environ["KZ_NO_BOARD_CONV"] = "1"
+    os.environ["KZ_NO_RESIDENT_F16G"] = "1"
     try:
         gen = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
     finally:
-        del os.environ["KZ_NO_BOARD_CONV"]
+        del os.environ["KZ_NO_BOARD_CONV"], os.environ["KZ_NO_RESIDENT_F16G"]
     assert gen.tower_path == "conv_igemm_f16"
     sg, pg = gen.eval_packed(bits, scalars_in)
     # same arithmetic (f16 operands, f32 accumulate, f16 activations), different summation order: a far tighter bound
@@ -527,6 +532,46 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
         se, pe = exact.eval_packed(bits, scalars_in)
         assert_f32(se, s, f"exact f32 vs split16 scalars b={batch}")
         assert_f32(pe, p, f"exact f32 vs split16 policy b={batch}")
+
+
+@pytest.mark.parametrize("game,depth,channels,head,batches", [
+    ("ataxx-7", 8, 128, "ataxx_conv", (1, 2, 13, 256)),  # BASELINE configs[1]'s network in f16: two boards per workgroup
+    ("chess", 2, 128, "attention", (3, 40)),             # 128 channels on an 8x8 board
+    ("go-9", 2, 128, "conv", (3, 11)),                   # 81 pixels: six tiles
+    ("go-9", 2, 256, "conv", (5,)),                      # more than 64 squares at 256 channels: not a shape of the launch
+])
+def test_resident_f16g_tower(dev, game, depth, channels, head, batches):
+    """The one-launch f16 tower for the shapes the chess launch does not take (kz_tower_resident_split without its lo
+    halves): against the oracle at the f16 tolerance, and against the per-layer implicit GEMM of the same engine — same
+    operands and rounding points — at the far tighter summation-order bound."""
+    blob = synth.random_model(game, depth, channels, head, seed=91)
+    net = O.OracleNet(blob)
+    model = capi.Model(blob=blob)
+    eng = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    if channels == 256:
+        assert eng.tower_path != "tower_resident_f16g"
+        return
+    assert eng.tower_path == "tower_resident_f16g"
+    os.environ["KZ_FORCE_GENERIC"] = "1"
+    os.environ["KZ_NO_BOARD_CONV"] = "1"
+    try:
+        gen = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    finally:
+        del os.environ["KZ_FORCE_GENERIC"], os.environ["KZ_NO_BOARD_CONV"]
+    assert gen.tower_path == "conv_igemm_f16"
+    for batch in batches:
+        bits, scalars_in = synth.random_boards(game, batch, seed=92 + batch)
+        s, p = eng.eval_packed(bits, scalars_in)
+        n = min(batch, 16)  # the oracle on a sample
+        dense = O.encode_input_full(bits[:n], scalars_in[:n], net.n_scalar, net.n_bool, net.h, net.w)
+        s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+        assert_f16(s[:n], s_ref, f"scalars b={batch}")
+        assert_f16(p[:n], p_ref, f"policy b={batch}")
+        sg, pg = gen.eval_packed(bits, scalars_in)
+        ds, dp = np.abs(sg - s).max(), np.abs(pg - p).max()
+        print(f"f16g {game} {depth}x{channels} b={batch} vs implicit GEMM f16: max |d scalars| {ds:.2e}, max |d policy| {dp:.2e}")
+        tol = F16_PATHS_ATOL if depth <= 2 else F16_PATHS_ATOL_DEEP
+        assert ds < tol and dp < tol
 
 
 @pytest.mark.parametrize("game,channels,head,batch", [
