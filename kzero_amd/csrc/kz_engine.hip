@@ -506,6 +506,13 @@ struct kz_engine {
             t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
             t.y = (float *)act[0]; t.ldy = cp; t.batch = batch; t.h = m.h; t.w = m.w; t.channels = m.channels;
             t.depth = m.depth;
+            if (packed) {  // (only asked for by forward_packed on the split / f16g launches)
+                t.bits = (const uint8_t *)packed->bits;
+                t.bits_stride = packed->stride;
+                t.scalars_in = (const float *)packed->scalars;
+                t.n_scalar = m.n_scalar;
+                t.n_bool = m.n_bool;
+            }
             prof.begin(split16 ? "kz_tower_resident_split" : pairs16 ? "kz_tower_resident_f16g" : "kz_tower_resident_f32", stream);
             if (split16) kz::launch_tower_split(t, stream);
             else if (pairs16) kz::launch_tower_pairs(t, false, stream);  // f16 tensors behind the same pointers
@@ -611,7 +618,7 @@ struct kz_engine {
 
     int forward_packed(const void *d_bits, size_t stride, const void *d_sin, int batch, void *d_sout, void *d_pol) {
         const Model &m = *model;
-        if (resident) {  // encode is fused into the tower launch
+        if (resident || split16 || pairs16) {  // encode is fused into the tower launch
             const PackedIn in{d_bits, stride, d_sin};
             if (run_tower(batch, (float *)d_sout, (float *)d_pol, &in)) return 1;
             return run_heads(batch, (float *)d_sout, (float *)d_pol);

@@ -129,6 +129,12 @@ struct Tower32Args {
     const float *post_scale, *post_shift;  // final BN [channels]
     float *y;             // tower output [batch*hw][ldy] f32
     int ldy, batch, h, w, channels, depth;
+    // launch_tower_split / launch_tower_pairs only: fused board encode (F0) — packed boards straight into the launch
+    // (bits == nullptr: read x0)
+    const uint8_t *bits = nullptr;
+    size_t bits_stride = 0;
+    const float *scalars_in = nullptr;
+    int n_scalar = 0, n_bool = 0;
 };
 bool tower32_supported(int dtype, int h, int w, int channels, int depth);
 int tower32_boards_per_workgroup(int h, int w, int channels);

@@ -61,6 +61,11 @@ struct SplitDev {
     void *y;            // tower output [batch*hw][ldy]: f32 (SPLIT) or f16
     int ldx0, ldy, batch, depth, h, w_, hw, nb;
     unsigned inv_w, inv_hw;  // ceil(65536 / w), ceil(65536 / hw): exact quotients for values < 512
+    // fused encode (F0): packed boards; when bits == nullptr the stem input comes from x0
+    const uint8_t *bits;
+    size_t bits_stride;
+    const float *scalars_in;
+    int n_scalar, n_bool;
 };
 
 __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
@@ -122,7 +127,29 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     for (int id = tid; id < L::ROWS * 8; id += 256) {  // (row, 4-channel piece)
         const int row = id >> 3, c4 = id & 7;
         const bool have = row < rows_valid && c4 * 4 < a.ldx0;
-        if constexpr (SPLIT) {
+        if (a.bits) {
+            // encode_input_full (rust/kz-core/src/mapping/mod.rs:40-63) for 4 channels of one square: scalar planes first,
+            // then the bool planes; bool i = bit i%8 of byte i/8 (bit_buffer.rs:73-75)
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < rows_valid) {
+                const int b = (int)(((unsigned)row * a.inv_hw) >> 16), q = row - b * a.hw;
+                const uint8_t *bb = a.bits + (size_t)(board0 + b) * a.bits_stride;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ch = c4 * 4 + j;
+                    if (ch < a.n_scalar) {
+                        v[j] = a.scalars_in[(size_t)(board0 + b) * a.n_scalar + ch];
+                    } else if (ch < a.n_scalar + a.n_bool) {
+                        const unsigned bit = (unsigned)(ch - a.n_scalar) * a.hw + q;
+                        v[j] = (float)((bb[bit >> 3] >> (bit & 7)) & 1);
+                    }
+                }
+            }
+            h16x4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = hi;
+            if constexpr (SPLIT) *reinterpret_cast<h16x4 *>(lds + L::SL + row * 64 + c4 * 8) = lo;
+        } else if constexpr (SPLIT) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (have) v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(a.x0) + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
             h16x4 hi, lo;
@@ -530,6 +557,11 @@ void launch_tower_split(const Tower32Args &t, hipStream_t stream) { launch_tower
 
 void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     SplitDev d{};
+    d.bits = t.bits;
+    d.bits_stride = t.bits_stride;
+    d.scalars_in = t.scalars_in;
+    d.n_scalar = t.n_scalar;
+    d.n_bool = t.n_bool;
     d.x0 = t.x0;  // (f16 tensors behind the same pointers when !split)
     d.ldx0 = t.ldx0;
     d.w = static_cast<const uint4 *>(t.weights);
