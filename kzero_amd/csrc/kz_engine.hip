@@ -138,9 +138,9 @@ struct DeviceWeights {
                 for (int t = 0; t < taps; t++)
                     flat[((size_t)t * d.cout_p + o) * d.cin_p + i] = cv.w[((size_t)o * cv.cin + i) * taps + t];
         if (upload_matrix(flat, taps * d.cout_p, d.cin_p, taps * d.cout_p, d.cin_p, &d.w)) return 1;
-        if (split16 && cv.k == 1 && kz::conv1x1_split_supported(d.cin_p, d.cout_p)) {
-            std::vector<uint16_t> packed(kz::conv1x1_split_weight_elems(d.cin_p, d.cout_p));
-            kz::conv1x1_split_pack_weights(cv.w.data(), cv.cout, cv.cin, d.cout_p, d.cin_p, packed.data());
+        if ((split16 || pairs16) && cv.k == 1 && kz::conv1x1_split_supported(d.cin_p, d.cout_p)) {
+            std::vector<uint16_t> packed(kz::conv1x1_split_weight_elems(d.cin_p, d.cout_p, split16));
+            kz::conv1x1_split_pack_weights(cv.w.data(), cv.cout, cv.cin, d.cout_p, d.cin_p, split16, packed.data());
             if (upload(packed.data(), packed.size() * 2, &d.sw)) return 1;
         }
         std::vector<float> b(d.cout_p, 0.0f);
@@ -443,9 +443,10 @@ struct kz_engine {
             HIP_TRY(hipGetLastError());
             return 0;
         }
-        if (w.sw && split16 && y && !res && !post && !y32 && ldx >= w.cin_p) {  // 1x1 head convolution behind the split tower
+        if (w.sw && (split16 || pairs16) && y && !res && !post && !y32 && ldx >= w.cin_p) {  // 1x1 head convolution behind the split / f16g tower
             kz::Conv1x1SplitArgs c{};
-            c.x = (const float *)x; c.ldx = ldx; c.weights = w.sw; c.bias = w.b; c.y = (float *)y; c.ldy = ldy;
+            c.split = split16;
+            c.x = x; c.ldx = ldx; c.weights = w.sw; c.bias = w.b; c.y = y; c.ldy = ldy;
             c.M = M; c.cin_p = w.cin_p; c.cout_p = w.cout_p; c.relu = relu;
             c.group = group; c.src_group = src_group; c.src_off = src_off;
             prof.begin("kz_conv1x1_split", stream);

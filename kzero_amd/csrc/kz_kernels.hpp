@@ -157,16 +157,17 @@ void launch_tower_pairs(const Tower32Args &a, bool split, hipStream_t stream);
 // ---- 1x1 convolution in the same split arithmetic (the head convolutions behind the split tower), f32 in and out:
 // y[r][0..cout_p) = [relu](bias + W x[row(r)]), row(r) = (r / group) * src_group + src_off + r % group ----
 struct Conv1x1SplitArgs {
-    const float *x;
+    const void *x;        // f32 (split) or f16
     int ldx;
     const void *weights;  // conv1x1_split_pack_weights
     const float *bias;    // [cout_p]
-    float *y;
+    void *y;              // f32 (split) or f16
     int ldy, M, cin_p, cout_p, relu, group, src_group, src_off;
+    bool split;           // false: plain f16 arithmetic and tensors (behind the one-launch f16 tower)
 };
 bool conv1x1_split_supported(int cin_p, int cout_p);
-size_t conv1x1_split_weight_elems(int cin_p, int cout_p);
-void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, int cin_p, uint16_t *dst);
+size_t conv1x1_split_weight_elems(int cin_p, int cout_p, bool split);
+void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, int cin_p, bool split, uint16_t *dst);
 void launch_conv1x1_split(const Conv1x1SplitArgs &a, hipStream_t stream);
 
 // ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----

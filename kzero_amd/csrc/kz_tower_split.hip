@@ -410,15 +410,16 @@ void launch(const SplitDev &d, int grid, hipStream_t stream) {
 // input as (hi, lo) images in LDS and runs passes of 64 * OT output channels over them (wave w: OT 16-channel tiles x the
 // four row tiles), the weights read from L2 in fragment order one 32-channel chunk ahead.
 struct Conv1x1SplitDev {
-    const float *x;
+    const void *x;      // f32 (SPLIT) or f16
     const uint4 *w;     // [pass][chunk cin/32][hi | lo][wave 4][ot OT][lane 64] x 16 B
     const float *bias;  // [cout_p]
-    float *y;
+    void *y;            // f32 (SPLIT) or f16
     int ldx, ldy, M, cin, cout_p, relu, group, src_group, src_off;
 };
 
-template <int OT>
+template <int OT, bool SPLIT>
 __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
+    constexpr int PARTS = SPLIT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,21 +434,29 @@ __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
     for (int id = tid; id < 64 * pieces; id += 256) {
         const int r = id / pieces, c4 = id - r * pieces;
         const int orow = row0 + r;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        size_t src = 0;
         if (orow < a.M) {
             const int b = orow / a.group, q = orow - b * a.group;
-            v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)b * a.src_group + a.src_off + q) * a.ldx + c4 * 4);
+            src = ((size_t)b * a.src_group + a.src_off + q) * a.ldx + c4 * 4;
         }
-        h16x4 hi, lo;
-        split4(v, hi, lo);
-        *reinterpret_cast<h16x4 *>(lds + r * RS + c4 * 8) = hi;
-        *reinterpret_cast<h16x4 *>(lds + LO + r * RS + c4 * 8) = lo;
+        if constexpr (SPLIT) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (orow < a.M) v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(a.x) + src);
+            h16x4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<h16x4 *>(lds + r * RS + c4 * 8) = hi;
+            *reinterpret_cast<h16x4 *>(lds + LO + r * RS + c4 * 8) = lo;
+        } else {
+            h16x4 v = h16x4{};
+            if (orow < a.M) v = *reinterpret_cast<const h16x4 *>(static_cast<const h16 *>(a.x) + src);
+            *reinterpret_cast<h16x4 *>(lds + r * RS + c4 * 8) = v;
+        }
     }
     __syncthreads();
 
     const int frag = fr * RS + kq * 16;  // natural k: chunk c covers channels [32 c, 32 c + 32), 8 per lane group
     const int passes = a.cout_p / (64 * OT);
-    const size_t step = (size_t)2 * 4 * OT * 64;  // uint4 per (pass, chunk)
+    const size_t step = (size_t)PARTS * 4 * OT * 64;  // uint4 per (pass, chunk)
     for (int pass = 0; pass < passes; pass++) {
         const uint4 *wp = a.w + (size_t)pass * chunks * step + (wave * OT) * 64 + lane;
         const int oc0 = pass * 64 * OT + wave * OT * 16 + kq * 4;
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) {
             wh[0][ot] = wp[ot * 64];
-            wl[0][ot] = wp[4 * OT * 64 + ot * 64];
+            if constexpr (SPLIT) wl[0][ot] = wp[4 * OT * 64 + ot * 64];
         }
 #pragma nounroll
         for (int c = 0; c < chunks; c += 2) {
@@ -474,18 +483,21 @@ __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
 #pragma unroll
                     for (int ot = 0; ot < OT; ot++) {
                         wh[half ^ 1][ot] = wp[(size_t)cn * step + ot * 64];
-                        wl[half ^ 1][ot] = wp[(size_t)cn * step + 4 * OT * 64 + ot * 64];
+                        if constexpr (SPLIT) wl[half ^ 1][ot] = wp[(size_t)cn * step + 4 * OT * 64 + ot * 64];
                     }
 #pragma unroll
                     for (int mt = 0; mt < 4; mt++) {
                         const h16x8 bh = *reinterpret_cast<const h16x8 *>(lds + frag + mt * 16 * RS + cc * 64);
-                        const h16x8 bl = *reinterpret_cast<const h16x8 *>(lds + LO + frag + mt * 16 * RS + cc * 64);
+                        h16x8 bl = h16x8{};
+                        if constexpr (SPLIT) bl = *reinterpret_cast<const h16x8 *>(lds + LO + frag + mt * 16 * RS + cc * 64);
 #pragma unroll
                         for (int ot = 0; ot < OT; ot++) {
                             const h16x8 ah = *reinterpret_cast<const h16x8 *>(&wh[half][ot]);
-                            const h16x8 al = *reinterpret_cast<const h16x8 *>(&wl[half][ot]);
-                            acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[ot][mt], 0, 0, 0);
-                            acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[ot][mt], 0, 0, 0);
+                            if constexpr (SPLIT) {
+                                const h16x8 al = *reinterpret_cast<const h16x8 *>(&wl[half][ot]);
+                                acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[ot][mt], 0, 0, 0);
+                                acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[ot][mt], 0, 0, 0);
+                            }
                             acc[ot][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[ot][mt], 0, 0, 0);
                         }
                     }
@@ -502,7 +514,11 @@ __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                 }
-                if (r < a.M) *reinterpret_cast<f32x4 *>(a.y + (size_t)r * a.ldy + oc0 + ot * 16) = v;
+                if (r < a.M) {
+                    const size_t o = (size_t)r * a.ldy + oc0 + ot * 16;
+                    if constexpr (SPLIT) *reinterpret_cast<f32x4 *>(static_cast<float *>(a.y) + o) = v;
+                    else *reinterpret_cast<h16x4 *>(static_cast<h16 *>(a.y) + o) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                }
             }
     }
 }
@@ -600,16 +616,16 @@ bool conv1x1_split_supported(int cin_p, int cout_p) {
     return cin_p % 32 == 0 && cin_p >= 32 && cin_p <= 512 && conv1x1_split_ot(cout_p) != 0;
 }
 
-size_t conv1x1_split_weight_elems(int cin_p, int cout_p) { return (size_t)2 * cin_p * cout_p; }  // f16 elements
+size_t conv1x1_split_weight_elems(int cin_p, int cout_p, bool split) { return (size_t)(split ? 2 : 1) * cin_p * cout_p; }  // f16 elements
 
 // [cout_p][cin_p] f32 (zero padded) -> [pass][chunk][hi | lo][wave 4][ot][lane 64][8] f16: element j of lane (fr, kq) is
 // W[oc = 64*OT*pass + 16*(wave*OT + ot) + fr][channel = 32*chunk + 8*kq + j]
-void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, int cin_p, uint16_t *dst) {
+void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, int cin_p, bool split, uint16_t *dst) {
     const int ot_n = conv1x1_split_ot(cout_p), passes = cout_p / (64 * ot_n), chunks = cin_p / 32;
     const size_t part = (size_t)4 * ot_n * 64 * 8;
     for (int pass = 0; pass < passes; pass++)
         for (int chunk = 0; chunk < chunks; chunk++) {
-            uint16_t *step = dst + ((size_t)pass * chunks + chunk) * 2 * part;
+            uint16_t *step = dst + ((size_t)pass * chunks + chunk) * (split ? 2 : 1) * part;
             for (int wave = 0; wave < 4; wave++)
                 for (int ot = 0; ot < ot_n; ot++)
                     for (int lane = 0; lane < 64; lane++)
@@ -624,7 +640,7 @@ void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, i
                             __builtin_memcpy(&lb, &lo, 2);
                             const size_t e = (((size_t)wave * ot_n + ot) * 64 + lane) * 8 + j;
                             step[e] = hb;
-                            step[part + e] = lb;
+                            if (split) step[part + e] = lb;
                         }
         }
 }
@@ -644,7 +660,7 @@ void launch_conv1x1_split(const Conv1x1SplitArgs &t, hipStream_t stream) {
     d.group = t.group;
     d.src_group = t.src_group;
     d.src_off = t.src_off;
-    const int lds_bytes = 2 * 64 * (t.cin_p * 2 + 16);
+    const int lds_bytes = (t.split ? 2 : 1) * 64 * (t.cin_p * 2 + 16);
     const int grid = (t.M + 63) / 64;
     const int ot = conv1x1_split_ot(t.cout_p);
     auto go = [&](auto kernel) {
@@ -657,9 +673,15 @@ void launch_conv1x1_split(const Conv1x1SplitArgs &t, hipStream_t stream) {
         }
         kernel<<<grid, 256, lds_bytes, stream>>>(d);
     };
-    if (ot == 4) go(kz_conv1x1_split<4>);
-    else if (ot == 2) go(kz_conv1x1_split<2>);
-    else go(kz_conv1x1_split<1>);
+    if (t.split) {
+        if (ot == 4) go(kz_conv1x1_split<4, true>);
+        else if (ot == 2) go(kz_conv1x1_split<2, true>);
+        else go(kz_conv1x1_split<1, true>);
+    } else {
+        if (ot == 4) go(kz_conv1x1_split<4, false>);
+        else if (ot == 2) go(kz_conv1x1_split<2, false>);
+        else go(kz_conv1x1_split<1, false>);
+    }
 }
 
 }  // namespace kz
