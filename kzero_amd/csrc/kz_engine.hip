@@ -781,7 +781,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->resident32 = kz::tower32_supported(dtype, m.h, m.w, m.channels, m.depth) && m.c_in <= e->cin_p &&
                     !(force && force[0] == '1') && !e->keep;
     if (split16) {
-        if (!kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in) || e->cin_p != 32)
+        if (!kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) || e->cin_p != 32)
             return fail("kz_engine_create: KZ_DTYPE_F32_SPLIT16 needs 256 tower channels on a board of at most 64 squares or "
                         "128 channels on at most 96 squares, and at most 32 input planes");
         e->split16 = e->resident32 = true;  // same tensors in and out as the exact-f32 resident launch
@@ -791,7 +791,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     const char *nopairs = getenv("KZ_NO_RESIDENT_F16G");
     e->pairs16 = dtype == KZ_DTYPE_F16 && !e->resident && !(force && force[0] == '1') && !e->keep &&
                  !(nopairs && nopairs[0] == '1') && e->cin_p == 32 &&
-                 kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in);
+                 kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
     const bool board_conv = board_conv_ok && !e->pairs16;
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"

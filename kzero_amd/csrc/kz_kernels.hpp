@@ -145,8 +145,8 @@ void launch_tower32(const Tower32Args &a, hipStream_t stream);
 // ---- the same tower with f32-equivalent results on the f16 matrix cores (kz_tower_split.hip): activations and weights
 // as (hi, lo) f16 pairs, three MFMAs per product.  Shapes of the exact-f32 launch with c_in <= 32; same Tower32Args
 // (f32 in/out), `weights` = tower_split_pack_weights stream: 9 stem k-steps, then 9*C/32 per tower convolution ----
-bool tower_split_supported(int h, int w, int channels, int depth, int c_in);
-int tower_split_boards_per_workgroup(int h, int w, int channels);
+bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split);
+int tower_split_boards_per_workgroup(int h, int w, int channels, bool split);
 size_t tower_split_weight_elems(int channels, int depth, bool split = true);  // f16 elements
 void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, bool split, uint16_t *dst);
 void launch_tower_split(const Tower32Args &a, hipStream_t stream);

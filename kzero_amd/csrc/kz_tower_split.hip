@@ -384,8 +384,9 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     }
 }
 
-int split_tiles_for(int hw, int channels) {
-    if (channels == 256) return hw <= 64 ? 4 : 0;
+int split_tiles_for(int hw, int channels, bool split) {
+    // (the plain-f16 launch has half the LDS footprint: 256 channels fit up to 96 squares — Go 9x9)
+    if (channels == 256) return hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
     if (channels == 128) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
     return 0;
 }
@@ -525,12 +526,12 @@ __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
 
 }  // namespace
 
-bool tower_split_supported(int h, int w, int channels, int depth, int c_in) {
-    return depth >= 1 && c_in <= 32 && h >= 2 && w >= 2 && w <= 32 && split_tiles_for(h * w, channels) != 0;
+bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split) {
+    return depth >= 1 && c_in <= 32 && h >= 2 && w >= 2 && w <= 32 && split_tiles_for(h * w, channels, split) != 0;
 }
 
-int tower_split_boards_per_workgroup(int h, int w, int channels) {
-    const int nt = split_tiles_for(h * w, channels);
+int tower_split_boards_per_workgroup(int h, int w, int channels, bool split) {
+    const int nt = split_tiles_for(h * w, channels, split);
     return nt ? nt * 16 / (h * w) : 0;
 }
 
@@ -591,7 +592,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     d.h = t.h;
     d.w_ = t.w;
     d.hw = t.h * t.w;
-    const int nt = split_tiles_for(d.hw, t.channels);
+    const int nt = split_tiles_for(d.hw, t.channels, split);
     d.nb = nt * 16 / d.hw;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
@@ -602,7 +603,8 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else if (nt == 6) launch<128, 6, true>(d, grid, stream);
         else launch<128, 4, true>(d, grid, stream);
     } else {
-        if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
+        if (t.channels == 256 && nt == 6) launch<256, 6, false>(d, grid, stream);
+        else if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
         else if (nt == 7) launch<128, 7, false>(d, grid, stream);
         else if (nt == 6) launch<128, 6, false>(d, grid, stream);
         else launch<128, 4, false>(d, grid, stream);

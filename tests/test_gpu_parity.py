@@ -538,7 +538,8 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     ("ataxx-7", 8, 128, "ataxx_conv", (1, 2, 13, 256)),  # BASELINE configs[1]'s network in f16: two boards per workgroup
     ("chess", 2, 128, "attention", (3, 40)),             # 128 channels on an 8x8 board
     ("go-9", 2, 128, "conv", (3, 11)),                   # 81 pixels: six tiles
-    ("go-9", 2, 256, "conv", (5,)),                      # more than 64 squares at 256 channels: not a shape of the launch
+    ("go-9", 2, 256, "conv", (5, 64)),                   # 256 channels on 81 squares: six tiles, one board per workgroup
+    ("go-19", 2, 128, "conv", (2,)),                     # 361 squares: not a shape of the launch
 ])
 def test_resident_f16g_tower(dev, game, depth, channels, head, batches):
     """The one-launch f16 tower for the shapes the chess launch does not take (kz_tower_resident_split without its lo
@@ -548,7 +549,7 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches):
     net = O.OracleNet(blob)
     model = capi.Model(blob=blob)
     eng = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
-    if channels == 256:
+    if game == "go-19":
         assert eng.tower_path != "tower_resident_f16g"
         return
     assert eng.tower_path == "tower_resident_f16g"
