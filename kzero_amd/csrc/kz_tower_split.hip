@@ -9,8 +9,12 @@
 // f16 MFMAs per product run at 2500 / 3 = 833 TFLOP/s.  The results agree with the CPU oracle within the same 1e-4 as
 // the exact-f32 path (tests/test_gpu_parity.py), which the plain f16 path cannot (it rounds the residual stream to 11
 // bits per layer).  Shapes of the exact-f32 launch (256 channels on <= 64 squares, 128 channels on <= 96); input and
-// output are the f32 tensors of the f32 engine path, so the encode kernel in front and the generic f32 head kernels
-// behind are unchanged.
+// output are the f32 tensors of the f32 engine path (or packed boards in: the board encode, F0, is fused like in
+// kz_tower.hip), the head kernels behind are the f32 engine's, with kz_conv1x1_split (below) for their 1x1 convolutions.
+//
+// The same template with SPLIT = false is the launch in plain f16 — one image per activation, one MFMA per product, f16
+// tensors — i.e. the one-launch f16 tower for the shapes kz_tower.hip (chess: 8x8, 256 channels, fused heads) does not
+// cover: "tower_resident_f16g".
 //
 // Arithmetic follows python/lib/model/post_act.py:201-239 with Conv+BN folded on the host (kz_model.cpp).
 #include <vector>
