@@ -27,8 +27,8 @@ extern "C" {
 #define KZ_DTYPE_F16 1 /* f16 storage, f32 accumulate: the throughput path */
 #define KZ_DTYPE_F32_SPLIT16 2 /* f32 tensors and the same <=1e-4 parity as KZ_DTYPE_F32, but the tower's products run on
                                   the f16 matrix cores: every activation and weight as a (hi, lo) f16 pair, three MFMAs per
-                                  product, f32 accumulate.  256 tower channels on <= 64 squares or 128 channels on <= 96
-                                  squares (kz_engine_create fails otherwise); everything outside the tower is the
+                                  product, f32 accumulate.  256 tower channels on <= 64 squares or 64 / 128 channels on
+                                  <= 96 squares (kz_engine_create fails otherwise); everything outside the tower is the
                                   KZ_DTYPE_F32 path */
 
 #define KZ_POLICY_ATAXX_CONV 0 /* AtaxxConvPolicyHead, python/lib/model/post_act.py:91-112 */

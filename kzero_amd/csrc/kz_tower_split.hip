@@ -30,7 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int PF = 4;  // weight ring depth in k-steps
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
 // Shapes: C tower channels (256 or 128), NT tiles of 16 pixel rows per workgroup = floor(16 NT / hw) whole boards packed
@@ -54,6 +53,7 @@ struct Geo {
     static constexpr int G = C / 32;    // k-steps per tap
     static constexpr int STEP = PARTS * 4 * OT * 64;  // uint4 per k-step: [hi | lo][wave 4][ot][lane 64]
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int PF = G >= 4 ? 4 : 2;  // weight ring depth in k-steps
     static_assert(G % PF == 0, "ring stage of a k-step must not depend on the tap");
 };
 
@@ -83,7 +83,7 @@ __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
 template <int C, int NT, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     using L = Geo<C, NT, SPLIT>;
-    constexpr int PARTS = L::PARTS;
+    constexpr int PARTS = L::PARTS, PF = L::PF;
     constexpr int RS = L::RS, OT = L::OT, G = L::G, DELTA = L::DELTA, XH = L::XH, YH = L::YH, ZH = L::ZH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
 int split_tiles_for(int hw, int channels, bool split) {
     // (the plain-f16 launch has half the LDS footprint: 256 channels fit up to 96 squares — Go 9x9)
     if (channels == 256) return hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
-    if (channels == 128) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
+    if (channels == 128 || channels == 64) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
     return 0;
 }
 
@@ -603,15 +603,21 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     const int grid = (t.batch + d.nb - 1) / d.nb;
     if (split) {
         if (t.channels == 256) launch<256, 4, true>(d, grid, stream);
-        else if (nt == 7) launch<128, 7, true>(d, grid, stream);
-        else if (nt == 6) launch<128, 6, true>(d, grid, stream);
-        else launch<128, 4, true>(d, grid, stream);
+        else if (t.channels == 128 && nt == 7) launch<128, 7, true>(d, grid, stream);
+        else if (t.channels == 128 && nt == 6) launch<128, 6, true>(d, grid, stream);
+        else if (t.channels == 128) launch<128, 4, true>(d, grid, stream);
+        else if (nt == 7) launch<64, 7, true>(d, grid, stream);
+        else if (nt == 6) launch<64, 6, true>(d, grid, stream);
+        else launch<64, 4, true>(d, grid, stream);
     } else {
         if (t.channels == 256 && nt == 6) launch<256, 6, false>(d, grid, stream);
         else if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
-        else if (nt == 7) launch<128, 7, false>(d, grid, stream);
-        else if (nt == 6) launch<128, 6, false>(d, grid, stream);
-        else launch<128, 4, false>(d, grid, stream);
+        else if (t.channels == 128 && nt == 7) launch<128, 7, false>(d, grid, stream);
+        else if (t.channels == 128 && nt == 6) launch<128, 6, false>(d, grid, stream);
+        else if (t.channels == 128) launch<128, 4, false>(d, grid, stream);
+        else if (nt == 7) launch<64, 7, false>(d, grid, stream);
+        else if (nt == 6) launch<64, 6, false>(d, grid, stream);
+        else launch<64, 4, false>(d, grid, stream);
     }
 }
 

@@ -503,6 +503,7 @@ def test_resident_f32_tower_vs_oracle(dev, game, depth, channels, head, batches)
     ("ataxx-7", 8, 128, "ataxx_conv", (1, 2, 13)),    # BASELINE configs[1]'s network: two boards per workgroup, ragged
     ("chess", 2, 128, "attention", (3,)),             # 128 channels on an 8x8 board
     ("go-9", 2, 128, "conv", (3,)),                   # 81 pixels: six tiles
+    ("ataxx-7", 4, 64, "ataxx_conv", (5,)),           # BASELINE configs[0]'s network (64 channels)
     ("chess", 2, 32, "dense", (4,)),                  # not a shape of the kernel
 ])
 def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
@@ -519,7 +520,7 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     eng = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32_SPLIT16)
     assert eng.tower_path == "tower_resident_split16"
     exact = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32)
-    assert exact.tower_path == "tower_resident_f32"
+    assert exact.tower_path == ("tower_resident_f32" if channels >= 128 else "conv_igemm_f32")
     for batch in batches:
         bits, scalars_in = synth.random_boards(game, batch, seed=82 + batch)
         dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
@@ -539,6 +540,7 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     ("chess", 2, 128, "attention", (3, 40)),             # 128 channels on an 8x8 board
     ("go-9", 2, 128, "conv", (3, 11)),                   # 81 pixels: six tiles
     ("go-9", 2, 256, "conv", (5, 64)),                   # 256 channels on 81 squares: six tiles, one board per workgroup
+    ("ataxx-7", 4, 64, "ataxx_conv", (7, 256)),          # BASELINE configs[0]'s network (64 channels)
     ("go-19", 2, 128, "conv", (2,)),                     # 361 squares: not a shape of the launch
 ])
 def test_resident_f16g_tower(dev, game, depth, channels, head, batches):
