@@ -29,7 +29,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=256, help="executor batch (gpu_batch_size)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="executor batch (gpu_batch_size); default: BASELINE.json's for the workload (256; Go 512)")
     ap.add_argument("--engines", type=int, default=None,
                     help="executor engines (streams) per GPU = gpu_threads_per_device; default: what fills the chip "
                          "for the workload (chess 2: half-chip launches; ataxx 3: covers its separate head kernels; "
@@ -43,6 +44,8 @@ def parse_args():
                          "two slots per engine); never the configuration `value` is quoted on")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 512 if args.workload == "go19-40x256" else 256
     if args.engines is None:
         args.engines = {"chess-20x256": 2, "ataxx-8x128": 3, "go19-40x256": 1}[args.workload]
     return args
