@@ -138,7 +138,8 @@ struct DeviceWeights {
                 for (int t = 0; t < taps; t++)
                     flat[((size_t)t * d.cout_p + o) * d.cin_p + i] = cv.w[((size_t)o * cv.cin + i) * taps + t];
         if (upload_matrix(flat, taps * d.cout_p, d.cin_p, taps * d.cout_p, d.cin_p, &d.w)) return 1;
-        if ((split16 || pairs16) && cv.k == 1 && kz::conv1x1_split_supported(d.cin_p, d.cout_p)) {
+        // 1x1 head convolutions: the tiled GEMM of kz_tower_split.hip in split arithmetic (split16) or plain f16
+        if ((split16 || dtype == KZ_DTYPE_F16) && cv.k == 1 && kz::conv1x1_split_supported(d.cin_p, d.cout_p)) {
             std::vector<uint16_t> packed(kz::conv1x1_split_weight_elems(d.cin_p, d.cout_p, split16));
             kz::conv1x1_split_pack_weights(cv.w.data(), cv.cout, cv.cin, d.cout_p, d.cin_p, split16, packed.data());
             if (upload(packed.data(), packed.size() * 2, &d.sw)) return 1;
@@ -443,7 +444,7 @@ struct kz_engine {
             HIP_TRY(hipGetLastError());
             return 0;
         }
-        if (w.sw && (split16 || pairs16) && y && !res && !post && !y32 && ldx >= w.cin_p) {  // 1x1 head convolution behind the split / f16g tower
+        if (w.sw && y && !res && !post && !y32 && ldx >= w.cin_p) {  // 1x1 head convolution: split16 or any f16 path
             kz::Conv1x1SplitArgs c{};
             c.split = split16;
             c.x = x; c.ldx = ldx; c.weights = w.sw; c.bias = w.b; c.y = y; c.ldy = ldy;
