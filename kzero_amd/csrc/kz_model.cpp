@@ -79,7 +79,7 @@ bool parse_container(const void *blob, size_t len, Container &c, std::string &er
         t.count = 1;
         for (uint32_t d = 0; d < ndim; d++) {
             t.dims.push_back(r.get<uint64_t>());
-            t.count *= t.dims.back();
+            if (__builtin_mul_overflow(t.count, t.dims.back(), &t.count)) r.bad = true;  // (a hostile file)
         }
         uint64_t off = r.get<uint64_t>(), nbytes = r.get<uint64_t>();
         spans.push_back({name, {off, nbytes}});
@@ -92,8 +92,9 @@ bool parse_container(const void *blob, size_t len, Container &c, std::string &er
     }
     for (auto &s : spans) {
         RawTensor &t = c.tensors[s.first];
-        uint64_t esz = t.dtype == 0 ? 4 : 8;
-        if (t.dtype > 1 || s.second.first + s.second.second > data_len || s.second.second != t.count * esz) {
+        uint64_t esz = t.dtype == 0 ? 4 : 8, end = 0, want = 0;
+        if (t.dtype > 1 || __builtin_add_overflow(s.second.first, s.second.second, &end) || end > data_len ||
+            __builtin_mul_overflow(t.count, esz, &want) || s.second.second != want) {
             err = "tensor '" + s.first + "' out of range";
             return false;
         }
@@ -120,6 +121,23 @@ struct Loader {
         return dflt;
     }
 
+    // (a failure unwinds to parse_model: nothing downstream ever sees a tensor of the wrong size, and a descriptor that
+    //  asks for an absurd size never turns into an allocation)
+    struct Failed {};
+    // a descriptor integer that must lie in [lo, hi] (sizes are products of these: bounded before anything is allocated
+    // or looped over)
+    int geti_in(const char *key, int64_t dflt, int64_t lo, int64_t hi, bool required = false) {
+        const int64_t v = geti(key, dflt, required);
+        if (v < lo || v > hi) {
+            if (ok) {
+                ok = false;
+                err = std::string("descriptor key '") + key + "' out of range";
+            }
+            return (int)lo;
+        }
+        return (int)v;
+    }
+
     std::vector<float> f32(const std::string &name, uint64_t expect) {
         auto it = c.tensors.find(name);
         if (it == c.tensors.end() || it->second.dtype != 0 || it->second.count != expect) {
@@ -127,7 +145,7 @@ struct Loader {
                 ok = false;
                 err = "missing or mis-shaped tensor '" + name + "' (want " + std::to_string(expect) + " f32 values)";
             }
-            return std::vector<float>(expect, 0.0f);
+            throw Failed{};
         }
         std::vector<float> v(expect);
         memcpy(v.data(), it->second.data, expect * 4);
@@ -230,29 +248,42 @@ void finalize_model(Model &m) {
     if (m.param_count == 0) m.param_count = params;
 }
 
+static Model *parse_model_checked(const void *blob, size_t len, std::string &err);
+
 Model *parse_model(const void *blob, size_t len, std::string &err) {
+    try {
+        return parse_model_checked(blob, len, err);
+    } catch (const Loader::Failed &) {
+        if (err.empty()) err = "malformed KZMODEL1 container";
+        return nullptr;
+    } catch (const std::exception &e) {  // bad_alloc / length_error on a hostile file
+        err = std::string("KZMODEL1 container: ") + e.what();
+        return nullptr;
+    }
+}
+
+static Model *parse_model_checked(const void *blob, size_t len, std::string &err) {
     Container c;
     if (!parse_container(blob, len, c, err)) return nullptr;
     Loader L{c, err};
     std::unique_ptr<Model> m(new Model());
 
-    m->h = (int)L.geti("board_h", 0, true);
-    m->w = (int)L.geti("board_w", 0, true);
-    m->n_scalar = (int)L.geti("input_scalar_channels", 0, true);
-    m->n_bool = (int)L.geti("input_bool_channels", 0, true);
+    m->h = L.geti_in("board_h", 0, 1, 64, true);
+    m->w = L.geti_in("board_w", 0, 1, 64, true);
+    m->n_scalar = L.geti_in("input_scalar_channels", 0, 0, 4096, true);
+    m->n_bool = L.geti_in("input_bool_channels", 0, 0, 4096, true);
     m->c_in = m->n_scalar + m->n_bool;
-    m->depth = (int)L.geti("tower_depth", 0, true);
-    m->channels = (int)L.geti("tower_channels", 0, true);
-    m->policy_len = (int)L.geti("policy_len", 0, true);
+    m->depth = L.geti_in("tower_depth", 0, 0, 1024, true);
+    m->channels = L.geti_in("tower_channels", 0, 1, 8192, true);
+    m->policy_len = L.geti_in("policy_len", 0, 1, 1 << 24, true);
     bool final_affine = L.geti("tower_final_affine", 1) != 0;
-    int sh_c = (int)L.geti("scalar_hidden_channels", 4);
-    int sh_s = (int)L.geti("scalar_hidden_size", 32);
+    int sh_c = L.geti_in("scalar_hidden_channels", 4, 1, 4096);
+    int sh_s = L.geti_in("scalar_hidden_size", 32, 1, 1 << 20);
     float eps = 1e-5f;
     if (c.floats.count("bn_eps")) eps = (float)c.floats.at("bn_eps");
     if (c.strings.count("game")) m->game = c.strings.at("game");
     if (!L.ok) return nullptr;
-    if (m->h <= 0 || m->w <= 0 || m->c_in <= 0 || m->depth < 0 || m->channels <= 0 || m->policy_len <= 0 || sh_c <= 0 ||
-        sh_s <= 0) {
+    if (m->c_in <= 0) {
         err = "bad architecture descriptor";
         return nullptr;
     }
@@ -299,7 +330,7 @@ Model *parse_model(const void *blob, size_t len, std::string &err) {
 
     switch (m->policy_kind) {
         case POLICY_ATAXX_CONV: {
-            int pc = m->policy_conv_channels = (int)L.geti("policy_conv_channels", 0, true);
+            int pc = m->policy_conv_channels = L.geti_in("policy_conv_channels", 0, 1, 65536, true);
             if (L.ok && pc * hw + 1 != m->policy_len) {
                 err = "ataxx_conv head: policy_len != policy_conv_channels*h*w + 1";
                 return nullptr;
@@ -310,8 +341,8 @@ Model *parse_model(const void *blob, size_t len, std::string &err) {
             break;
         }
         case POLICY_CONV: {
-            int pc = m->policy_conv_channels = (int)L.geti("policy_conv_channels", 0, true);
-            int ex = m->policy_extra_moves = (int)L.geti("policy_extra_moves", 0);
+            int pc = m->policy_conv_channels = L.geti_in("policy_conv_channels", 0, 1, 65536, true);
+            int ex = m->policy_extra_moves = L.geti_in("policy_extra_moves", 0, 0, 65536);
             if (L.ok && pc * hw + ex != m->policy_len) {
                 err = "conv head: policy_len != policy_conv_channels*h*w + extra_moves";
                 return nullptr;
@@ -327,11 +358,12 @@ Model *parse_model(const void *blob, size_t len, std::string &err) {
             break;
         }
         case POLICY_ATTENTION: {
-            int Q = m->policy_query_channels = (int)L.geti("policy_query_channels", 0, true);
+            int Q = m->policy_query_channels = L.geti_in("policy_query_channels", 0, 1, 8192, true);
             if (L.ok && (m->h != 8 || m->w != 8)) {
                 err = "attention head needs an 8x8 board";
                 return nullptr;
             }
+            if (!L.ok) return nullptr;
             m->p_bulk = L.conv("policy_head.conv_bulk", 2 * Q, C, 1);
             m->p_under = L.conv("policy_head.conv_under", 3 * Q, C, 1);
             auto it = c.tensors.find("policy_head.FLAT_TO_ATT");
@@ -353,8 +385,9 @@ Model *parse_model(const void *blob, size_t len, std::string &err) {
             break;
         }
         case POLICY_DENSE: {
-            int hc = m->dense_hidden_channels = (int)L.geti("policy_dense_hidden_channels", 0);
-            int hs = m->dense_hidden_size = (int)L.geti("policy_dense_hidden_size", 0);
+            int hc = m->dense_hidden_channels = L.geti_in("policy_dense_hidden_channels", 0, 0, 8192);
+            int hs = m->dense_hidden_size = L.geti_in("policy_dense_hidden_size", 0, 0, 1 << 20);
+            if (!L.ok) return nullptr;
             int idx = 0, ch = C;
             if (hc) {
                 m->p_conv0 = L.conv("policy_head.seq.0", hc, C, 1);

@@ -76,9 +76,19 @@ struct OAttr {
     std::shared_ptr<OTensor> t;
 };
 
+// node input / output names: indexing past the end yields the empty name ("absent", as ONNX writes an omitted optional
+// input), which no tensor or node answers to — so a malformed node fails the pattern match with a message instead of
+// reading out of bounds
+struct Names : std::vector<std::string> {
+    const std::string &operator[](size_t i) const {
+        static const std::string none;
+        return i < size() ? std::vector<std::string>::operator[](i) : none;
+    }
+};
+
 struct ONode {
     std::string op;
-    std::vector<std::string> in, out;
+    Names in, out;
     std::map<std::string, OAttr> attr;
     int64_t attr_i(const char *k, int64_t dflt) const { auto it = attr.find(k); return it == attr.end() ? dflt : it->second.i; }
     float attr_f(const char *k, float dflt) const { auto it = attr.find(k); return it == attr.end() ? dflt : it->second.f; }
