@@ -103,3 +103,92 @@ def test_recorded_boards_are_engine_inputs(tmp_path):
     assert dense.shape == (15, 4, 7, 7)
     assert np.array_equal(dense[:, 0, 0, 0], scalars[:, 0])
     assert np.array_equal(dense[3, 1:].reshape(-1).astype(np.uint8), np.unpackbits(bits[3], bitorder="little")[:147])
+
+
+# ---- the C++ writer/reader of the host mirror (kzero_amd/csrc/host/position_file.hpp) against the Python one ----
+def _fnv(parts):
+    h = 1469598103934665603
+    for p in parts:
+        for b in p:
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _checksum_lines(f: PositionFile):
+    out = []
+    for i in range(len(f)):
+        r = f.position(i)
+        parts = [np.array([r.scalars[n] for n in SCALAR_NAMES], dtype="<f4").tobytes(), r.bits.tobytes(),
+                 np.asarray(r.input_scalars, dtype="<f4").tobytes(), np.asarray(r.policy_indices, dtype="<u4").tobytes(),
+                 np.asarray(r.policy_values, dtype="<f4").tobytes()]
+        out.append(f"pos {i} mv {len(r.policy_values)} sum {_fnv(parts):016x}")
+    return out
+
+
+def _tool():
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build = os.path.join(repo, "tests", "cpp", "build")
+    os.makedirs(build, exist_ok=True)
+    exe = os.path.join(build, "position_file_tool")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", os.path.join(repo, "tests", "cpp", "position_file_tool.cpp"),
+                           "-o", exe])
+    return exe
+
+
+def test_cpp_writer_is_read_by_the_python_reader_and_back(tmp_path):
+    import subprocess
+    exe = _tool()
+    # C++ writes, Python reads: every record byte for byte, offsets, game starts, metadata
+    path = str(tmp_path / "games_7")
+    out = subprocess.run([exe, "write", path, "11", "5"], capture_output=True, text=True, check=True).stdout.split("\n")
+    written = [line for line in out if line.startswith("pos ")]
+    f = PositionFile(path)
+    assert f.meta.game == "chess" and list(f.meta.input_bool_shape) == [13, 8, 8] and f.meta.game_count == 5
+    assert not os.path.exists(path + ".json.tmp")
+    assert _checksum_lines(f) == written
+    starts = f.game_starts.tolist()
+    assert starts[0] == 0 and starts == sorted(starts) and len(starts) == 5
+    # ... and the C++ reader reads its own file the same way
+    dumped = subprocess.run([exe, "dump", path], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert [line for line in dumped if line.startswith("pos ")] == written
+    assert dumped[0].startswith(f"meta game chess positions {len(written)} games 5 bits_bytes 104 scalars 8 starts 0")
+    # Python writes, C++ reads
+    games, shape, ns, pshape = _games(np.random.default_rng(3))
+    path2 = str(tmp_path / "games_8")
+    _write(path2, games, shape, ns, pshape)
+    dumped2 = subprocess.run([exe, "dump", path2], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert [line for line in dumped2 if line.startswith("pos ")] == _checksum_lines(PositionFile(path2))
+    assert dumped2[0].startswith("meta game ataxx-7 positions 15 games 3 bits_bytes 19 scalars 1 starts 0 4 9")
+    # a truncated .bin is refused with a message
+    with open(path2 + ".bin", "r+b") as fh:
+        fh.truncate(os.path.getsize(path2 + ".bin") - 3)
+    bad = subprocess.run([exe, "dump", path2], capture_output=True, text=True)
+    assert bad.returncode == 1 and "error:" in bad.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference's own reader only exists in the build container")
+def test_reference_reader_accepts_the_cpp_writers_files(tmp_path):
+    """The reference's DataFile (python/lib/data/file.py) opens what the C++ writer wrote: chess-shaped records."""
+    import subprocess
+    exe = _tool()
+    path = str(tmp_path / "games_9")
+    subprocess.run([exe, "write", path, "5", "4"], capture_output=True, text=True, check=True)
+    ours = PositionFile(path)
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        from lib.data.file import DataFile
+        from lib.games import Game
+        df = DataFile.open(Game.find("chess"), path)
+        assert len(df.positions) == len(ours) and len(df.simulations) == 4
+        for i in range(len(ours)):
+            r, p = ours.position(i), df.positions[i]
+            assert p.available_mv_count == len(r.policy_indices)
+            assert np.array_equal(p.input_bools, np.unpackbits(r.bits, bitorder="little")[:13 * 64].reshape(13, 8, 8))
+            assert np.array_equal(p.input_scalars, r.input_scalars)
+            assert np.array_equal(p.policy_indices, r.policy_indices.astype(np.int32))
+            assert np.array_equal(p.policy_values, r.policy_values)
+    finally:
+        sys.path.remove(REF)
