@@ -7,6 +7,8 @@
 // PolicyMapper concept (rust/kz-core/src/mapping/mod.rs:67-80):
 //     size_t policy_len() const;  size_t move_to_index(const B&, const Move&) const;
 #pragma once
+#include <algorithm>
+#include <string>
 #include <cmath>
 #include <cstddef>
 #include <limits>
@@ -105,6 +107,100 @@ struct DummyNetwork : Network<B> {
             out[i].policy.assign(count, count ? 1.0f / count : 0.0f);
         }
         return out;
+    }
+};
+
+// ---- the other adapters behind the same trait (dummy.rs:18-148, multibatch.rs:10-49) ----
+
+inline ZeroValuesPov uniform_values() { return ZeroValuesPov{0.0f, WDL{1.0f / 3, 1.0f / 3, 1.0f / 3}, 0.0f}; }  // dummy.rs:98-108
+inline std::vector<float> uniform_policy(size_t available_moves) {                                                // :110-112
+    return std::vector<float>(available_moves, available_moves ? 1.0f / (float)available_moves : 0.0f);
+}
+
+// uniform wdl, the inner network's policy (dummy.rs:18-23, 62-78)
+template <class B, class N>
+struct DummyValueNetwork : Network<B> {
+    N inner;
+    explicit DummyValueNetwork(N n) : inner(std::move(n)) {}
+    size_t max_batch_size() const override { return inner.max_batch_size(); }
+    std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
+        auto out = inner.evaluate_batch(boards, n);
+        for (auto &e : out) e.values = uniform_values();
+        return out;
+    }
+};
+
+// the inner network's values, uniform policy (dummy.rs:25-30, 80-96)
+template <class B, class N>
+struct DummyPolicyNetwork : Network<B> {
+    N inner;
+    explicit DummyPolicyNetwork(N n) : inner(std::move(n)) {}
+    size_t max_batch_size() const override { return inner.max_batch_size(); }
+    std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
+        auto out = inner.evaluate_batch(boards, n);
+        for (auto &e : out) e.policy = uniform_policy(e.policy.size());
+        return out;
+    }
+};
+
+// accepts a board wrapper W with `inner()` (MaxMovesBoard<B>) and passes the inner board along (dummy.rs:114-131)
+template <class W, class B, class N>
+struct MaxMovesNetwork : Network<W> {
+    N inner;
+    explicit MaxMovesNetwork(N n) : inner(std::move(n)) {}
+    size_t max_batch_size() const override { return inner.max_batch_size(); }
+    std::vector<ZeroEvaluation> evaluate_batch(const W *boards, size_t n) override {
+        std::vector<B> in;
+        in.reserve(n);
+        for (size_t i = 0; i < n; i++) in.push_back(boards[i].inner());
+        return inner.evaluate_batch(in.data(), n);
+    }
+};
+
+// NetworkOrDummy = Either<N, DummyNetwork> (dummy.rs:133-148): what the executor holds after "UseDummyNetwork"
+template <class B, class L, class R>
+struct EitherNetwork : Network<B> {
+    std::optional<L> left;
+    std::optional<R> right;
+    explicit EitherNetwork(L l) : left(std::move(l)) {}
+    struct RightTag {};
+    EitherNetwork(RightTag, R r) : right(std::move(r)) {}
+    size_t max_batch_size() const override { return left ? left->max_batch_size() : right->max_batch_size(); }
+    std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
+        return left ? left->evaluate_batch(boards, n) : right->evaluate_batch(boards, n);
+    }
+};
+
+// several instances of one network built for different batch sizes: a batch goes to the smallest that fits
+// (multibatch.rs:10-49; with Kyanite every instance is planned for a fixed batch — kz_engine takes any batch up to its
+// max_batch, so this is only needed by callers that already hold such a set)
+template <class B, class I>
+class MultiBatchNetwork : public Network<B> {
+    std::vector<std::pair<size_t, I>> networks_;
+
+  public:
+    explicit MultiBatchNetwork(std::vector<std::pair<size_t, I>> networks) : networks_(std::move(networks)) {}
+    template <class F>
+    static MultiBatchNetwork build_sizes(const std::vector<size_t> &sizes, F f) {  // :19-22
+        std::vector<std::pair<size_t, I>> nets;
+        for (size_t s : sizes) nets.emplace_back(s, f(s));
+        return MultiBatchNetwork(std::move(nets));
+    }
+    size_t used_network_index(size_t batch_size) const {  // :26-31
+        size_t best = networks_.size();
+        for (size_t i = 0; i < networks_.size(); i++)
+            if (networks_[i].first >= batch_size && (best == networks_.size() || networks_[i].first < networks_[best].first)) best = i;
+        if (best == networks_.size()) throw std::invalid_argument("No network for batch size " + std::to_string(batch_size));
+        return best;
+    }
+    size_t used_batch_size(size_t batch_size) const { return networks_[used_network_index(batch_size)].first; }  // :33-35
+    size_t max_batch_size() const override {                                                                      // :39-41
+        size_t m = 0;
+        for (auto &n : networks_) m = std::max(m, n.first);
+        return m;
+    }
+    std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {  // :43-48
+        return networks_[used_network_index(n)].second.evaluate_batch(boards, n);
     }
 };
 

@@ -155,6 +155,71 @@ static void test_mappers() {
     }
 }
 
+// ---- the other adapters behind the Network contract (dummy.rs, multibatch.rs) ----
+struct CountingNet : Network<PackedBoard> {  // value = batch size it was called with, policy = 1, 2, 3, ... per move
+    size_t cap;
+    int *calls;
+    CountingNet(size_t cap, int *calls) : cap(cap), calls(calls) {}
+    size_t max_batch_size() const override { return cap; }
+    std::vector<ZeroEvaluation> evaluate_batch(const PackedBoard *boards, size_t n) override {
+        if (calls) (*calls)++;
+        std::vector<ZeroEvaluation> out(n);
+        for (size_t i = 0; i < n; i++) {
+            out[i].values = ZeroValuesPov{(float)cap, WDL{1, 0, 0}, 7.0f};
+            const size_t moves = boards[i].moves ? boards[i].moves->size() : 0;
+            for (size_t k = 0; k < moves; k++) out[i].policy.push_back((float)(k + 1));
+        }
+        return out;
+    }
+};
+struct WrappedBoard {  // MaxMovesBoard<B>: a board with a move counter around an inner board
+    PackedBoard b;
+    int moves_played = 0;
+    const PackedBoard &inner() const { return b; }
+};
+
+static void test_adapters() {
+    PackedBoard three, none;
+    three.moves = std::vector<int32_t>{4, 5, 6};
+    std::vector<PackedBoard> boards{three, none, three};
+    {
+        DummyValueNetwork<PackedBoard, CountingNet> dv(CountingNet(8, nullptr));
+        auto y = dv.evaluate_batch(boards.data(), boards.size());
+        CHECK(y.size() == 3 && y[0].values.value == 0.0f && std::fabs(y[0].values.wdl.win - 1.0f / 3) < 1e-7f);
+        CHECK((y[0].policy == std::vector<float>{1, 2, 3}) && y[1].policy.empty());
+        DummyPolicyNetwork<PackedBoard, CountingNet> dp(CountingNet(8, nullptr));
+        auto z = dp.evaluate_batch(boards.data(), boards.size());
+        CHECK(z[0].values.value == 8.0f && z[0].values.moves_left == 7.0f);
+        CHECK(z[0].policy.size() == 3 && std::fabs(z[0].policy[1] - 1.0f / 3) < 1e-7f && z[1].policy.empty());
+        CHECK(dp.max_batch_size() == 8);
+    }
+    {
+        std::vector<WrappedBoard> wrapped{{three, 5}, {none, 9}};
+        MaxMovesNetwork<WrappedBoard, PackedBoard, CountingNet> mm(CountingNet(4, nullptr));
+        auto y = mm.evaluate_batch(wrapped.data(), wrapped.size());
+        CHECK(y.size() == 2 && y[0].policy.size() == 3 && y[1].policy.empty() && mm.max_batch_size() == 4);
+    }
+    {
+        using E = EitherNetwork<PackedBoard, CountingNet, DummyNetwork<PackedBoard>>;
+        E left(CountingNet(8, nullptr));
+        E right(E::RightTag{}, DummyNetwork<PackedBoard>{});
+        CHECK(left.max_batch_size() == 8 && left.evaluate_batch(boards.data(), 3)[0].values.value == 8.0f);
+        auto y = right.evaluate_batch(boards.data(), 3);  // "UseDummyNetwork": uniform everything
+        CHECK(y[0].values.value == 0.0f && std::fabs(y[0].policy[2] - 1.0f / 3) < 1e-7f);
+        CHECK(right.max_batch_size() == std::numeric_limits<size_t>::max());
+    }
+    {
+        int calls[3] = {0, 0, 0};
+        int which = 0;
+        auto mb = MultiBatchNetwork<PackedBoard, CountingNet>::build_sizes({16, 2, 4}, [&](size_t s) { return CountingNet(s, &calls[which++]); });
+        CHECK(mb.max_batch_size() == 16);
+        CHECK(mb.used_batch_size(1) == 2 && mb.used_batch_size(2) == 2 && mb.used_batch_size(3) == 4 && mb.used_batch_size(5) == 16);
+        CHECK(mb.evaluate_batch(boards.data(), 3)[0].values.value == 4.0f);  // the smallest instance that fits 3 boards
+        CHECK(calls[0] == 0 && calls[1] == 0 && calls[2] == 1);
+        CHECK(throws([&] { mb.used_network_index(17); }));  // "No network for batch size"
+    }
+}
+
 // ---- chess policy indexing: chess.rs:180-507, pinned to the reference's own data ----
 //  * python/lib/mapping/chess_flat_to_move_input.txt / chess_flat_to_conv.txt / chess_flat_to_att.txt (written by
 //    rust/kz-misc/src/bin/write_chess_mapping.rs from generate_all_flat_moves_pov): every one of the 1880 flat moves,
@@ -654,6 +719,7 @@ int main(int argc, char **argv) {
     std::fputs("mappers\n", stderr); test_mappers();
     std::fputs("decode\n", stderr); test_decode();
     std::fputs("chess policy\n", stderr); test_chess_policy(golden);
+    std::fputs("adapters\n", stderr); test_adapters();
     std::fputs("job_channel\n", stderr); test_job_channel();
     std::fputs("state\n", stderr); test_executor_state();
     std::fputs("loop\n", stderr); test_executor_loop();
