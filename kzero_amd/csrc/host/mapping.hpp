@@ -152,6 +152,12 @@ struct ChessPosition {
     int repetitions = 0, non_pawn_or_capture_moves = 0;
     std::optional<std::vector<Move>> moves;
     std::optional<std::vector<Move>> available_moves() const { return moves; }
+    // earlier positions of the game, oldest first (ChessBoard::history()), for ChessHistoryMapper: absolute colours
+    struct Past {
+        uint64_t pieces[2][6] = {};
+        int repetitions = 0;  // repetitions_for(that board)
+    };
+    std::vector<Past> history;
 };
 
 // chess.rs:173-178: black sees the board with ranks flipped (BitBoard::reverse_colors = byte swap)
@@ -186,6 +192,47 @@ struct ChessStdMapper {
         for (int color : {pov, other})  // pieces, us then them (:160-165)
             for (int piece = 0; piece < 6; piece++) bools.push_block(pov_ranks(b.pieces[color][piece], b.white_to_move));
         bools.push_block(pov_ranks(b.en_passant, b.white_to_move));  // :168-169
+    }
+};
+
+// ChessHistoryMapper (chess.rs:26-124; `Game::ChessHist { length }`, kz-selfplay/src/server/server.rs:162-173): the
+// current board and the last `length` boards of the game.  Bool planes: en passant, then 12 piece planes per board
+// (current first, then history newest to oldest, empty boards as zeros); scalars: side to move (white, black), castling
+// rights (us K/Q, them K/Q), the 50-move counter, then 1 + repetitions per board (0 for an empty one).  Same policy as
+// ChessStdMapper.
+struct ChessHistoryMapper {
+    size_t length;
+    explicit ChessHistoryMapper(size_t length) : length(length) {}
+    std::array<size_t, 3> input_bool_shape() const { return {1 + (length + 1) * 12, 8, 8}; }  // :33-36
+    size_t input_scalar_count() const { return 7 + (length + 1); }                            // :38-40
+    size_t policy_len() const { return 1880; }
+    size_t move_to_index(const ChessPosition &b, ChessMove mv) const { return ChessStdMapper().move_to_index(b, mv); }
+    ChessMove index_to_move(const ChessPosition &b, size_t index) const { return ChessStdMapper().index_to_move(b, index); }
+    void encode_input(BitBuffer &bools, std::vector<float> &scalars, const ChessPosition &b) const {  // :42-81
+        const int pov = b.white_to_move ? 0 : 1, other = 1 - pov;
+        scalars.push_back(pov == 0 ? 1.0f : 0.0f);
+        scalars.push_back(pov == 1 ? 1.0f : 0.0f);
+        for (int color : {pov, other}) {
+            scalars.push_back(b.castle_kingside[color] ? 1.0f : 0.0f);
+            scalars.push_back(b.castle_queenside[color] ? 1.0f : 0.0f);
+        }
+        scalars.push_back((float)b.non_pawn_or_capture_moves);
+        bools.push_block(pov_ranks(b.en_passant, b.white_to_move));
+        auto append_board = [&](const uint64_t (&pieces)[2][6], int repetitions) {  // :83-97
+            for (int color : {pov, other})
+                for (int piece = 0; piece < 6; piece++) bools.push_block(pov_ranks(pieces[color][piece], b.white_to_move));
+            scalars.push_back(1.0f + (float)repetitions);  // one more than the count: tells a real board from padding
+        };
+        append_board(b.pieces, b.repetitions);
+        const size_t have = b.history.size(), used = std::min(length, have);
+        for (size_t k = 0; k < used; k++) {  // newest first
+            const ChessPosition::Past &h = b.history[have - 1 - k];
+            append_board(h.pieces, h.repetitions);
+        }
+        for (size_t k = used; k < length; k++) {
+            for (int i = 0; i < 12; i++) bools.push_block(0);
+            scalars.push_back(0.0f);
+        }
     }
 };
 

@@ -106,6 +106,44 @@ static void test_mappers() {
         CHECK(full[0] == 1 && full[63] == 1 && full[64] == 0 && full[2 * 64 + 5] == 1);
         CHECK(full[8 * 64 + 8] == 1 && full[8 * 64 + 0] == 0);
     }
+    {  // ChessHistoryMapper (chess.rs:26-124): shapes for every length (tests/mapper/chess/pairs.rs:366-368), contents
+        ChessPosition p;
+        p.pieces[0][0] = 0xFF00ull; p.pieces[0][5] = 0x10;
+        p.pieces[1][0] = 0xFFull << 48; p.pieces[1][5] = 0x10ull << 56;
+        p.repetitions = 1;
+        p.non_pawn_or_capture_moves = 3;
+        p.en_passant = 1ull << 20;
+        ChessPosition::Past older, newer;
+        older.pieces[0][0] = 0x1; older.repetitions = 2;
+        newer.pieces[0][0] = 0x2; newer.repetitions = 0;
+        p.history = {older, newer};
+        for (size_t length : {0, 1, 2, 8}) {
+            ChessHistoryMapper m(length);
+            BitBuffer bools(input_bool_len(m));
+            std::vector<float> scalars;
+            m.encode_input(bools, scalars, p);
+            CHECK(bools.len() == input_bool_len(m) && input_bool_len(m) == (1 + (length + 1) * 12) * 64);
+            CHECK(scalars.size() == m.input_scalar_count() && scalars.size() == 7 + length + 1);
+            CHECK((std::vector<float>(scalars.begin(), scalars.begin() + 8) == std::vector<float>{1, 0, 0, 0, 0, 0, 3, 2}));
+            CHECK(bools[20] && !bools[21]);                  // plane 0: en passant
+            CHECK(bools[64 + 8] && bools[64 + 5 * 64 + 4]);  // current board: our pawns, our king
+            if (length >= 1) CHECK(bools[13 * 64 + 1] && !bools[13 * 64 + 0] && scalars[8] == 1.0f);      // newest past board first
+            if (length >= 2) CHECK(bools[25 * 64 + 0] && scalars[9] == 3.0f);                             // then the older one
+            if (length == 8) CHECK(!bools[37 * 64 + 0] && scalars[10] == 0.0f && scalars.back() == 0.0f);  // padding
+            CHECK(m.move_to_index(p, ChessMove{12, 28, 0}) == ChessStdMapper().move_to_index(p, ChessMove{12, 28, 0}));
+        }
+        // black to move: every board, past ones included, is seen with the ranks flipped
+        ChessPosition q = p;
+        q.white_to_move = false;
+        ChessHistoryMapper m(1);
+        BitBuffer bools(input_bool_len(m));
+        std::vector<float> scalars;
+        m.encode_input(bools, scalars, q);
+        CHECK(scalars[0] == 0 && scalars[1] == 1);
+        CHECK(bools[64 + 0 * 64 + 8] && !bools[64 + 0 * 64 + 48]);  // black's pawns (rank 7) appear as "our" pawns on rank 2
+        CHECK(bools[64 + 6 * 64 + 48]);                              // white's pawns (rank 2) as "their" pawns on rank 7
+        CHECK(bools[13 * 64 + 6 * 64 + 57]);  // the newer past board's white pawn on b1 is "theirs", seen on b8
+    }
     for (int size = 2; size <= 8; size++) {  // ataxx: every index maps to a unique move and back (mod.rs:37-72)
         AtaxxStdMapper m(size);
         std::set<size_t> seen;
