@@ -134,3 +134,19 @@ def test_onnx_reader_rejects_what_it_does_not_understand():
     bad = blob.replace(b"BatchNormalization", b"BatchNormalizatioX")
     with pytest.raises(capi.KzError, match="unsupported ONNX graph"):
         capi.Model(blob=bad, onnx_scalar_channels=1)
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/kz_hip.h is the boundary any FFI binds: it must compile as C99 with nothing but the standard headers, and
+    examples/eval_packed.c (model load -> engine -> submit / zero-copy wait) must link against libkzhip.so alone."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "kz_hip.h"\nint main(void) { return KZ_ENGINE_SLOTS == 2 && KZ_DTYPE_F32_SPLIT16 == 2 ? 0 : 1; }\n')
+    REPO = O.REPO
+    inc = os.path.join(REPO, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(tmp_path / "abi")])
+    assert subprocess.run([str(tmp_path / "abi")]).returncode == 0
+    lib = os.path.join(REPO, "kzero_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc,
+                           os.path.join(REPO, "examples", "eval_packed.c"), "-L", lib, "-lkzhip", f"-Wl,-rpath,{lib}",
+                           "-o", str(tmp_path / "eval_packed")])
