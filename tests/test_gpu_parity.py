@@ -328,6 +328,25 @@ def test_config_c1_f32_vs_oracle_sample(dev, chess_full):
     assert_f32(p2, p, "split16 vs exact f32 policy")
 
 
+def test_config_c1_f16_against_the_f32_accurate_launch_on_the_whole_batch(dev, chess_full):
+    """BASELINE.json configs[2] at full size, ALL 256 boards: the oracle needs a second per board, but the split-f16
+    launch is pinned to it at 1e-4 (test_config_c1_f32_vs_oracle_sample) and evaluates the whole batch in milliseconds,
+    so it serves as the f32-accurate reference for every board of the f16 path."""
+    blob, bits, scalars_in = chess_full
+    model = capi.Model(blob=blob)
+    ref = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F32_SPLIT16)
+    s_ref, p_ref = ref.eval_packed(bits, scalars_in)
+    eng = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    assert eng.tower_path == "tower_resident_f16+heads"
+    s, p = eng.eval_packed(bits, scalars_in)
+    rs = assert_f16(s, s_ref, "scalars, 256 boards")
+    rp = assert_f16(p, p_ref, "policy, 256 boards")
+    sm = np.abs(softmax(p) - softmax(p_ref)).max()
+    print(f"chess 20x256 f16 vs f32-accurate, 256 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, max |dsoftmax| {sm:.2e}, "
+          f"rms |dlogit| {np.sqrt(np.mean((p - p_ref) ** 2)):.2e}")
+    assert sm < 1e-3
+
+
 def test_full_size_properties(dev, chess_full):
     """Size-independent properties at the full configuration: permutation equivariance over the batch,
     batch-size invariance, determinism, and agreement of the board-resident tower with the generic per-layer path."""
