@@ -347,6 +347,29 @@ def test_config_c1_f16_against_the_f32_accurate_launch_on_the_whole_batch(dev, c
     assert sm < 1e-3
 
 
+def test_config_g8_go19_40x256_f16_against_exact_f32_on_the_gpu(dev):
+    """BASELINE.json configs[4]'s network at full depth (Go 19x19, 40 blocks x 256 channels), 96 boards: the f16
+    board-tile path against the exact-f32 implicit-GEMM path of the same library (which the small-net tests pin to the
+    oracle at 1e-4; the oracle itself would need ~10 s per board here), plus the oracle on one board."""
+    blob = synth.random_model("go-19", 40, 256, "conv", seed=31)
+    bits, scalars_in = synth.random_boards("go-19", 96, seed=32)
+    model = capi.Model(blob=blob)
+    f32 = capi.Engine(model, dev, 96, capi.KZ_DTYPE_F32)
+    s_ref, p_ref = f32.eval_packed(bits, scalars_in)
+    f16 = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
+    assert f16.tower_path == "board_conv_f16"
+    s, p = f16.eval_packed(bits, scalars_in)
+    rs = assert_f16(s, s_ref, "scalars, 96 boards")
+    rp = assert_f16(p, p_ref, "policy, 96 boards")
+    print(f"go-19 40x256 f16 vs exact f32, 96 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, "
+          f"max |dsoftmax| {np.abs(softmax(p) - softmax(p_ref)).max():.2e}")
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits[:1], scalars_in[:1], net.n_scalar, net.n_bool, net.h, net.w)
+    so, po = net.forward(dense, threads=os.cpu_count() or 1)
+    assert_f32(s_ref[:1], so, "exact f32 vs oracle, scalars")
+    assert_f32(p_ref[:1], po, "exact f32 vs oracle, policy")
+
+
 def test_full_size_properties(dev, chess_full):
     """Size-independent properties at the full configuration: permutation equivariance over the batch,
     batch-size invariance, determinism, and agreement of the board-resident tower with the generic per-layer path."""
