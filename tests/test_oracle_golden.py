@@ -163,3 +163,49 @@ def test_chess_conv_index_known_answers_of_the_reference_tests():
     assert len(rows) == 84 and {r["case"] for r in rows} >= {"castles", "en_passant", "black_potential_promotions"}
     for r in rows:
         assert L.kzo_chess_conv_index(int(r["white_to_move"]), r["from"], r["to"], r["promotion"]) == r["conv_index"], r
+
+
+# ---- property tests of the checker itself (hypothesis): the oracle against independent numpy formulations ----
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(0, 5), st.integers(0, 9), st.integers(1, 9), st.integers(1, 9), st.integers(1, 4), st.integers(0, 2 ** 31))
+def test_encode_input_full_matches_numpy_unpackbits(n_scalar, n_bool, h, w, batch, seed):
+    """encode_input_full (mapping/mod.rs:40-63) for arbitrary shapes: scalar planes are broadcasts, bool planes are
+    np.unpackbits(bitorder="little") of the BitBuffer storage — the formulation of the reference's own reader
+    (python/lib/data/position.py:95-97)."""
+    if n_scalar + n_bool == 0:
+        return
+    rng = np.random.default_rng(seed)
+    nbytes = max((n_bool * h * w + 7) // 8, 1)
+    bits = rng.integers(0, 256, size=(batch, nbytes), dtype=np.uint8)
+    scalars = rng.normal(size=(batch, max(n_scalar, 1))).astype(np.float32)[:, :n_scalar]
+    got = O.encode_input_full(bits, scalars, n_scalar, n_bool, h, w)
+    want = np.empty((batch, n_scalar + n_bool, h, w), np.float32)
+    want[:, :n_scalar] = scalars[:, :, None, None]
+    planes = np.unpackbits(bits, axis=1, bitorder="little")[:, :n_bool * h * w].reshape(batch, n_bool, h, w)
+    want[:, n_scalar:] = planes
+    assert np.array_equal(got, want)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 6), st.integers(2, 60), st.integers(0, 2 ** 31))
+def test_decode_output_matches_numpy(batch, policy_len, seed):
+    """decode_output (network/common.rs:16-100) against a direct numpy softmax / tanh over random legal-move lists."""
+    rng = np.random.default_rng(seed)
+    scalars = rng.normal(size=(batch, 5)).astype(np.float32)
+    logits = (3 * rng.normal(size=(batch, policy_len))).astype(np.float32)
+    moves = [rng.permutation(policy_len)[:rng.integers(0, policy_len + 1)].astype(np.int32) for _ in range(batch)]
+    values, probs = O.decode_output(scalars, logits, moves)
+    for b in range(batch):
+        wdl = np.exp(scalars[b, 1:4] - scalars[b, 1:4].max())
+        wdl /= wdl.sum()
+        np.testing.assert_allclose(values[b], [np.tanh(scalars[b, 0]), *wdl, scalars[b, 4]], rtol=2e-6, atol=1e-7)
+        if len(moves[b]):
+            g = logits[b, moves[b]].astype(np.float64)
+            e = np.exp(g - g.max())
+            np.testing.assert_allclose(probs[b], e / e.sum(), rtol=5e-6, atol=1e-8)
+            assert abs(float(probs[b].sum()) - 1.0) < 1e-5
+        else:
+            assert probs[b].size == 0
