@@ -27,7 +27,8 @@ sys.path.insert(0, REPO)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps; default: about 5 s of the workload (SURVEY.md §8(d)): chess 10000, ataxx 10000, go 400")
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=None,
                     help="executor batch (gpu_batch_size); default: BASELINE.json's for the workload (256; Go 512)")
@@ -46,6 +47,8 @@ def parse_args():
                          "two slots per engine); never the configuration `value` is quoted on")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 400 if args.workload == "go19-40x256" else 10000
     if args.batch is None:
         args.batch = 512 if args.workload == "go19-40x256" else 256
     if args.engines is None:
