@@ -1,30 +1,72 @@
 #!/usr/bin/env python3
 """bench.py — self-play NN evals/sec, Chess 20x256 ResNet, executor batch 256 (BASELINE.json metric).
 
-A "step" is one executor batch (256 synthetic packed boards, already resident in HBM) through the whole hot path:
-board encode -> ResNet tower -> scalar + attention-policy heads, outputs left in HBM.  evals/s = sum of batch lengths of
-completed evaluations / wall time — the reference's own `real` counter (rust/kz-selfplay/src/server/
-server_alphazero.rs:113-115, collector.rs:172-191).  Steps are issued round-robin over `--engines` executor engines per
-GPU (the reference's gpu_threads_per_device, rust/Readme.md:51), each with its own HIP stream.
+A "step" is one executor batch (256 synthetic packed boards) through the whole hot path: board encode -> ResNet tower ->
+scalar + attention-policy heads.  evals/s = sum of batch lengths of completed evaluations / wall time — the reference's
+own `real` counter (rust/kz-selfplay/src/server/server_alphazero.rs:113-115, collector.rs:172-191).  Steps are issued
+round-robin over `--engines` executor engines per GPU (the reference's gpu_threads_per_device, rust/Readme.md:51), each
+with its own HIP stream(s).
 
-Multi-GPU: the path shards by game -> device with no collective (each device has its own job channel, server.rs:325-331):
-one process per GPU, every rank runs K steps on its own boards ("weak" scaling), value = all ranks' evals / max time.
-torch.distributed is only the control plane (barrier + max of the elapsed time) and runs on gloo: there is no tensor
-to exchange, so RCCL/xGMI stay idle by design.
+One JSON line on rank 0 carries
+  * `value`: the K timed steps with the packed boards already resident in HBM and the outputs left in HBM (the
+    measurement contract: inputs resident when the timed region starts);
+  * `pcie_inclusive`: the same K steps through the host-pointer boundary the reference's `evaluate_batch` has
+    (cudnn.rs:55-87: host boards in, host results out): kz_engine_submit_packed -> kz_engine_wait_view, pinned staging,
+    H2D of 136 B and D2H of 7,540 B per evaluation inside the timed region, two slots per engine in flight;
+  * `roofline` for the dominant kernel, HIP events on the engines' own streams over the timed region;
+  * `others` (N=1 only): the other single-GPU BASELINE configs as ~1 s sub-records — A1 Ataxx 8x128 f32 B=256, the G8
+    network Go-19 40x256 f16 B=512, and the chess network through the <=1e-4-parity path (f32split16);
+  * `cpu_baseline` (N=1 only): the oracle on this box's host cores, bounded sample.
 
-Prints ONE JSON line on rank 0.
+Multi-GPU: the path shards by game -> device with no collective (each device has its own job channel,
+server.rs:323-331): one process per GPU.  `--gpus N` without a RANK in the environment starts the N rank processes
+itself (fresh children, before this process touches the GPU); under `torch.distributed.run` the ranks already exist.
+Every rank runs K steps on its own boards ("weak" scaling), value = all ranks' evals / max time.  torch.distributed is
+only the control plane (barrier, max of the elapsed time, gather of the PCI bus ids) and runs on gloo: there is no
+tensor to exchange, so RCCL/xGMI stay idle by design.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+WORKLOADS = {
+    "chess-20x256": dict(game="chess", depth=20, channels=256, head="attention", batch=256, steps=10000,
+                         engines={"f16": 2, "f32": 2, "f32split16": 2},
+                         label="Chess 20x256 ResNet b=256"),
+    "ataxx-8x128": dict(game="ataxx-7", depth=8, channels=128, head="ataxx_conv", batch=256, steps=10000,
+                        engines={"f16": 3, "f32": 3, "f32split16": 3},
+                        label="Ataxx 7x7 8x128 ResNet b=256"),
+    "go19-40x256": dict(game="go-19", depth=40, channels=256, head="conv", batch=512, steps=400,
+                        engines={"f16": 1, "f32": 1, "f32split16": 1},
+                        label="Go 19x19 40x256 ResNet b=512"),
+}
+# the other single-GPU BASELINE configs, reported as sub-records of the default line
+OTHERS = [("ataxx-8x128", "f32"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16")]
 
-def parse_args():
+KERNEL_OF_PATH = {
+    "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
+    "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_split16": "kz_tower_resident_split",
+    "tower_resident_f16g": "kz_tower_resident_f16g", "board_conv_f16": "kz_board_conv_f16",
+    "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32",
+}
+# source file of each dominant kernel: the committed PMC traffic figure is only reported while this file is unchanged
+KERNEL_SOURCE = {
+    "kz_tower_resident_f16": "kz_tower.hip", "kz_tower_resident_f32": "kz_tower_f32.hip",
+    "kz_tower_resident_split": "kz_tower_split.hip", "kz_tower_resident_f16g": "kz_tower_split.hip",
+    "kz_board_conv_f16": "kz_board_conv.hip", "kz_conv_igemm_f16": "kz_kernels.hip", "kz_conv_igemm_f32": "kz_kernels.hip",
+}
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "hbm_traffic.json")
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
@@ -34,33 +76,69 @@ def parse_args():
                     help="executor batch (gpu_batch_size); default: BASELINE.json's for the workload (256; Go 512)")
     ap.add_argument("--engines", type=int, default=None,
                     help="executor engines (streams) per GPU = gpu_threads_per_device; default: what fills the chip "
-                         "for the workload (chess 2: half-chip launches; ataxx 3: covers its separate head kernels; "
-                         "go 1: a launch per layer already fills the chip)")
+                         "for the workload (chess 2: half-chip launches; ataxx 3; go 1: a launch per layer fills the chip)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f32split16"],
                     help="f32split16: f32 tensors and <=1e-4 parity, tower products as three f16 MFMAs on (hi, lo) pairs")
-    ap.add_argument("--workload", default="chess-20x256", choices=["chess-20x256", "ataxx-8x128", "go19-40x256"])
+    ap.add_argument("--workload", default="chess-20x256", choices=sorted(WORKLOADS))
     ap.add_argument("--prewarm", type=float, default=0.25,
                     help="seconds of untimed conditioning steps before the --warmup steps (0 to disable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-io", action="store_true",
-                    help="diagnostic: feed host buffers through kz_engine_submit_packed/kz_engine_wait (PCIe-inclusive, "
-                         "two slots per engine); never the configuration `value` is quoted on")
+    ap.add_argument("--no-others", action="store_true", help="skip the sub-records of the other BASELINE configs")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive timed region")
+    ap.add_argument("--other-seconds", type=float, default=1.0, help="timed seconds per sub-record")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
-    args = ap.parse_args()
+    ap.add_argument("--fake-step", type=float, default=None, metavar="MS",
+                    help="TEST ONLY (tests/test_bench_launcher.py): no GPU, no library — a step is a sleep of MS "
+                         "milliseconds; exercises the rank launcher and the aggregation; the line says data=fake")
+    args = ap.parse_args(argv)
+    wl = WORKLOADS[args.workload]
+    explicit = args.steps is not None or args.batch is not None or args.engines is not None
     if args.steps is None:
-        args.steps = 400 if args.workload == "go19-40x256" else 10000
+        args.steps = wl["steps"]
     if args.batch is None:
-        args.batch = 512 if args.workload == "go19-40x256" else 256
+        args.batch = wl["batch"]
     if args.engines is None:
-        args.engines = {"chess-20x256": 2, "ataxx-8x128": 3, "go19-40x256": 1}[args.workload]
+        args.engines = wl["engines"][args.dtype]
+    args.is_default_line = args.workload == "chess-20x256" and args.dtype == "f16" and args.batch == 256
+    del explicit
     return args
 
 
-WORKLOADS = {
-    "chess-20x256": dict(game="chess", depth=20, channels=256, head="attention"),
-    "ataxx-8x128": dict(game="ataxx-7", depth=8, channels=128, head="ataxx_conv"),
-    "go19-40x256": dict(game="go-19", depth=40, channels=256, head="conv"),
-}
+# ------------------------------------------------------------------------------------------------------------------
+# rank launcher: `python bench.py --gpus N` on its own starts N fresh rank processes (one per GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    """Starts N children with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, BEFORE this process has made any HIP call (a
+    process that has initialised the GPU must not fork+exec on this pool).  Rank 0 prints the one JSON line; the exit
+    code is the worst child's."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            r = p.poll()
+            if r is None:
+                continue
+            procs.remove(p)
+            if r != 0:
+                rc = rc or r
+                deadline = deadline or time.time() + 20.0  # a failed rank: give the others a moment, then stop them
+        if deadline and time.time() > deadline:
+            for p in procs:
+                p.kill()  # exact PIDs we started
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.05)
+    return rc
 
 
 def usable_cores():
@@ -87,7 +165,6 @@ def usable_cores():
 def cpu_baseline(blob, bits, scalars_in, target_seconds):
     """The CPU restatement (oracle, kind 'port') timed on this box's host cores, on a bounded sample of the same
     boards.  Reported beside the GPU number; never the thing measured as `value`."""
-    import numpy as np
     from tests import oracle_lib as O
     net = O.OracleNet(blob)
     cores = usable_cores()
@@ -107,153 +184,281 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
                       f"single-thread {1.0 / one:.3f} evals/s"}
 
 
+def committed_traffic(kernel: str, workload: str, batch: int):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/hbm_traffic.json, written by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950
+    correction) — reported only while the kernel's source file still has the hash it had when the passes ran."""
+    try:
+        table = json.load(open(TRAFFIC_FILE))
+        src = os.path.join(REPO, "kzero_amd", "csrc", KERNEL_SOURCE[kernel])
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for rec in table.get("records", []):
+        if rec["kernel"] == kernel and rec["workload"] == workload and rec["batch"] == batch:
+            if rec["source_sha256_16"] != sha:
+                return None, f"stale: {KERNEL_SOURCE[kernel]} changed since {rec['profile']}"
+            return rec["traffic_bytes_per_launch"], rec["profile"]
+    return None, None
+
+
+class Workload:
+    """One (network, dtype, batch) on one device: engines, resident inputs, the two kinds of step."""
+
+    def __init__(self, capi, synth, name, dtype_name, batch, n_engines, device, seed):
+        import numpy as np
+        self.np, self.capi = np, capi
+        self.name, self.dtype_name, self.B, self.device = name, dtype_name, batch, device
+        wl = WORKLOADS[name]
+        self.wl = wl
+        dtype = {"f16": capi.KZ_DTYPE_F16, "f32": capi.KZ_DTYPE_F32, "f32split16": capi.KZ_DTYPE_F32_SPLIT16}[dtype_name]
+        self.blob = synth.random_model(wl["game"], wl["depth"], wl["channels"], wl["head"], seed=0)
+        self.model = capi.Model(blob=self.blob)
+        self.info = self.model.info
+        self.bits, self.scalars_in = synth.random_boards(wl["game"], batch, seed=seed)
+        self.engines = [capi.Engine(self.model, device, batch, dtype) for _ in range(n_engines)]
+        self.d_bits = capi.DeviceBuffer.from_host(device, self.bits)
+        self.d_sin = capi.DeviceBuffer.from_host(device, self.scalars_in)
+        self.outs = [(capi.DeviceBuffer(device, batch * 5 * 4), capi.DeviceBuffer(device, batch * self.info.policy_len * 4))
+                     for _ in self.engines]
+        self.stride = self.bits.shape[1]
+        self.inflight = {}
+        self.tower_path = self.engines[0].tower_path
+        self.kernel = KERNEL_OF_PATH[self.tower_path]
+
+    def step_resident(self, i):
+        e = i % len(self.engines)
+        self.engines[e].enqueue_packed_device(self.d_bits, self.stride, self.d_sin, self.B, self.outs[e][0], self.outs[e][1])
+
+    def step_host(self, i):
+        # round-robin over (engine, slot); wait for the slot's previous batch before reusing it.  Results are read in
+        # place through kz_engine_wait_view (the lifetime of the reference executor's `&[DTensor]`, cudnn.rs:73-82)
+        n, S = len(self.engines), self.capi.KZ_ENGINE_SLOTS
+        e, slot = i % n, (i // n) % S
+        if (e, slot) in self.inflight:
+            self.engines[e].wait_view(slot, self.inflight.pop((e, slot)))
+        self.inflight[(e, slot)] = self.engines[e].submit_packed(slot, self.bits, self.scalars_in)
+
+    def sync(self):
+        for (e, slot), n in list(self.inflight.items()):
+            self.engines[e].wait_view(slot, n)
+        self.inflight.clear()
+        for e in self.engines:
+            e.synchronize()
+        self.capi.check(self.capi.load().kz_device_synchronize(self.device))
+
+    def profiling(self, on):
+        for e in self.engines:
+            e.set_profiling(on)
+
+    def kernel_time(self):
+        ms, n = 0.0, 0
+        for e in self.engines:
+            m, k = e.kernel_time(self.kernel)
+            ms += m
+            n += k
+        return ms, n
+
+    def condition(self, step, seconds):
+        """Conditioning, not measurement: takes the device out of its idle power state and through first-launch set-up,
+        so that a short --steps/--warmup run measures the same steady state as a long one."""
+        t_end = time.perf_counter() + seconds
+        i = 0
+        while time.perf_counter() < t_end:
+            step(i)
+            i += 1
+        self.sync()
+        return i
+
+    def check_finite(self):
+        s = self.outs[0][0].to_host(self.np.float32, (self.B, 5))
+        assert self.np.isfinite(s).all(), "non-finite network output"
+
+    def flops_per_launch(self, launches_per_step):
+        info, B = self.info, self.B
+        hw, C = info.board_h * info.board_w, info.tower_channels
+        tower = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
+        p = self.tower_path
+        if p == "tower_resident_f16+heads":
+            return info.flops_per_eval * B  # one launch = tower + heads for one batch
+        if p.startswith("tower_resident"):
+            return tower * B  # one launch = the whole tower for one batch
+        if p == "board_conv_f16":
+            return 2.0 * hw * 9 * C * C * B  # one launch per 3x3 tower convolution (the stem goes through conv_igemm)
+        return info.flops_per_eval * B / max(launches_per_step, 1)  # per-layer launches: average over the step
+
+    def roofline(self, k_ms, k_n, steps, evals_per_s_per_gpu):
+        peak = 157.3 if self.dtype_name == "f32" else 2500.0  # f32split16: algorithmic FLOP against the f16 matrix cores
+        avg_ms = k_ms / max(k_n, 1)
+        fpl = self.flops_per_launch(k_n / max(steps, 1))
+        achieved = fpl / (avg_ms * 1e-3) / 1e12 if k_n else 0.0
+        wgs, per = self.engines[0].launch_geometry(self.B)
+        traffic, source = committed_traffic(self.kernel, self.name, self.B)
+        # `achieved`/`frac` follow the contract literally: algorithmic FLOP of ONE launch / its average duration.  A
+        # resident launch covers `workgroups_per_launch` of the 256 CUs and `concurrent_launches` run side by side, so
+        # the chip-level figure is `chip_frac` (all engines' FLOP / wall time), not `frac`.
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
+                "avg_launch_ms": round(avg_ms, 5), "launches": k_n, "flop_per_launch": fpl,
+                "workgroups_per_launch": wgs, "boards_per_workgroup": per or None,
+                "concurrent_launches": len(self.engines),
+                "chip_frac": round(evals_per_s_per_gpu * self.info.flops_per_eval / 1e12 / peak, 4)}
+
+    def close(self):
+        self.sync()
+        for e in self.engines:
+            e.close()
+        for a, b in self.outs:
+            a.free()
+            b.free()
+        self.d_bits.free()
+        self.d_sin.free()
+        self.model.close()
+
+
+def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm):
+    """~`seconds` of timed steps of another BASELINE config on this GPU (N=1 only), device-resident like `value`."""
+    wl = WORKLOADS[name]
+    w = Workload(capi, synth, name, dtype_name, wl["batch"], wl["engines"][dtype_name], device, seed=1000)
+    try:
+        w.condition(w.step_resident, prewarm)
+        t0 = time.perf_counter()
+        probe = max(4, 2 * len(w.engines))
+        for i in range(probe):
+            w.step_resident(i)
+        w.sync()
+        per = (time.perf_counter() - t0) / probe
+        steps = max(probe, int(seconds / max(per, 1e-6)))
+        w.profiling(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            w.step_resident(i)
+        w.sync()
+        dt = time.perf_counter() - t0
+        k_ms, k_n = w.kernel_time()
+        w.profiling(False)
+        w.check_finite()
+        value = steps * w.B / dt
+        return {"metric": f"self-play NN evals/sec, {wl['label']}, 1 GPU", "workload": name, "dtype": dtype_name,
+                "value": round(value, 1), "unit": "evals/s", "batch": w.B, "steps": steps,
+                "ms_per_step": round(dt / steps * 1e3, 4), "engines_per_gpu": len(w.engines), "tower_path": w.tower_path,
+                "flop_per_eval": w.info.flops_per_eval, "roofline": w.roofline(k_ms, k_n, steps, value)}
+    finally:
+        w.close()
+
+
+def fake_main(args, benchlib, rank, world, dist):
+    """--fake-step: the launcher and aggregation without a GPU (tests/test_bench_launcher.py)."""
+    def step(i):
+        time.sleep(args.fake_step * 1e-3)
+    elapsed = benchlib.run_timed(step, lambda: None, args.steps, args.warmup, dist)
+    seen = benchlib.gather_strings(dist, f"fake:{rank}")
+    if rank == 0:
+        print(json.dumps({"metric": "fake steps/sec (launcher test)", "value": round(args.steps * world / elapsed, 3),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "fake", "devices_seen": sorted(set(seen)),
+                          "config": {"workload": "sleep", "parallelism": f"dp{world} (no collective)"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse_args()
     from kzero_amd import benchlib
     rank, local_rank, world, distributed = benchlib.rank_info()
-    torch = None
+    if args.gpus > 1 and not distributed:
+        return spawn_ranks(args)  # nothing in this process has touched the GPU
+    if distributed and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
     if distributed:
-        import torch  # noqa: F811  (control plane only; imported before the HIP library on purpose)
+        import torch  # noqa: F401  (control plane only; imported before the HIP library on purpose)
     dist = benchlib.init_control_plane()
+    if args.fake_step is not None:
+        return fake_main(args, benchlib, rank, world, dist)
 
-    import numpy as np
     from kzero_amd import capi, synth
-
     ndev = capi.device_count()
-    device = local_rank % max(ndev, 1)
-    dtype = {"f16": capi.KZ_DTYPE_F16, "f32": capi.KZ_DTYPE_F32, "f32split16": capi.KZ_DTYPE_F32_SPLIT16}[args.dtype]
-    wl = WORKLOADS[args.workload]
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if ndev < local_world or local_rank >= ndev:
+        # never fold several ranks onto one GPU: a scaling curve measured that way would be wrong without any error
+        print(f"bench.py: rank {rank} needs device {local_rank} of {local_world} on this node, but only {ndev} GPU(s) "
+              f"are visible", file=sys.stderr)
+        return 3
+    device = local_rank
+    devices_seen = benchlib.gather_strings(dist, capi.device_pci_bus_id(device))
+    if len(set(devices_seen)) != world:
+        print(f"bench.py: {world} ranks on {len(set(devices_seen))} distinct GPUs: {devices_seen}", file=sys.stderr)
+        return 3
 
-    blob = synth.random_model(wl["game"], wl["depth"], wl["channels"], wl["head"], seed=0)
-    model = capi.Model(blob=blob)
-    info = model.info
+    w = Workload(capi, synth, args.workload, args.dtype, args.batch, args.engines, device, benchlib.board_seed(rank))
     B = args.batch
-    bits, scalars_in = synth.random_boards(wl["game"], B, seed=benchlib.board_seed(rank))
 
-    engines = [capi.Engine(model, device, B, dtype) for _ in range(args.engines)]
-    d_bits = capi.DeviceBuffer.from_host(device, bits)
-    d_sin = capi.DeviceBuffer.from_host(device, scalars_in)
-    outs = [(capi.DeviceBuffer(device, B * 5 * 4), capi.DeviceBuffer(device, B * info.policy_len * 4))
-            for _ in engines]
-    stride = bits.shape[1]
+    # ---- timed region 1 (`value`): inputs resident in HBM, outputs left in HBM ----
+    w.condition(w.step_resident, args.prewarm)
+    elapsed = benchlib.run_timed(w.step_resident, w.sync, args.steps, args.warmup, dist,
+                                 on_timed_start=lambda: w.profiling(True))
+    k_ms, k_n = w.kernel_time()
+    w.profiling(False)
+    w.check_finite()
+    value = benchlib.whole_job_value(args.steps, B, world, elapsed)
 
-    inflight = {}
-
-    def step_host(i):
-        # round-robin over (engine, slot); wait for the slot's previous batch before reusing it
-        e, slot = i % len(engines), (i // len(engines)) % capi.KZ_ENGINE_SLOTS
-        if (e, slot) in inflight:
-            engines[e].wait_view(slot, inflight.pop((e, slot)))  # zero-copy: the results stay in pinned staging
-        inflight[(e, slot)] = engines[e].submit_packed(slot, bits, scalars_in)
-
-    def step(i):
-        if args.host_io:
-            return step_host(i)
-        e = i % len(engines)
-        engines[e].enqueue_packed_device(d_bits, stride, d_sin, B, outs[e][0], outs[e][1])
-
-    def sync_all():
-        for (e, slot), n in list(inflight.items()):
-            engines[e].wait_view(slot, n)
-        inflight.clear()
-        for e in engines:
-            e.synchronize()
-        capi.check(capi.load().kz_device_synchronize(device))
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
-
-    def start_profiling():
-        for e in engines:
-            e.set_profiling(True)
-
-    # Conditioning, not measurement: a quarter of a second of the same steps takes the device out of its idle power
-    # state and through first-launch set-up before the W warm-up steps and the K timed steps of the contract, so that a
-    # short --steps/--warmup run measures the same steady state as a long one.
-    t_end = time.perf_counter() + args.prewarm
-    i = 0
-    while time.perf_counter() < t_end:
-        step(i)
-        i += 1
-    sync_all()
-    elapsed = benchlib.run_timed(step, sync_all, args.steps, args.warmup, dist, on_timed_start=start_profiling)
-
-    # dominant kernel, timed with HIP events on the engines' own streams over the timed region
-    tower_path = engines[0].tower_path
-    kname = {"tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
-             "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_split16": "kz_tower_resident_split", "tower_resident_f16g": "kz_tower_resident_f16g",
-             "board_conv_f16": "kz_board_conv_f16", "conv_igemm_f16": "kz_conv_igemm_f16",
-             "conv_igemm_f32": "kz_conv_igemm_f32"}[tower_path]
-    k_ms, k_n = 0.0, 0
-    for e in engines:
-        ms, n = e.kernel_time(kname)
-        k_ms += ms
-        k_n += n
-        e.set_profiling(False)
-
-    # sanity: outputs are finite numbers
-    if not args.host_io:
-        s_host = outs[0][0].to_host(np.float32, (B, 5))
-        assert np.isfinite(s_host).all(), "non-finite network output"
+    # ---- timed region 2 (`pcie_inclusive`): the same K steps through the host-pointer boundary ----
+    host = None
+    if not args.no_host_io:
+        w.condition(w.step_host, min(args.prewarm, 0.1))
+        h_elapsed = benchlib.run_timed(w.step_host, w.sync, args.steps, args.warmup, dist,
+                                       on_timed_start=lambda: w.profiling(True))
+        h_ms, h_n = w.kernel_time()
+        w.profiling(False)
+        h_value = benchlib.whole_job_value(args.steps, B, world, h_elapsed)
+        info = w.info
+        host = {"value": round(h_value, 1), "unit": "evals/s", "steps": args.steps,
+                "ms_per_step": round(h_elapsed / args.steps * 1e3, 4), "of_resident": round(h_value / value, 4),
+                "entry_points": "kz_engine_submit_packed -> kz_engine_wait_view (pinned staging, "
+                                f"{capi.KZ_ENGINE_SLOTS} slots per engine)",
+                "h2d_bytes_per_eval": int(w.stride + 4 * info.input_scalar_channels),
+                "d2h_bytes_per_eval": int(4 * (5 + info.policy_len)),
+                "kernel_avg_launch_ms": round(h_ms / max(h_n, 1), 5),
+                "chip_frac": round(h_value / world * info.flops_per_eval / 1e12 / (157.3 if args.dtype == "f32" else 2500.0), 4)}
 
     if rank != 0:
+        w.close()
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return 0
 
-    value = benchlib.whole_job_value(args.steps, B, world, elapsed)
-    hw = info.board_h * info.board_w
-    C = info.tower_channels
-    tower_flops = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
-    if tower_path == "tower_resident_f16+heads":
-        flops_per_launch = info.flops_per_eval * B  # one launch = tower + heads for one batch
-    elif tower_path in ("tower_resident_f16", "tower_resident_f32", "tower_resident_split16", "tower_resident_f16g"):
-        flops_per_launch = tower_flops * B  # one launch = the whole tower for one batch
-    elif tower_path == "board_conv_f16":
-        # one launch per 3x3 tower convolution except the stem (which has too few input channels for this kernel)
-        flops_per_launch = 2.0 * hw * 9 * C * C * B
-    else:
-        # per-layer launches (tower + the 1x1 head convolutions that share the kernel): average over the step
-        head_flops = info.flops_per_eval - tower_flops
-        launches_per_step = k_n / max(args.steps, 1)
-        flops_per_launch = (tower_flops + head_flops) * B / max(launches_per_step, 1)
-    # f32split16: algorithmic FLOP (one multiply-add per product) against the f16 matrix cores that execute three
-    peak = 157.3 if args.dtype == "f32" else 2500.0
-    avg_ms = k_ms / max(k_n, 1)
-    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if k_n else 0.0
-    # `achieved`/`frac` follow the contract literally: algorithmic FLOP of ONE launch / its average duration.  A resident
-    # launch covers ceil(batch / boards_per_workgroup) of the 256 CUs and `engines` launches run side by side, so the
-    # chip-level figure is `chip_frac` (all engines' FLOP / wall time), not `frac`.
-    nb = int(os.environ.get("KZ_TOWER_NB", "2")) if tower_path.startswith("tower_resident_f16") else None
-    wgs = -(-B // (1 if nb == 1 else 2)) if nb else None
-    # HBM-side bytes per launch of this kernel at this shape, from the separate rocprofv3 --pmc passes committed under
-    # profiles/r1_pmc_final/ (FETCH_SIZE 188,179 KiB x2 per the gfx950 wide-read correction + WRITE_SIZE 1,888 KiB):
-    # each of the 8 non-coherent XCD L2s pulls the 49 MB weight stream once.  None for shapes that were not profiled.
-    traffic = None
-    if tower_path == "tower_resident_f16+heads" and B == 256 and args.workload == "chess-20x256":
-        traffic = (2 * 188179.35 + 1888.0) * 1024
-    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
-                "launches": k_n, "flop_per_launch": flops_per_launch,
-                "workgroups_per_launch": wgs, "concurrent_launches": args.engines,
-                "chip_frac": round(value / world * info.flops_per_eval / 1e12 / peak, 4)}
-
+    wl = WORKLOADS[args.workload]
+    metric = ("self-play NN evals/sec (node), Chess 20x256 ResNet b=256, 1/2/4/8 GPU" if args.is_default_line else
+              f"self-play NN evals/sec (node), {wl['label'].rsplit(' b=', 1)[0]} b={B}, {world} GPU")
     out = {
-        "metric": "self-play NN evals/sec (node), Chess 20x256 ResNet b=256, 1/2/4/8 GPU",
+        "metric": metric,
         "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, " +
-                               ("host buffers over PCIe (diagnostic)" if args.host_io else "packed boards resident in HBM"),
-                   "engines_per_gpu": args.engines, "conditioning_s": args.prewarm, "tower_path": tower_path, "parallelism": f"dp{world} (no collective)",
-                   "flop_per_eval": info.flops_per_eval},
-        "roofline": roofline,
+        "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, packed boards resident in HBM",
+                   "engines_per_gpu": args.engines, "conditioning_s": args.prewarm, "tower_path": w.tower_path,
+                   "parallelism": f"dp{world} (no collective)", "flop_per_eval": w.info.flops_per_eval,
+                   "device_resident_evals_s": round(value, 1),
+                   "pcie_inclusive_evals_s": host["value"] if host else None},
+        "devices_seen": sorted(set(devices_seen)),
+        "roofline": w.roofline(k_ms, k_n, args.steps, value / world),
     }
+    if host:
+        out["pcie_inclusive"] = host
+    blob, bits, scalars_in = w.blob, w.bits, w.scalars_in
+    w.close()
+    if world == 1 and args.is_default_line and not args.no_others:
+        out["others"] = [sub_record(capi, synth, n, d, device, args.other_seconds, args.prewarm) for n, d in OTHERS]
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(blob, bits, scalars_in, args.cpu_seconds)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -62,6 +62,9 @@ const char *kz_last_error(void);
 
 /* Replaces CudaDevice::all() (rust/kz-selfplay/src/server/server.rs:48-52). */
 int kz_device_count(int *count);
+/* PCI bus id of `device` as a NUL-terminated string ("0000:c1:00.0"): lets a launcher that starts one process per GPU
+ * prove that its ranks sit on distinct devices (bench.py reports the set). */
+int kz_device_pci_bus_id(int device, char *buf, size_t len);
 
 /* ---- model: replaces load_graph_from_onnx_path + optimize_graph (server_alphazero.rs:126-128) ----
  * Accepts the KZMODEL1 container (kzero_amd/model_file.py); Conv+BN folding happens here. */
@@ -151,9 +154,14 @@ int kz_device_synchronize(int device);
  * profiling was last enabled (it synchronizes the stream first). */
 int kz_engine_set_profiling(kz_engine *engine, int enable);
 int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_ms, int64_t *launches);
-/* Name of the path the engine chose: "tower_resident_f16+heads" (whole network in one launch), "tower_resident_f16",
- * "conv_igemm_f16" or "conv_igemm_f32" (per-layer launches). */
+/* Name of the path the engine chose.  One launch for the whole tower: "tower_resident_f16+heads" (chess attention
+ * network, heads included), "tower_resident_f16", "tower_resident_f16g" (other board-resident f16 shapes),
+ * "tower_resident_f32" (exact f32), "tower_resident_split16" (KZ_DTYPE_F32_SPLIT16).  One launch per layer:
+ * "board_conv_f16" (whole boards as LDS tiles, Go-size boards), "conv_igemm_f16", "conv_igemm_f32". */
 const char *kz_engine_tower_path(const kz_engine *engine);
+/* How the dominant launch of that path covers the chip for a batch of `batch` boards: workgroups per launch and boards
+ * per workgroup (per-layer paths: boards_per_workgroup = 0 when a workgroup holds a tile, not whole boards). */
+int kz_engine_launch_geometry(const kz_engine *engine, int batch, int *workgroups, int *boards_per_workgroup);
 
 /* ---- debugging / parity: copy an intermediate activation of the last evaluation to the host as f32 NCHW.
  * name: "tower.<i>" as in python/lib/model/post_act.py's nn.Sequential indices (0 = stem, 1..d = blocks,

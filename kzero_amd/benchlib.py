@@ -23,8 +23,29 @@ def init_control_plane():
         return None
     import torch.distributed as dist
     if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # gloo's C++ side announces its connections on stdout; stdout carries exactly one JSON line, so the
+        # announcement goes to stderr
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return dist
+
+
+def gather_strings(dist, s: str):
+    """Every rank's string, in rank order, on every rank (e.g. the PCI bus id of the GPU a rank drives)."""
+    if dist is None:
+        return [s]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, s)
+    return out
 
 
 def board_seed(rank: int) -> int:

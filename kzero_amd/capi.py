@@ -36,6 +36,7 @@ class ModelInfo(C.Structure):
 SIGNATURES = {
     "kz_last_error": (C.c_char_p, []),
     "kz_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "kz_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "kz_model_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "kz_model_load_memory": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "kz_model_load_onnx": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "kz_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "kz_engine_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "kz_engine_tower_path": (C.c_char_p, [C.c_void_p]),
+    "kz_engine_launch_geometry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kz_engine_read_activation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]),
 }
 
@@ -99,6 +101,12 @@ def device_count() -> int:
     n = C.c_int()
     check(load().kz_device_count(C.byref(n)))
     return n.value
+
+
+def device_pci_bus_id(device: int) -> str:
+    buf = C.create_string_buffer(64)
+    check(load().kz_device_pci_bus_id(device, buf, len(buf)))
+    return buf.value.decode()
 
 
 class Model:
@@ -178,6 +186,12 @@ class Engine:
     @property
     def tower_path(self) -> str:
         return load().kz_engine_tower_path(self._h).decode()
+
+    def launch_geometry(self, batch: int):
+        """(workgroups per launch, boards per workgroup) of the path's dominant launch at `batch`."""
+        wgs, per = C.c_int(), C.c_int()
+        check(load().kz_engine_launch_geometry(self._h, batch, C.byref(wgs), C.byref(per)))
+        return wgs.value, per.value
 
     def eval_dense(self, x: np.ndarray):
         info = self.model.info

@@ -660,6 +660,12 @@ KZ_API int kz_device_count(int *count) {
     return 0;
 }
 
+KZ_API int kz_device_pci_bus_id(int device, char *buf, size_t len) {
+    if (!buf || len < 16) return fail("kz_device_pci_bus_id: buffer of at least 16 bytes needed");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)len, device));
+    return 0;
+}
+
 KZ_API int kz_model_load_onnx_memory(const void *blob, size_t len, int input_scalar_channels, kz_model **out) {
     if (!blob || !out) return fail("kz_model_load_onnx: null argument");
     std::string err;
@@ -869,6 +875,22 @@ KZ_API int kz_engine_max_batch(const kz_engine *e) { return e ? e->max_batch : 0
 
 KZ_API const char *kz_engine_tower_path(const kz_engine *e) { return e ? e->path.c_str() : ""; }
 
+KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgroups, int *boards_per_workgroup) {
+    if (!e || !workgroups || !boards_per_workgroup) return fail("kz_engine_launch_geometry: null argument");
+    if ((batch < 0 || batch > e->max_batch ? fail("kz_engine_launch_geometry: batch out of range") : 0)) return 1;
+    const Model &m = *e->model;
+    int per = 0, wgs = 0;
+    if (e->resident) per = kz::tower_resident_boards_per_workgroup();
+    else if (e->split16 || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
+    else if (e->resident32) per = kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
+    if (per) wgs = (batch + per - 1) / per;
+    else if (e->path == "board_conv_f16") wgs = kz::board_conv_workgroups(batch, m.h, m.w, m.channels);
+    else wgs = kz::conv_workgroups(e->dtype, batch * m.h * m.w, e->cp);
+    *workgroups = wgs;
+    *boards_per_workgroup = per;
+    return 0;
+}
+
 static int check_packed(const kz_engine *e, const char *fn) {
     if (e && e->model->n_scalar < 0)
         return fail(std::string(fn) + ": the model was loaded from ONNX without the scalar/bool plane split; load it "
@@ -895,10 +917,12 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
     if (batch > 0 && (!bits || (m.n_scalar && !scalars_in))) return fail("kz_engine_submit_packed: null input");
     if (batch > 0 && bits_stride < bits_bytes) return fail("kz_engine_submit_packed: bits_stride too small");
     HIP_TRY(hipSetDevice(e->device));
-    s.batch = batch;
-    if (batch == 0) return 0;
+    if (batch == 0) {
+        s.batch = 0;
+        return 0;
+    }
     for (int b = 0; b < batch; b++) memcpy(s.h_bits + b * bits_bytes, bits + b * bits_stride, bits_bytes);
-    memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
+    if (m.n_scalar) memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
     // on the fused path every slot has its own stream, so two submitted batches run side by side (each resident
     // launch covers half of the CUs at batch 256); otherwise the slots share the activation buffers and one stream
     struct StreamSwap {
@@ -913,6 +937,7 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
     HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, (size_t)batch * 5 * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(s.h_pol, s.d_pol, (size_t)batch * m.policy_len * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipEventRecord(s.done, e->stream));
+    s.batch = batch;  // in flight only once the event is recorded: a failed submit leaves the slot free
     return 0;
 }
 

@@ -369,6 +369,14 @@ void launch_conv(int dtype, const ConvArgs &a, hipStream_t stream) {
     else launch_conv_t<h16>(a, stream);
 }
 
+// grid size launch_conv picks for a 3x3 tower convolution of M rows and cout_p channels (same dispatch as above)
+int conv_workgroups(int dtype, int M, int cout_p) {
+    (void)dtype;
+    if (cout_p % 128 == 0 && M >= 128 * 128) return ((M + 127) / 128) * (cout_p / 128);
+    if (cout_p % 64 == 0) return ((M + 63) / 64) * (cout_p / 64);
+    return ((M + 63) / 64) * (cout_p / 32);
+}
+
 const char *conv_kernel_name(int dtype) { return dtype == 0 ? "kz_conv_igemm_f32" : "kz_conv_igemm_f16"; }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -46,6 +46,7 @@ struct ConvArgs {
 };
 void launch_conv(int dtype, const ConvArgs &a, hipStream_t stream);
 const char *conv_kernel_name(int dtype);
+int conv_workgroups(int dtype, int M, int cout_p);
 
 // ScalarHead (post_act.py:10-23) from the tower output x [batch*hw][ldx] -> scalars [batch][5] f32
 struct ScalarHeadArgs {
@@ -193,6 +194,7 @@ struct TowerArgs {
     float *scalars, *policy;
 };
 bool tower_resident_supported(int dtype, int h, int w, int channels, int depth);
+int tower_resident_boards_per_workgroup();  // 2 (1 with KZ_TOWER_NB=1)
 bool tower_heads_supported(int policy_kind, int query_channels, int policy_len, int sh_channels, int sh_size);
 size_t tower_packed_weight_elems(int cin_p, int depth);
 size_t tower_heads_weight_elems();

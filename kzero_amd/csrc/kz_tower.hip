@@ -596,6 +596,8 @@ void pack_1x1(const float *w, uint16_t *dst) {
 
 }  // namespace
 
+int tower_resident_boards_per_workgroup() { return boards_per_wg(); }
+
 bool tower_resident_supported(int dtype, int h, int w, int channels, int depth) {
     return dtype == 1 && h == 8 && w == 8 && channels == C && depth >= 1;
 }
