@@ -92,7 +92,6 @@ def parse_args(argv=None):
                          "milliseconds; exercises the rank launcher and the aggregation; the line says data=fake")
     args = ap.parse_args(argv)
     wl = WORKLOADS[args.workload]
-    explicit = args.steps is not None or args.batch is not None or args.engines is not None
     if args.steps is None:
         args.steps = wl["steps"]
     if args.batch is None:
@@ -100,7 +99,6 @@ def parse_args(argv=None):
     if args.engines is None:
         args.engines = wl["engines"][args.dtype]
     args.is_default_line = args.workload == "chess-20x256" and args.dtype == "f16" and args.batch == 256
-    del explicit
     return args
 
 
@@ -225,6 +223,10 @@ class Workload:
         self.inflight = {}
         self.tower_path = self.engines[0].tower_path
         self.kernel = KERNEL_OF_PATH[self.tower_path]
+        # host-pointer loop: on the fused path an engine's two slots own a stream each, so ONE executor thread keeps
+        # both half-chip launches in flight; more launches than the chip holds at once (engines x slots x 128 workgroups
+        # > 256 CUs) only queue, and on a cold start that queueing has been seen to stall a stream for ~8 ms
+        self.host_engines = self.engines[:1] if self.tower_path == "tower_resident_f16+heads" else self.engines
 
     def step_resident(self, i):
         e = i % len(self.engines)
@@ -233,15 +235,15 @@ class Workload:
     def step_host(self, i):
         # round-robin over (engine, slot); wait for the slot's previous batch before reusing it.  Results are read in
         # place through kz_engine_wait_view (the lifetime of the reference executor's `&[DTensor]`, cudnn.rs:73-82)
-        n, S = len(self.engines), self.capi.KZ_ENGINE_SLOTS
+        n, S = len(self.host_engines), self.capi.KZ_ENGINE_SLOTS
         e, slot = i % n, (i // n) % S
         if (e, slot) in self.inflight:
-            self.engines[e].wait_view(slot, self.inflight.pop((e, slot)))
-        self.inflight[(e, slot)] = self.engines[e].submit_packed(slot, self.bits, self.scalars_in)
+            self.host_engines[e].wait_view(slot, self.inflight.pop((e, slot)))
+        self.inflight[(e, slot)] = self.host_engines[e].submit_packed(slot, self.bits, self.scalars_in)
 
     def sync(self):
         for (e, slot), n in list(self.inflight.items()):
-            self.engines[e].wait_view(slot, n)
+            self.host_engines[e].wait_view(slot, n)
         self.inflight.clear()
         for e in self.engines:
             e.synchronize()
@@ -417,6 +419,7 @@ def main():
         info = w.info
         host = {"value": round(h_value, 1), "unit": "evals/s", "steps": args.steps,
                 "ms_per_step": round(h_elapsed / args.steps * 1e3, 4), "of_resident": round(h_value / value, 4),
+                "engines_per_gpu": len(w.host_engines),
                 "entry_points": "kz_engine_submit_packed -> kz_engine_wait_view (pinned staging, "
                                 f"{capi.KZ_ENGINE_SLOTS} slots per engine)",
                 "h2d_bytes_per_eval": int(w.stride + 4 * info.input_scalar_channels),
