@@ -24,7 +24,12 @@ extern "C" {
 #endif
 
 #define KZ_DTYPE_F32 0 /* f32 storage, exact-f32 MFMA: the <=1e-4 parity path (the reference is f32 only, cudnn.rs:73) */
-#define KZ_DTYPE_F16 1 /* f16 storage, f32 accumulate: the throughput path */
+#define KZ_DTYPE_F16 1 /* f16 storage, f32 accumulate: the throughput path.  RANGE: activations are stored as f16, so a
+                          residual stream beyond +-65504 overflows; the overflow is DETECTED, not saturated: the call that
+                          returns the batch (kz_engine_eval_*, kz_engine_wait*, or kz_engine_synchronize after the
+                          device-resident entry points) fails with a "non-finite activation" message and the caller
+                          should evaluate that network with KZ_DTYPE_F32.  The same limit and the same check apply to
+                          KZ_DTYPE_F32_SPLIT16 (its (hi, lo) pairs are f16 too) */
 #define KZ_DTYPE_F32_SPLIT16 2 /* f32 tensors and the same <=1e-4 parity as KZ_DTYPE_F32, but the tower's products run on
                                   the f16 matrix cores: every activation and weight as a (hi, lo) f16 pair, three MFMAs per
                                   product, f32 accumulate.  256 tower channels on <= 64 squares or 64 / 128 channels on

@@ -385,10 +385,13 @@ struct kz_engine {
     struct Slot {
         uint8_t *d_bits = nullptr, *h_bits = nullptr;
         float *d_sin = nullptr, *h_sin = nullptr;
+        // d_sout / h_sout start with a 16-byte header: [0] = the range-check flag (kz::ScalarHeadArgs::nonfinite_flag),
+        // so that it crosses PCIe in the same copy as the scalars
         float *d_sout = nullptr, *h_sout = nullptr;
         float *d_pol = nullptr, *h_pol = nullptr;
         hipEvent_t done = nullptr;
         int batch = -1;
+        int epoch = 0;  // what the flag reads when this submission saw a non-finite activation
         // device-side decode (N2): CSR move lists, decoded values, probabilities, error flag; grown on demand
         bool decoded = false;  // what is in flight was submitted with a move list
         size_t move_cap = 0, moves = 0;
@@ -398,6 +401,33 @@ struct kz_engine {
         int *d_err = nullptr, *h_err = nullptr;
     } slots[KZ_ENGINE_SLOTS];
     float *d_dense = nullptr, *h_dense = nullptr;
+    static constexpr int SOUT_HDR = 4;  // floats in front of the scalars
+    // range check (see kz::ScalarHeadArgs): every submission gets a new epoch; a kernel that meets a non-finite
+    // activation raises the flag it was given to that epoch.  No reset between batches is needed.
+    int epoch = 0;
+    int *nf_flag = nullptr;  // what the running forward pass writes to
+    int nf_epoch = 0;
+    int *d_devflag = nullptr;  // flag of the device-resident entry points, checked by kz_engine_synchronize
+    int dev_epoch_checked = 0;
+    void arm(Slot &s) {  // the forward pass enqueued next reports into this slot's header
+        s.epoch = ++epoch;
+        nf_flag = reinterpret_cast<int *>(s.d_sout);
+        nf_epoch = s.epoch;
+    }
+    static bool slot_nonfinite(const Slot &s) { return *reinterpret_cast<const int *>(s.h_sout) == s.epoch; }
+    int check_devflag() {
+        if (!d_devflag || dev_epoch_checked == epoch) return 0;
+        int v = 0;
+        HIP_TRY(hipMemcpy(&v, d_devflag, 4, hipMemcpyDeviceToHost));
+        const int since = dev_epoch_checked;
+        dev_epoch_checked = epoch;
+        if (v > since) return fail(nonfinite_message("kz_engine_synchronize"));
+        return 0;
+    }
+    static std::string nonfinite_message(const char *fn) {
+        return std::string(fn) + ": non-finite activation in the network output of this batch (beyond +-65504 the f16 "
+               "and split-f16 paths overflow: evaluate this network with KZ_DTYPE_F32)";
+    }
 
     // debugging
     bool keep = false;
@@ -495,6 +525,7 @@ struct kz_engine {
             t.sh_w0 = wts->sh_w0; t.sh_b0 = wts->sh_b0; t.sh_w1 = wts->sh_w1; t.sh_b1 = wts->sh_b1;
             t.sh_w2 = wts->sh_w2; t.sh_b2 = wts->sh_b2; t.att_idx = wts->att_idx;
             t.scalars = d_scalars; t.policy = d_policy;
+            t.nonfinite_flag = nf_flag; t.epoch = nf_epoch;
             prof.begin("kz_tower_resident_f16", stream);
             kz::launch_tower_resident(t, stream);
             prof.end(stream);
@@ -551,7 +582,8 @@ struct kz_engine {
         const void *x = act[tower_out];
         {
             kz::ScalarHeadArgs a{x, cp, batch, hw, m.channels, m.sh_conv.cout, m.sh_fc0.out,
-                                 wts->sh_w0, wts->sh_b0, wts->sh_w1, wts->sh_b1, wts->sh_w2, wts->sh_b2, d_scalars};
+                                 wts->sh_w0, wts->sh_b0, wts->sh_w1, wts->sh_b1, wts->sh_w2, wts->sh_b2, d_scalars,
+                                 nf_flag, nf_epoch};
             prof.begin("kz_scalar_head", stream);
             kz::launch_scalar_head(dtype, a, stream);
             prof.end(stream);
@@ -857,16 +889,20 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     for (auto &s : e->slots) {
         if (e->dmalloc((void **)&s.d_bits, max_batch * bits_bytes) ||
             e->dmalloc((void **)&s.d_sin, (size_t)max_batch * ns_planes * 4) ||
-            e->dmalloc((void **)&s.d_sout, (size_t)max_batch * 5 * 4) ||
+            e->dmalloc((void **)&s.d_sout, ((size_t)max_batch * 5 + kz_engine::SOUT_HDR) * 4) ||
             e->dmalloc((void **)&s.d_pol, (size_t)max_batch * m.policy_len * 4))
             return 1;
         if (e->hmalloc((void **)&s.h_bits, max_batch * bits_bytes) ||
             e->hmalloc((void **)&s.h_sin, (size_t)max_batch * ns_planes * 4) ||
-            e->hmalloc((void **)&s.h_sout, (size_t)max_batch * 5 * 4) ||
+            e->hmalloc((void **)&s.h_sout, ((size_t)max_batch * 5 + kz_engine::SOUT_HDR) * 4) ||
             e->hmalloc((void **)&s.h_pol, (size_t)max_batch * m.policy_len * 4))
             return 1;
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(hipMemset(s.d_sout, 0, kz_engine::SOUT_HDR * 4));
+        memset(s.h_sout, 0, kz_engine::SOUT_HDR * 4);
     }
+    if (e->dmalloc((void **)&e->d_devflag, 16)) return 1;
+    HIP_TRY(hipMemset(e->d_devflag, 0, 16));
     *out = e.release();
     return 0;
 }
@@ -933,8 +969,10 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
     if (e->slot_stream[slot]) e->stream = e->slot_stream[slot];
     HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
-    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout, s.d_pol)) return 1;
-    HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, (size_t)batch * 5 * 4, hipMemcpyDeviceToHost, e->stream));
+    e->arm(s);
+    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol)) return 1;
+    HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, ((size_t)batch * 5 + kz_engine::SOUT_HDR) * 4, hipMemcpyDeviceToHost,
+                           e->stream));
     HIP_TRY(hipMemcpyAsync(s.h_pol, s.d_pol, (size_t)batch * m.policy_len * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipEventRecord(s.done, e->stream));
     s.batch = batch;  // in flight only once the event is recorded: a failed submit leaves the slot free
@@ -952,8 +990,9 @@ KZ_API int kz_engine_wait(kz_engine *e, int slot, float *scalars_out, float *pol
     if (!scalars_out || !policy_out) return fail("kz_engine_wait: null output");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(s.done));
-    memcpy(scalars_out, s.h_sout, (size_t)batch * 5 * 4);
+    memcpy(scalars_out, s.h_sout + kz_engine::SOUT_HDR, (size_t)batch * 5 * 4);
     memcpy(policy_out, s.h_pol, (size_t)batch * e->model->policy_len * 4);
+    if (kz_engine::slot_nonfinite(s)) return fail(kz_engine::nonfinite_message("kz_engine_wait"));
     return 0;
 }
 
@@ -965,11 +1004,12 @@ KZ_API int kz_engine_wait_view(kz_engine *e, int slot, const float **scalars_out
     if (s.batch < 0 || s.decoded) return fail("kz_engine_wait_view: nothing submitted on this slot");
     const int batch = s.batch;
     s.batch = -1;
-    *scalars_out = s.h_sout;
+    *scalars_out = s.h_sout + kz_engine::SOUT_HDR;
     *policy_out = s.h_pol;
     if (batch == 0) return 0;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(s.done));
+    if (kz_engine::slot_nonfinite(s)) return fail(kz_engine::nonfinite_message("kz_engine_wait_view"));
     return 0;
 }
 
@@ -1033,10 +1073,11 @@ KZ_API int kz_engine_submit_packed_decoded(kz_engine *e, int slot, const uint8_t
     HIP_TRY(hipMemcpyAsync(s.d_moff, s.h_moff, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, e->stream));
     if (total) HIP_TRY(hipMemcpyAsync(s.d_midx, s.h_midx, total * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemsetAsync(s.d_err, 0, 4, e->stream));
-    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout, s.d_pol)) return 1;
+    e->arm(s);
+    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol)) return 1;
     e->prof.begin("kz_decode_output", e->stream);
-    kz::launch_decode_output(s.d_sout, s.d_pol, batch, m.policy_len, s.d_moff, s.d_midx, s.d_values, s.d_probs, s.d_err,
-                             e->stream);
+    kz::launch_decode_output(s.d_sout + kz_engine::SOUT_HDR, s.d_pol, batch, m.policy_len, s.d_moff, s.d_midx, s.d_values,
+                             s.d_probs, s.d_err, reinterpret_cast<const int *>(s.d_sout), s.epoch, e->stream);
     e->prof.end(e->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(s.h_values, s.d_values, (size_t)batch * 20, hipMemcpyDeviceToHost, e->stream));
@@ -1063,6 +1104,7 @@ KZ_API int kz_engine_wait_decoded(kz_engine *e, int slot, const float **values_o
     if (batch == 0) return 0;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(s.done));
+    if (*s.h_err & 2) return fail(kz_engine::nonfinite_message("kz_engine_wait_decoded"));
     if (*s.h_err) return fail("kz_engine_wait_decoded: Softmax input sum must be strictly positive (or a move index is out of range)");
     return 0;
 }
@@ -1099,12 +1141,15 @@ KZ_API int kz_engine_eval_dense(kz_engine *e, const float *input_nchw, int batch
     }
     memcpy(e->h_dense, input_nchw, batch * per);
     HIP_TRY(hipMemcpyAsync(e->d_dense, e->h_dense, batch * per, hipMemcpyHostToDevice, e->stream));
-    if (e->forward_dense(e->d_dense, batch, s.d_sout, s.d_pol)) return 1;
-    HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, (size_t)batch * 5 * 4, hipMemcpyDeviceToHost, e->stream));
+    e->arm(s);
+    if (e->forward_dense(e->d_dense, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol)) return 1;
+    HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, ((size_t)batch * 5 + kz_engine::SOUT_HDR) * 4, hipMemcpyDeviceToHost,
+                           e->stream));
     HIP_TRY(hipMemcpyAsync(s.h_pol, s.d_pol, (size_t)batch * m.policy_len * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    memcpy(scalars_out, s.h_sout, (size_t)batch * 5 * 4);
+    memcpy(scalars_out, s.h_sout + kz_engine::SOUT_HDR, (size_t)batch * 5 * 4);
     memcpy(policy_out, s.h_pol, (size_t)batch * m.policy_len * 4);
+    if (kz_engine::slot_nonfinite(s)) return fail(kz_engine::nonfinite_message("kz_engine_eval_dense"));
     return 0;
 }
 
@@ -1119,6 +1164,8 @@ KZ_API int kz_engine_enqueue_packed_device(kz_engine *e, const void *d_bits, siz
     if (bits_stride < (size_t)(m.n_bool * m.h * m.w + 7) / 8)
         return fail("kz_engine_enqueue_packed_device: bits_stride too small");
     HIP_TRY(hipSetDevice(e->device));
+    e->nf_flag = e->d_devflag;
+    e->nf_epoch = ++e->epoch;
     return e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
 }
 
@@ -1128,13 +1175,16 @@ KZ_API int kz_engine_enqueue_dense_device(kz_engine *e, const void *d_input_nchw
     if (batch == 0) return 0;
     if (!d_input_nchw || !d_scalars_out || !d_policy_out) return fail("kz_engine_enqueue_dense_device: null argument");
     HIP_TRY(hipSetDevice(e->device));
+    e->nf_flag = e->d_devflag;
+    e->nf_epoch = ++e->epoch;
     return e->forward_dense(d_input_nchw, batch, d_scalars_out, d_policy_out);
 }
 
 KZ_API int kz_engine_synchronize(kz_engine *e) {
     if (!e) return fail("kz_engine_synchronize: null engine");
     HIP_TRY(hipSetDevice(e->device));
-    return e->sync_all();
+    if (e->sync_all()) return 1;
+    return e->check_devflag();
 }
 
 KZ_API int kz_device_malloc(int device, size_t bytes, void **out) {

@@ -464,6 +464,8 @@ struct ScalarHeadDev {
     int ldx, batch, hw, c, hc, hs;
     const float *w0, *b0, *w1, *b1, *w2, *b2;
     float *out;
+    int *nonfinite_flag;
+    int epoch;
 };
 
 template <typename T>
@@ -474,19 +476,25 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const T *xb = static_cast<const T *>(a.x) + (size_t)b * a.hw * a.ldx;
 
+    bool bad = false;  // a non-finite sum = a non-finite value somewhere in this board's tower output
     if (a.hc == 4 && rows_coalescable<T>(a.ldx)) {
         const float bias[4] = {a.b0[0], a.b0[1], a.b0[2], a.b0[3]};
         rows_dot<T, 4>(xb, a.ldx, a.hw, a.c, a.w0, [&](int p, const float(&sum)[4]) {
 #pragma unroll
-            for (int ch = 0; ch < 4; ch++) act[ch * a.hw + p] = fmaxf(sum[ch] + bias[ch], 0.0f);
+            for (int ch = 0; ch < 4; ch++) {
+                bad |= !(fabsf(sum[ch]) <= 3.0e38f);
+                act[ch * a.hw + p] = fmaxf(sum[ch] + bias[ch], 0.0f);
+            }
         });
     } else {
         for (int o = tid; o < a.hc * a.hw; o += 256) {
             const int ch = o / a.hw, p = o % a.hw;
             const float v = dot_row<T>(xb + (size_t)p * a.ldx, a.w0 + (size_t)ch * a.c, a.c) + a.b0[ch];
+            bad |= !(fabsf(v) <= 3.0e38f);
             act[o] = fmaxf(v, 0.0f);
         }
     }
+    if (bad && a.nonfinite_flag) atomicMax(a.nonfinite_flag, a.epoch);
     __syncthreads();
     const int n_in = a.hc * a.hw;
     for (int j = wave; j < a.hs; j += 4) {
@@ -505,7 +513,8 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
 }
 
 void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream) {
-    ScalarHeadDev d{a.x, a.ldx, a.batch, a.hw, a.c, a.hc, a.hs, a.w0, a.b0, a.w1, a.b1, a.w2, a.b2, a.out};
+    ScalarHeadDev d{a.x, a.ldx, a.batch, a.hw, a.c, a.hc, a.hs, a.w0, a.b0, a.w1, a.b1, a.w2, a.b2, a.out,
+                    a.nonfinite_flag, a.epoch};
     size_t shmem = sizeof(float) * ((size_t)a.hc * a.hw + a.hs);
     if (dtype == 0) kz_scalar_head<float><<<a.batch, 256, shmem, stream>>>(d);
     else kz_scalar_head<h16><<<a.batch, 256, shmem, stream>>>(d);
@@ -641,10 +650,12 @@ __global__ __launch_bounds__(256) void kz_decode_output(const float *__restrict_
                                                         const int64_t *__restrict__ move_offsets,
                                                         const int32_t *__restrict__ move_indices,
                                                         float *__restrict__ values, float *__restrict__ probs,
-                                                        int *__restrict__ error_flag) {
+                                                        int *__restrict__ error_flag,
+                                                        const int *__restrict__ nonfinite_flag, int epoch) {
     __shared__ float red[4];
     __shared__ float bcast;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (b == 0 && tid == 0 && nonfinite_flag && *nonfinite_flag == epoch) atomicOr(error_flag, 2);
     if (tid == 0) {
         const float *s = scalars + (size_t)b * 5;
         const float m = fmaxf(s[1], fmaxf(s[2], s[3]));
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(256) void kz_decode_output(const float *__restrict_
         v[2] = e1 / sum;
         v[3] = e2 / sum;
         v[4] = s[4];
-        if (!(sum > 0.0f)) atomicExch(error_flag, 1);
+        if (!(sum > 0.0f)) atomicOr(error_flag, 1);
     }
     const int64_t lo = move_offsets[b], hi = move_offsets[b + 1];
     const int n = (int)(hi - lo);
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(256) void kz_decode_output(const float *__restrict_
     __syncthreads();
     if (tid == 0) {
         bcast = red[0] + red[1] + red[2] + red[3];
-        if (!(bcast > 0.0f)) atomicExch(error_flag, 1);
+        if (!(bcast > 0.0f)) atomicOr(error_flag, 1);
     }
     __syncthreads();
     const float inv_sum = bcast;
@@ -704,9 +715,9 @@ __global__ __launch_bounds__(256) void kz_decode_output(const float *__restrict_
 
 void launch_decode_output(const float *scalars, const float *logits, int batch, int policy_len,
                           const int64_t *move_offsets, const int32_t *move_indices, float *values, float *probs,
-                          int *error_flag, hipStream_t stream) {
+                          int *error_flag, const int *nonfinite_flag, int epoch, hipStream_t stream) {
     kz_decode_output<<<batch, 256, 0, stream>>>(scalars, logits, policy_len, move_offsets, move_indices, values, probs,
-                                                error_flag);
+                                                error_flag, nonfinite_flag, epoch);
 }
 
 void launch_attention(int dtype, const AttentionArgs &a, hipStream_t stream) {

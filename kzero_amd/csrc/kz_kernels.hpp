@@ -56,6 +56,11 @@ struct ScalarHeadArgs {
     const float *w1, *b1;  // [hs][hc*hw] (channel-major flatten index c*hw + p), [hs]
     const float *w2, *b2;  // [5][hs], [5]
     float *out;
+    // range check: when a pre-activation sum of the head's 1x1 convolution (it reads every value of the tower output)
+    // is not finite, *nonfinite_flag = max(*nonfinite_flag, epoch).  An f16 overflow anywhere in the residual stream
+    // persists to the tower output (x + relu(..) never removes an inf/NaN), so this is where every path checks it.
+    int *nonfinite_flag = nullptr;
+    int epoch = 0;
 };
 void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream);
 
@@ -95,9 +100,10 @@ void launch_attention(int dtype, const AttentionArgs &a, hipStream_t stream);
 
 // F7 — decode_output (rust/kz-core/src/network/common.rs:16-100) on the device: values [batch][5] = tanh / wdl softmax /
 // moves_left; probs = per-board softmax over the logits at the available-move indices (CSR lists).
+// error_flag: bit 0 = a softmax sum is not strictly positive; bit 1 = *nonfinite_flag == epoch (see ScalarHeadArgs)
 void launch_decode_output(const float *scalars, const float *logits, int batch, int policy_len,
                           const int64_t *move_offsets, const int32_t *move_indices, float *values, float *probs,
-                          int *error_flag, hipStream_t stream);
+                          int *error_flag, const int *nonfinite_flag, int epoch, hipStream_t stream);
 
 // ---- per-layer 3x3 convolution with the board as an LDS-resident spatial tile (kz_board_conv.hip): f16, cin and cout
 // multiples of 64, h*w <= 384.  Same epilogue contract as ConvArgs. ----
@@ -192,6 +198,8 @@ struct TowerArgs {
     const float *sh_w0, *sh_b0, *sh_w1, *sh_b1, *sh_w2, *sh_b2;
     const int32_t *att_idx;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
     float *scalars, *policy;
+    int *nonfinite_flag;  // fused heads only: see ScalarHeadArgs
+    int epoch;
 };
 bool tower_resident_supported(int dtype, int h, int w, int channels, int depth);
 int tower_resident_boards_per_workgroup();  // 2 (1 with KZ_TOWER_NB=1)

@@ -60,6 +60,8 @@ struct TowerDev {
     const float *sh_w0, *sh_b0, *sh_w1, *sh_b1, *sh_w2, *sh_b2;
     const int32_t *att_idx;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
     float *scalars, *policy;
+    int *nonfinite_flag;  // range check (fused heads), see ScalarHeadArgs in kz_kernels.hpp
+    int epoch;
 };
 
 template <int NB>
@@ -430,6 +432,9 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) s += (float)xv[j] * w0[j] + (float)xv[4 + j] * w1[j];
                 }
+                // range check: this sum runs over every channel of one square of the tower output, and an f16 overflow
+                // anywhere in the residual stream persists to the tower output (x + relu(..) never removes an inf/NaN)
+                if (!(fabsf(s) <= 3.0e38f) && a.nonfinite_flag && board0 + b < a.batch) atomicMax(a.nonfinite_flag, a.epoch);
                 act[o] = fmaxf(s, 0.0f);
             }
         }
@@ -676,6 +681,8 @@ void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
     d.att_idx = t.att_idx;
     d.scalars = t.scalars;
     d.policy = t.policy;
+    d.nonfinite_flag = t.nonfinite_flag;
+    d.epoch = t.epoch;
     const bool heads = t.fused_heads;
     // (the dynamic-LDS attribute is per device: set it on every launch's current device, it is a cheap host call,
     //  but only once per kernel and device)

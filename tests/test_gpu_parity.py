@@ -4,8 +4,12 @@ Tolerances:
   f32 path: max |delta| <= 1e-4 on policy logits and the 5 scalars (BASELINE.json north_star / BASELINE.md §4).
   f16 path: 1e-4 is not attainable by construction (f16 storage of weights and activations, f32 accumulate: every
             layer rounds the residual stream to 11 bits).  Stated tolerance, per board and per output tensor:
-            max |delta| <= F16_REL * max(1, max |ref|)   with F16_REL = 1e-2
-            (measured: ~5e-3 RMS of the logit scale after 41 convolutions; the tests print the measured maximum).
+            max |delta| <= F16_REL * max(1, max |ref|)   with F16_REL = 5e-3   (largest value any test measures: 2.3e-3)
+            rms |delta| <= F16_RMS * max(1, max |ref|)   with F16_RMS = 1e-3   (measured 3.4e-4: rms |dlogit| 1.1e-3 at
+                                                                                logit scale 3.3, chess 20x256)
+            A mis-scaled layer or a wrong weight fragment moves the rms by far more than 3x.
+            Two f16 paths of this library against each other (same operands and rounding points, different summation
+            order) are bounded relative to the output scale as well: F16_PATHS_REL for 2-block nets, _DEEP for 40+ layers.
 """
 import os
 
@@ -19,10 +23,20 @@ from tests import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 F32_ATOL = 1e-4
-F16_REL = 1e-2
-# two f16 paths of this library against each other (measured <= 2e-4 on 2-block nets, <= 4e-3 after 41 convolutions)
+F16_REL = 5e-3
+F16_RMS = 1e-3
+# two f16 paths of this library against each other (measured <= 2e-4 on 2-block nets, <= 4e-3 after 41 convolutions at
+# logit scale 3.3): absolute on the shallow nets (outputs of order 1), relative to the output scale on the deep ones
 F16_PATHS_ATOL = 2e-3
-F16_PATHS_ATOL_DEEP = 2e-2
+F16_PATHS_REL_DEEP = 3e-3
+
+
+def assert_f16_paths_deep(a, b, what):
+    """Two f16 paths after 40+ layers: max |delta| relative to the tensor's own scale."""
+    scale = max(1.0, float(np.abs(b).max()))
+    d = float(np.abs(a - b).max()) / scale
+    print(f"[f16 paths] {what}: max |delta| / scale = {d:.3e} (scale {scale:.2f})")
+    assert d <= F16_PATHS_REL_DEEP, f"{what}: {d:.3e} > {F16_PATHS_REL_DEEP}"
 
 
 def assert_f32(actual, ref, what):
@@ -33,8 +47,10 @@ def assert_f32(actual, ref, what):
 def assert_f16(actual, ref, what):
     scale = np.maximum(1.0, np.abs(ref).max(axis=-1, keepdims=True))
     rel = (np.abs(actual - ref) / scale).max()
-    print(f"[f16] {what}: max |delta| / scale = {rel:.3e}")
+    rms = float(np.sqrt(np.mean(((actual - ref) / scale) ** 2)))
+    print(f"[f16] {what}: max |delta| / scale = {rel:.3e}, rms = {rms:.3e}")
     assert rel <= F16_REL, f"{what}: max |delta| / scale = {rel:.3e} > {F16_REL}"
+    assert rms <= F16_RMS, f"{what}: rms |delta| / scale = {rms:.3e} > {F16_RMS}"
     return rel
 
 
@@ -289,10 +305,12 @@ def chess_full():
 
 
 def test_config_c1_chess_20x256_f16_vs_oracle_sample(dev, chess_full):
-    """BASELINE.json configs[2] at full size; the oracle checks a sample of boards (it needs ~1 s per board)."""
+    """BASELINE.json configs[2] at full size; the REAL oracle on 32 of the 256 boards (one board takes the oracle about
+    0.3 s on one core; all host threads are used), both boards of 16 workgroups, the half-empty edges included."""
     blob, bits, scalars_in = chess_full
     net = O.OracleNet(blob)
-    pick = np.array([0, 1, 63, 64, 127, 128, 200, 255])
+    pick = np.array([0, 1, 2, 3, 62, 63, 64, 65, 126, 127, 128, 129, 198, 199, 200, 201, 254, 255] + list(range(10, 220, 15)))
+    assert len(set(pick.tolist())) == 32
     dense = O.encode_input_full(bits[pick], scalars_in[pick], net.n_scalar, net.n_bool, net.h, net.w)
     s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
     eng = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F16)
@@ -347,27 +365,98 @@ def test_config_c1_f16_against_the_f32_accurate_launch_on_the_whole_batch(dev, c
     assert sm < 1e-3
 
 
-def test_config_g8_go19_40x256_f16_against_exact_f32_on_the_gpu(dev):
-    """BASELINE.json configs[4]'s network at full depth (Go 19x19, 40 blocks x 256 channels), 96 boards: the f16
-    board-tile path against the exact-f32 implicit-GEMM path of the same library (which the small-net tests pin to the
-    oracle at 1e-4; the oracle itself would need ~10 s per board here), plus the oracle on one board."""
-    blob = synth.random_model("go-19", 40, 256, "conv", seed=31)
-    bits, scalars_in = synth.random_boards("go-19", 96, seed=32)
+def test_config_g8_go19_40x256_at_executor_batch_512(dev):
+    """BASELINE.json configs[4] at its stated size on one GPU: Go 19x19, 40 blocks x 256 channels, f16, executor batch
+    512 through kz_board_conv_f16.  Size-independent properties on all 512 boards (determinism, permutation
+    equivariance over the batch, batch-size invariance), the exact-f32 path of this library on a 64-board sample, and
+    the real oracle on 2 boards (it needs ~10 s of one core per board)."""
+    blob = synth.random_model("go-19", 40, 256, "conv", seed=33)
+    bits, scalars_in = synth.random_boards("go-19", 512, seed=34)
     model = capi.Model(blob=blob)
-    f32 = capi.Engine(model, dev, 96, capi.KZ_DTYPE_F32)
-    s_ref, p_ref = f32.eval_packed(bits, scalars_in)
     f16 = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
-    assert f16.tower_path == "board_conv_f16"
+    assert f16.tower_path == "board_conv_f16" and f16.max_batch == 512
     s, p = f16.eval_packed(bits, scalars_in)
-    rs = assert_f16(s, s_ref, "scalars, 96 boards")
-    rp = assert_f16(p, p_ref, "policy, 96 boards")
-    print(f"go-19 40x256 f16 vs exact f32, 96 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, "
-          f"max |dsoftmax| {np.abs(softmax(p) - softmax(p_ref)).max():.2e}")
+    assert s.shape == (512, 5) and p.shape == (512, 362)
+    assert np.isfinite(s).all() and np.isfinite(p).all()
+    s2, p2 = f16.eval_packed(bits, scalars_in)
+    assert np.array_equal(s, s2) and np.array_equal(p, p2), "not deterministic"
+    perm = np.random.default_rng(6).permutation(512)
+    sp, pp = f16.eval_packed(bits[perm], scalars_in[perm])
+    assert np.array_equal(sp, s[perm]) and np.array_equal(pp, p[perm]), "not permutation equivariant"
+    for lo, n in ((0, 7), (300, 64), (511, 1)):
+        sn, pn = f16.eval_packed(bits[lo:lo + n], scalars_in[lo:lo + n])
+        assert np.array_equal(sn, s[lo:lo + n]) and np.array_equal(pn, p[lo:lo + n]), "result depends on the batch size"
+    sample = np.arange(0, 512, 8)
+    f32 = capi.Engine(model, dev, 64, capi.KZ_DTYPE_F32)
+    s_ref, p_ref = f32.eval_packed(bits[sample], scalars_in[sample])
+    rs = assert_f16(s[sample], s_ref, "scalars, 64 of 512 boards vs exact f32")
+    rp = assert_f16(p[sample], p_ref, "policy, 64 of 512 boards vs exact f32")
+    print(f"go-19 40x256 B=512 f16 vs exact f32 on 64 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, "
+          f"max |dsoftmax| {np.abs(softmax(p[sample]) - softmax(p_ref)).max():.2e}")
     net = O.OracleNet(blob)
-    dense = O.encode_input_full(bits[:1], scalars_in[:1], net.n_scalar, net.n_bool, net.h, net.w)
+    two = sample[:2]
+    dense = O.encode_input_full(bits[two], scalars_in[two], net.n_scalar, net.n_bool, net.h, net.w)
     so, po = net.forward(dense, threads=os.cpu_count() or 1)
-    assert_f32(s_ref[:1], so, "exact f32 vs oracle, scalars")
-    assert_f32(p_ref[:1], po, "exact f32 vs oracle, policy")
+    assert_f32(s_ref[:2], so, "exact f32 vs oracle, scalars")
+    assert_f32(p_ref[:2], po, "exact f32 vs oracle, policy")
+    assert_f16(s[two], so, "f16 vs oracle, scalars")
+    assert_f16(p[two], po, "f16 vs oracle, policy")
+
+
+def _scaled_stem(blob, factor):
+    """The same network with its stem convolution scaled: the residual stream grows by `factor`."""
+    from kzero_amd.model_file import write_model
+    meta, tensors = read_model(blob)
+    tensors = dict(tensors)
+    tensors["common.tower.0.weight"] = tensors["common.tower.0.weight"] * np.float32(factor)
+    tensors["common.tower.0.bias"] = tensors["common.tower.0.bias"] * np.float32(factor)
+    return write_model(meta, tensors)
+
+
+@pytest.mark.parametrize("game,depth,channels,head,dtype,path,env", [
+    ("chess", 2, 256, "attention", "f16", "tower_resident_f16+heads", {}),
+    ("chess", 2, 256, "attention", "f16", "tower_resident_f16", {"KZ_NO_FUSED_HEADS": "1"}),
+    ("chess", 2, 256, "attention", "split16", "tower_resident_split16", {}),
+    ("ataxx-7", 2, 128, "ataxx_conv", "f16", "tower_resident_f16g", {}),
+    ("go-9", 2, 128, "conv", "f16", "board_conv_f16", {"KZ_NO_RESIDENT_F16G": "1"}),
+    ("go-9", 2, 128, "conv", "f16", "conv_igemm_f16", {"KZ_NO_RESIDENT_F16G": "1", "KZ_NO_BOARD_CONV": "1"}),
+])
+def test_f16_range_overflow_is_reported(dev, game, depth, channels, head, dtype, path, env):
+    """f16 storage overflows beyond +-65504 (include/kz_hip.h, KZ_DTYPE_F16): a network whose residual stream leaves that
+    range must not come back as silent inf/NaN with rc 0.  Every f16 / split-f16 path reports it on the call that
+    returns the batch; the same network through KZ_DTYPE_F32 evaluates normally; the engine stays usable."""
+    base = synth.random_model(game, depth, channels, head, seed=17)
+    big = _scaled_stem(base, 3.0e5)  # stem outputs of order 1e5 > 65504
+    bits, scalars_in = synth.random_boards(game, 9, seed=18)
+    code = capi.KZ_DTYPE_F16 if dtype == "f16" else capi.KZ_DTYPE_F32_SPLIT16
+    os.environ.update(env)
+    try:
+        eng_big = capi.Engine(capi.Model(blob=big), dev, 512, code)
+        eng_ok = capi.Engine(capi.Model(blob=base), dev, 512, code)
+    finally:
+        for k in env:
+            del os.environ[k]
+    assert eng_big.tower_path == path
+    s_ok, p_ok = eng_ok.eval_packed(bits, scalars_in)  # in range: no error
+    assert np.isfinite(s_ok).all() and np.isfinite(p_ok).all()
+    with pytest.raises(capi.KzError, match="non-finite activation"):
+        eng_big.eval_packed(bits, scalars_in)
+    with pytest.raises(capi.KzError, match="non-finite activation"):  # the asynchronous pair reports it at the wait
+        eng_big.wait_view(0, eng_big.submit_packed(0, bits, scalars_in))
+    n = eng_ok.submit_packed(1, bits, scalars_in)  # other engines and later batches are unaffected
+    s_again, _ = eng_ok.wait_view(1, n)
+    assert np.array_equal(s_again, s_ok)
+    # device-resident entry points: kz_engine_synchronize reports it, once
+    d_s, d_p = capi.DeviceBuffer(dev, 9 * 5 * 4), capi.DeviceBuffer(dev, 9 * eng_big.model.info.policy_len * 4)
+    eng_big.enqueue_packed_device(capi.DeviceBuffer.from_host(dev, bits), bits.shape[1],
+                                  capi.DeviceBuffer.from_host(dev, scalars_in), 9, d_s, d_p)
+    with pytest.raises(capi.KzError, match="non-finite activation"):
+        eng_big.synchronize()
+    eng_big.synchronize()
+    # the exact-f32 path has no such limit
+    f32 = capi.Engine(capi.Model(blob=big), dev, 16, capi.KZ_DTYPE_F32)
+    s32, p32 = f32.eval_packed(bits, scalars_in)
+    assert np.isfinite(s32).all() and np.isfinite(p32).all()
 
 
 def test_full_size_properties(dev, chess_full):
@@ -394,9 +483,8 @@ def test_full_size_properties(dev, chess_full):
         assert gen.tower_path in ("board_conv_f16", "conv_igemm_f16")
         sg, pg = gen.eval_packed(bits, scalars_in)
         # both are f16-storage/f32-accumulate; they differ only in summation order
-        ds, dp = np.abs(sg - s).max(), np.abs(pg - p).max()
-        print(f"resident vs per-layer f16: max |d scalars| {ds:.2e}, max |d policy| {dp:.2e}")
-        assert ds < F16_PATHS_ATOL_DEEP and dp < F16_PATHS_ATOL_DEEP
+        assert_f16_paths_deep(sg, s, "resident vs per-layer f16, scalars")
+        assert_f16_paths_deep(pg, p, "resident vs per-layer f16, policy")
 
 
 def test_fused_heads_match_separate_head_kernels(dev, chess_full):
@@ -615,8 +703,11 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches):
         sg, pg = gen.eval_packed(bits, scalars_in)
         ds, dp = np.abs(sg - s).max(), np.abs(pg - p).max()
         print(f"f16g {game} {depth}x{channels} b={batch} vs implicit GEMM f16: max |d scalars| {ds:.2e}, max |d policy| {dp:.2e}")
-        tol = F16_PATHS_ATOL if depth <= 2 else F16_PATHS_ATOL_DEEP
-        assert ds < tol and dp < tol
+        if depth <= 2:
+            assert ds < F16_PATHS_ATOL and dp < F16_PATHS_ATOL
+        else:
+            assert_f16_paths_deep(sg, s, "scalars")
+            assert_f16_paths_deep(pg, p, "policy")
 
 
 @pytest.mark.parametrize("game,channels,head,batch", [
