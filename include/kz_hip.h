@@ -88,6 +88,10 @@ int kz_model_get_info(const kz_model *model, kz_model_info *out);
 /* ---- engine: replaces CudaNetwork::new(mapper, &graph, max_batch_size, device) (cudnn.rs:29-43) ---- */
 int kz_engine_create(const kz_model *model, int device, int max_batch, int dtype, kz_engine **out);
 void kz_engine_destroy(kz_engine *engine);
+/* 1 when kz_engine_create would accept `dtype` for this model, 0 when not (KZ_DTYPE_F32_SPLIT16 has shape limits,
+ * see above), negative on a null/unknown argument.  Lets a host pick "the fastest path with <= 1e-4 parity":
+ * KZ_DTYPE_F32_SPLIT16 where supported, else KZ_DTYPE_F32. */
+int kz_model_supports_dtype(const kz_model *model, int dtype);
 int kz_engine_max_batch(const kz_engine *engine); /* Network::max_batch_size, network/mod.rs:53 */
 
 /* ---- synchronous evaluation: replaces CudaNetwork::evaluate_batch's encode + executor.evaluate (cudnn.rs:55-82) ----

@@ -45,6 +45,7 @@ SIGNATURES = {
     "kz_model_get_info": (C.c_int, [C.c_void_p, C.POINTER(ModelInfo)]),
     "kz_engine_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kz_engine_destroy": (None, [C.c_void_p]),
+    "kz_model_supports_dtype": (C.c_int, [C.c_void_p, C.c_int]),
     "kz_engine_max_batch": (C.c_int, [C.c_void_p]),
     "kz_engine_eval_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kz_engine_eval_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
@@ -128,6 +129,9 @@ class Model:
         info = ModelInfo()
         check(load().kz_model_get_info(self._h, C.byref(info)))
         self.info = info
+
+    def supports_dtype(self, dtype: int) -> bool:
+        return load().kz_model_supports_dtype(self._h, dtype) == 1
 
     def close(self):
         if self._h:

@@ -907,6 +907,15 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     return 0;
 }
 
+KZ_API int kz_model_supports_dtype(const kz_model *model, int dtype) {
+    if (!model) return -1;
+    const Model &m = *model->m;
+    if (dtype == KZ_DTYPE_F32 || dtype == KZ_DTYPE_F16) return 1;
+    if (dtype == KZ_DTYPE_F32_SPLIT16)
+        return kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) && round_up(m.c_in, 32) == 32 ? 1 : 0;
+    return -1;
+}
+
 KZ_API int kz_engine_max_batch(const kz_engine *e) { return e ? e->max_batch : 0; }
 
 KZ_API const char *kz_engine_tower_path(const kz_engine *e) { return e ? e->path.c_str() : ""; }

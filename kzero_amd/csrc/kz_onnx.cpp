@@ -377,7 +377,8 @@ Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err) 
         m->n_bool = n_scalar < 0 ? -1 : m->c_in - n_scalar;
         bool has_scalars = false, has_policy = false;
         for (auto &o : g.outputs) { has_scalars |= o == "scalars"; has_policy |= o == "policy"; }
-        if (g.outputs.size() != 2 || !has_scalars || !has_policy) fail("outputs must be 'scalars' and 'policy'");
+        if (g.outputs.size() != 2 || !has_scalars || !has_policy) fail("outputs must be 'scalars' and 'policy' (legacy (value, wdl, policy) graphs, network/common.rs:36-45, "
+                                                                        "are not taken: re-export with save_onnx.py)");
         const int hw = m->h * m->w;
 
         // ---- ResTower (post_act.py:201-228) ----

@@ -46,38 +46,50 @@ pub const KZ_DTYPE_F32: c_int = 0;
 pub const KZ_DTYPE_F16: c_int = 1;
 /// f32 tensors and the same <= 1e-4 parity as KZ_DTYPE_F32, the tower's products as three f16 MFMAs on (hi, lo) pairs
 pub const KZ_DTYPE_F32_SPLIT16: c_int = 2;
+pub const KZ_ENGINE_SLOTS: usize = 2;
 
+// The C ABI of include/kz_hip.h, declaration for declaration (tests/test_rust_shim_text.py compares the two files:
+// every function of the header is bound here with the same name, arity and pointer-ness).  `kz_model` / `kz_engine`
+// are opaque: `*mut c_void` / `*const c_void`.
 #[link(name = "kzhip")]
 extern "C" {
     fn kz_last_error() -> *const c_char;
     fn kz_device_count(count: *mut c_int) -> c_int;
+    fn kz_device_pci_bus_id(device: c_int, buf: *mut c_char, len: usize) -> c_int;
+    fn kz_model_load(path: *const c_char, out: *mut *mut c_void) -> c_int;
+    fn kz_model_load_memory(blob: *const c_void, len: usize, out: *mut *mut c_void) -> c_int;
     fn kz_model_load_onnx(path: *const c_char, input_scalar_channels: c_int, out: *mut *mut c_void) -> c_int;
+    fn kz_model_load_onnx_memory(blob: *const c_void, len: usize, input_scalar_channels: c_int, out: *mut *mut c_void) -> c_int;
     fn kz_model_free(model: *mut c_void);
     fn kz_model_get_info(model: *const c_void, out: *mut KzModelInfo) -> c_int;
     fn kz_engine_create(model: *const c_void, device: c_int, max_batch: c_int, dtype: c_int, out: *mut *mut c_void) -> c_int;
     fn kz_engine_destroy(engine: *mut c_void);
-    fn kz_engine_eval_packed(
-        engine: *mut c_void,
-        bits: *const u8,
-        bits_stride: usize,
-        scalars_in: *const f32,
-        batch: c_int,
-        scalars_out: *mut f32,
-        policy_out: *mut f32,
-    ) -> c_int;
+    fn kz_model_supports_dtype(model: *const c_void, dtype: c_int) -> c_int;
+    fn kz_engine_max_batch(engine: *const c_void) -> c_int;
+    fn kz_engine_eval_dense(engine: *mut c_void, input_nchw: *const f32, batch: c_int, scalars_out: *mut f32, policy_out: *mut f32) -> c_int;
+    fn kz_engine_eval_packed(engine: *mut c_void, bits: *const u8, bits_stride: usize, scalars_in: *const f32, batch: c_int, scalars_out: *mut f32, policy_out: *mut f32) -> c_int;
+    fn kz_engine_eval_packed_decoded(engine: *mut c_void, bits: *const u8, bits_stride: usize, scalars_in: *const f32, batch: c_int, move_offsets: *const i64, move_indices: *const i32, values_out: *mut f32, probs_out: *mut f32) -> c_int;
     // asynchronous pair, slot in [0, KZ_ENGINE_SLOTS): inputs are copied to pinned staging before submit returns
-    fn kz_engine_submit_packed(
-        engine: *mut c_void,
-        slot: c_int,
-        bits: *const u8,
-        bits_stride: usize,
-        scalars_in: *const f32,
-        batch: c_int,
-    ) -> c_int;
+    fn kz_engine_submit_packed(engine: *mut c_void, slot: c_int, bits: *const u8, bits_stride: usize, scalars_in: *const f32, batch: c_int) -> c_int;
     fn kz_engine_wait(engine: *mut c_void, slot: c_int, scalars_out: *mut f32, policy_out: *mut f32) -> c_int;
+    fn kz_engine_wait_view(engine: *mut c_void, slot: c_int, scalars_out: *mut *const f32, policy_out: *mut *const f32) -> c_int;
+    fn kz_engine_submit_packed_decoded(engine: *mut c_void, slot: c_int, bits: *const u8, bits_stride: usize, scalars_in: *const f32, batch: c_int, move_offsets: *const i64, move_indices: *const i32) -> c_int;
+    fn kz_engine_wait_decoded(engine: *mut c_void, slot: c_int, values_out: *mut *const f32, probs_out: *mut *const f32) -> c_int;
+    // device-resident entry points and helpers (benchmarks and parity tests; the server does not need them)
+    fn kz_engine_enqueue_packed_device(engine: *mut c_void, d_bits: *const c_void, bits_stride: usize, d_scalars_in: *const c_void, batch: c_int, d_scalars_out: *mut c_void, d_policy_out: *mut c_void) -> c_int;
+    fn kz_engine_enqueue_dense_device(engine: *mut c_void, d_input_nchw: *const c_void, batch: c_int, d_scalars_out: *mut c_void, d_policy_out: *mut c_void) -> c_int;
+    fn kz_engine_synchronize(engine: *mut c_void) -> c_int;
+    fn kz_device_malloc(device: c_int, bytes: usize, out: *mut *mut c_void) -> c_int;
+    fn kz_device_free(device: c_int, ptr: *mut c_void) -> c_int;
+    fn kz_memcpy_h2d(device: c_int, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    fn kz_memcpy_d2h(device: c_int, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    fn kz_device_synchronize(device: c_int) -> c_int;
+    fn kz_engine_set_profiling(engine: *mut c_void, enable: c_int) -> c_int;
+    fn kz_engine_kernel_time(engine: *mut c_void, prefix: *const c_char, total_ms: *mut f64, launches: *mut i64) -> c_int;
+    fn kz_engine_tower_path(engine: *const c_void) -> *const c_char;
+    fn kz_engine_launch_geometry(engine: *const c_void, batch: c_int, workgroups: *mut c_int, boards_per_workgroup: *mut c_int) -> c_int;
+    fn kz_engine_read_activation(engine: *mut c_void, name: *const c_char, batch: c_int, out_nchw: *mut f32) -> c_int;
 }
-
-pub const KZ_ENGINE_SLOTS: usize = 2;
 
 /// The reference panics on every executor error (`unwrap()` cudnn.rs:70,78); keep that behaviour.
 fn check(rc: c_int) {
@@ -91,6 +103,63 @@ pub fn hip_device_count() -> usize {
     let mut n = 0;
     check(unsafe { kz_device_count(&mut n) });
     n as usize
+}
+
+/// What replaces `kn_cuda_sys::wrapper::handle::CudaDevice` at the server seam (`ZeroSpecialization::Device`,
+/// INTEGRATION.md §1): a HIP device ordinal.  `CudaDevice::all()` (server.rs:49) -> `HipDevice::all()`,
+/// `CudaDevice::new(d).unwrap()` (server.rs:51) -> `HipDevice::new(d)`.
+#[derive(Debug, Copy, Clone, Eq, PartialEq, Hash)]
+pub struct HipDevice(pub usize);
+
+impl HipDevice {
+    pub fn all() -> Vec<HipDevice> {
+        (0..hip_device_count()).map(HipDevice).collect()
+    }
+    pub fn new(index: i32) -> HipDevice {
+        assert!(index >= 0 && (index as usize) < hip_device_count(), "No HIP device {}", index);
+        HipDevice(index as usize)
+    }
+    pub fn pci_bus_id(self) -> String {
+        let mut buf = [0 as c_char; 64];
+        check(unsafe { kz_device_pci_bus_id(self.0 as c_int, buf.as_mut_ptr(), buf.len()) });
+        unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()
+    }
+}
+
+/// Arithmetic of the engine, a start-up choice (environment variable `KZ_HIP_DTYPE`, read once by
+/// `HipSpecialization`).  The reference's executor is f32 only (`DTensor::F32`, cudnn.rs:73) and the stated parity is
+/// 1e-4, so the DEFAULT is the fastest path that keeps it: `KZ_DTYPE_F32_SPLIT16` where the network's shape allows,
+/// else `KZ_DTYPE_F32`.  `f16` (3 x faster again, tolerance 5e-3 of the output scale, range +-65504 with overflow
+/// reported as an error) is opt-in.
+#[derive(Debug, Copy, Clone, Eq, PartialEq)]
+pub enum HipDtype {
+    Parity,
+    F32,
+    F16,
+}
+
+impl HipDtype {
+    pub fn from_env() -> HipDtype {
+        match std::env::var("KZ_HIP_DTYPE").as_deref() {
+            Err(_) | Ok("parity") | Ok("f32split16") => HipDtype::Parity,
+            Ok("f32") => HipDtype::F32,
+            Ok("f16") => HipDtype::F16,
+            Ok(other) => panic!("KZ_HIP_DTYPE must be parity, f32 or f16, got '{}'", other),
+        }
+    }
+    fn resolve(self, model: &HipModel) -> c_int {
+        match self {
+            HipDtype::F32 => KZ_DTYPE_F32,
+            HipDtype::F16 => KZ_DTYPE_F16,
+            HipDtype::Parity => {
+                if unsafe { kz_model_supports_dtype(model.ptr, KZ_DTYPE_F32_SPLIT16) } == 1 {
+                    KZ_DTYPE_F32_SPLIT16
+                } else {
+                    KZ_DTYPE_F32
+                }
+            }
+        }
+    }
 }
 
 /// Host-side parsed model: the `G` of `ZeroSpecialization` (what `Arc<Graph>` is for `AlphaZeroSpecialization`).
@@ -143,7 +212,7 @@ unsafe impl<B: Board, M: BoardMapper<B>> Send for HipNetwork<B, M> {}
 
 impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
     /// Mirrors `CudaNetwork::new(mapper, &graph, max_batch_size, device)` (cudnn.rs:29-43).
-    pub fn new(mapper: M, model: Arc<HipModel>, max_batch_size: usize, device: usize, dtype: c_int) -> Self {
+    pub fn new(mapper: M, model: Arc<HipModel>, max_batch_size: usize, device: HipDevice, dtype: HipDtype) -> Self {
         // check_graph_shapes (network/common.rs:165-198)
         let info = model.info;
         let [c, h, w] = mapper.input_full_shape();
@@ -156,7 +225,8 @@ impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
         assert_eq!(info.policy_len as usize, mapper.policy_len(), "Wrong policy shape");
 
         let mut engine = std::ptr::null_mut();
-        check(unsafe { kz_engine_create(model.ptr, device as c_int, max_batch_size as c_int, dtype, &mut engine) });
+        let dtype = dtype.resolve(&model);
+        check(unsafe { kz_engine_create(model.ptr, device.0 as c_int, max_batch_size as c_int, dtype, &mut engine) });
 
         HipNetwork {
             mapper,

@@ -1,16 +1,38 @@
 //! kz-selfplay/src/server/server_hip.rs — `HipSpecialization`: the MI355X executor behind the server's
 //! `ZeroSpecialization` seam (kz-selfplay/src/server/server.rs:287-302).
 //!
-//! What a maintainer changes, and nothing else:
-//!   1. In `server_alphazero.rs`, the body of `spawn_device_threads` up to and including the generator pool
-//!      (lines 39-87: sizing, `job_pair`, `ThreadPoolBuilder`, `generator_alphazero_main` tasks) moves unchanged into a
-//!      helper `spawn_alphazero_generators(device_id, startup, start_pos, update_sender) ->
-//!      (Vec<Sender<Settings>>, JobServer<B, ZeroEvaluation<'static>>)`, which `AlphaZeroSpecialization` keeps calling.
-//!   2. This file supplies the other half for the HIP backend: the executor threads and the model loader.
+//! The seam itself carries a kn-cuda-sys type today (`device: CudaDevice`, server.rs:293; `devices: Vec<CudaDevice>`,
+//! server.rs:105,207,249,306; enumeration server.rs:47-53), so it is edited, once, to stop naming a backend
+//! (INTEGRATION.md §1 lists every line):
+//!
+//! ```ignore
+//! pub trait ZeroSpecialization<B: Board, M: BoardMapper<B> + 'static> {
+//!     type G: Send + Sync;
+//!     type Device: Copy + Debug + Send + Sync + 'static;                 // NEW
+//!     /// `indices` = the `--device` arguments; empty = every device      // NEW (was server.rs:48-52)
+//!     fn devices(indices: &[i32]) -> Vec<Self::Device>;
+//!     fn spawn_device_threads<'s>(&self, s: &Scope<'s>, device: Self::Device, /* the rest unchanged */ ...)
+//!         -> (Vec<Sender<Settings>>, Vec<GraphSender<Self::G>>);
+//!     fn load_graph(&self, path: &str, mapper: M, startup: &StartupSettings) -> Self::G;
+//! }
+//! ```
+//!
+//! `AlphaZeroSpecialization` / `MuZeroSpecialization` get `type Device = CudaDevice;` and the moved enumeration;
+//! `selfplay_server_main` and the three dispatch functions pass `args.device: Vec<i32>` down instead of
+//! `Vec<CudaDevice>`, and `selfplay_start` begins with `let devices = Z::devices(&devices);`.
+//!
+//! Generator half: `server_alphazero.rs:39-87` (sizing, `job_pair`, `ThreadPoolBuilder`, the
+//! `generator_alphazero_main` tasks) moves unchanged into
+//! `pub(super) fn spawn_alphazero_generators(s, device_id, startup, mapper, start_pos, update_sender)
+//!     -> (Vec<Sender<Settings>>, JobServer<B, ZeroEvaluation<'static>>)`,
+//! which `AlphaZeroSpecialization::spawn_device_threads` keeps calling first.  This file supplies the other half for
+//! the HIP backend: the executor threads and the model loader.
 //!
 //! Generators, MCTS, job channel, `batched_executor_loop`, collector, commander and the wire protocol are untouched.
-//! NOT compiled in this repository's CI (no cargo in the build image); written against the cited signatures.
+//! NOT compiled in this repository's CI (no cargo in the build image); written against the cited signatures and kept
+//! consistent with include/kz_hip.h by tests/test_rust_shim_text.py.
 
+use std::hash::Hash;
 use std::sync::Arc;
 
 use board_game::board::Board;
@@ -20,26 +42,47 @@ use rand::rngs::StdRng;
 use rand::thread_rng;
 
 use kz_core::mapping::BoardMapper;
-use kz_core::network::hip::{HipModel, HipNetwork, KZ_DTYPE_F16};
+use kz_core::network::hip::{HipDevice, HipDtype, HipModel, HipNetwork};
 use kz_core::network::symmetry::RandomSymmetryNetwork;
 use kz_core::network::Network;
 
 use crate::server::executor::{batched_executor_loop, RunCondition};
 use crate::server::protocol::{Evals, GeneratorUpdate, Settings, StartupSettings};
 use crate::server::server::{GraphSender, ZeroSpecialization};
-use crate::server::server_alphazero::spawn_alphazero_generators; // step 1 above
+use crate::server::server_alphazero::spawn_alphazero_generators;
 
 #[derive(Debug)]
-pub struct HipSpecialization;
+pub struct HipSpecialization {
+    /// `KZ_HIP_DTYPE`: parity (default: <= 1e-4, the reference's f32 results) | f32 | f16
+    pub dtype: HipDtype,
+}
 
-impl<B: Board + std::hash::Hash, M: BoardMapper<B> + 'static> ZeroSpecialization<B, M> for HipSpecialization {
+impl HipSpecialization {
+    pub fn from_env() -> Self {
+        HipSpecialization { dtype: HipDtype::from_env() }
+    }
+}
+
+impl<B: Board + Hash, M: BoardMapper<B> + 'static> ZeroSpecialization<B, M> for HipSpecialization {
     /// What the commander wraps in an `Arc` and clones to every executor (commander.rs:36-45).
     type G = HipModel;
+    type Device = HipDevice;
+
+    /// server.rs:47-53 for this backend.
+    fn devices(indices: &[i32]) -> Vec<HipDevice> {
+        let devices = if indices.is_empty() {
+            HipDevice::all()
+        } else {
+            indices.iter().map(|&d| HipDevice::new(d)).collect()
+        };
+        assert!(!devices.is_empty(), "No HIP devices found");
+        devices
+    }
 
     fn spawn_device_threads<'s>(
         &self,
         s: &Scope<'s>,
-        device: CudaDevice, // only its index is used; with the cuda crates gone this is a plain device index
+        device: HipDevice,
         device_id: usize,
         startup: &StartupSettings,
         mapper: M,
@@ -47,47 +90,50 @@ impl<B: Board + std::hash::Hash, M: BoardMapper<B> + 'static> ZeroSpecialization
         update_sender: Sender<GeneratorUpdate<B>>,
     ) -> (Vec<Sender<Settings>>, Vec<GraphSender<HipModel>>) {
         let (settings_senders, eval_server) =
-            spawn_alphazero_generators(device_id, startup, start_pos, update_sender.clone());
+            spawn_alphazero_generators(s, device_id, startup, mapper, start_pos, update_sender.clone());
 
-        let batch = startup.gpu_batch_size;
-        let jobs_per_batch = batch / startup.search_batch_size; // RunCondition::JobCount, as before
-        let symmetries = startup.eval_random_symmetries;
-        let device_index = device.inner() as usize;
+        let gpu_batch_size = startup.gpu_batch_size;
+        let eval_job_count = gpu_batch_size / startup.search_batch_size; // server_alphazero.rs:48
+        let eval_random_symmetries = startup.eval_random_symmetries;
+        let dtype = self.dtype;
 
-        let graph_senders = (0..startup.gpu_threads_per_device)
-            .map(|local_id| {
-                let (graph_sender, graph_receiver) = flume::bounded(1);
-                let (eval_server, update_sender) = (eval_server.clone(), update_sender.clone());
-                s.builder()
-                    .name(format!("gpu-expand-{}-{}", device_id, local_id))
-                    .spawn(move |_| {
-                        batched_executor_loop(
-                            batch,
-                            RunCondition::JobCount(jobs_per_batch),
-                            graph_receiver,
-                            eval_server,
-                            // one engine per executor thread, created on that thread; engines of one device share
-                            // the uploaded weights inside libkzhip
-                            |message| {
-                                message.map_left(|model: Arc<HipModel>| {
-                                    let engine = HipNetwork::new(mapper, model, batch, device_index, KZ_DTYPE_F16);
-                                    RandomSymmetryNetwork::new(engine, thread_rng(), symmetries)
-                                })
-                            },
-                            |network, boards| {
-                                let evals = network.evaluate_batch(&boards);
-                                let real = boards.len() as u64; // the collector's `real` evals/s
-                                update_sender
-                                    .send(GeneratorUpdate::ExpandEvals(Evals::new(real, batch as u64, 0)))
-                                    .unwrap();
-                                evals
-                            },
-                        )
-                    })
-                    .unwrap();
-                graph_sender
-            })
-            .collect();
+        let mut graph_senders: Vec<GraphSender<HipModel>> = vec![];
+        // spawn gpu eval threads (server_alphazero.rs:89-121 with the network constructor exchanged)
+        for local_id in 0..startup.gpu_threads_per_device {
+            let (graph_sender, graph_receiver) = flume::bounded(1);
+            graph_senders.push(graph_sender);
+
+            let eval_server = eval_server.clone();
+            let update_sender = update_sender.clone();
+
+            s.builder()
+                .name(format!("gpu-expand-{}-{}", device_id, local_id))
+                .spawn(move |_| {
+                    batched_executor_loop(
+                        gpu_batch_size,
+                        RunCondition::JobCount(eval_job_count),
+                        graph_receiver,
+                        eval_server,
+                        // one engine per executor thread, created on that thread (executor.rs:320-342); engines of
+                        // one device share the uploaded weights inside libkzhip
+                        |graph| {
+                            graph.map_left(|model: Arc<HipModel>| {
+                                let inner = HipNetwork::new(mapper, model, gpu_batch_size, device, dtype);
+                                RandomSymmetryNetwork::new(inner, thread_rng(), eval_random_symmetries)
+                            })
+                        },
+                        |network, x| {
+                            let y = network.evaluate_batch(&x);
+                            // the collector's `real` evals/s (server_alphazero.rs:111-117)
+                            let msg =
+                                GeneratorUpdate::ExpandEvals(Evals::new(x.len() as u64, gpu_batch_size as u64, 0));
+                            update_sender.send(msg).unwrap();
+                            y
+                        },
+                    );
+                })
+                .unwrap();
+        }
 
         (settings_senders, graph_senders)
     }

@@ -1,0 +1,128 @@
+"""The Rust shim (kzero_amd/rust/*.rs) cannot be compiled here (no cargo in the image), so it is at least kept
+consistent as text: every prototype of include/kz_hip.h is bound in hip.rs with the same name, arity, pointer-ness and
+scalar types (as test_abi.py does for capi.py); the `#[repr(C)]` info struct and the constants match; and
+server_hip.rs only names items hip.rs defines and calls them with the arity they have."""
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(REPO, "include", "kz_hip.h")).read()
+HIP_RS = open(os.path.join(REPO, "kzero_amd", "rust", "hip.rs")).read()
+SERVER_RS = open(os.path.join(REPO, "kzero_amd", "rust", "server_hip.rs")).read()
+
+C_TO_RUST = {
+    "int": "c_int", "size_t": "usize", "const char *": "*const c_char", "char *": "*mut c_char",
+    "const float *": "*const f32", "float *": "*mut f32", "const float **": "*mut *const f32",
+    "const uint8_t *": "*const u8", "const int64_t *": "*const i64", "const int32_t *": "*const i32",
+    "int *": "*mut c_int", "double *": "*mut f64", "int64_t *": "*mut i64",
+    "kz_model **": "*mut *mut c_void", "const kz_model *": "*const c_void", "kz_model *": "*mut c_void",
+    "kz_engine **": "*mut *mut c_void", "const kz_engine *": "*const c_void", "kz_engine *": "*mut c_void",
+    "const void *": "*const c_void", "void *": "*mut c_void", "void **": "*mut *mut c_void",
+    "kz_model_info *": "*mut KzModelInfo",
+}
+C_RET = {"int": "c_int", "void": None, "const char *": "*const c_char"}
+
+
+def strip_c_comments(text):
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def header_prototypes():
+    body = strip_c_comments(HEADER)
+    body = "\n".join(ln for ln in body.splitlines() if not ln.lstrip().startswith("#"))
+    protos = {}
+    for m in re.finditer(r"(?:^|;|\})\s*((?:const\s+)?\w+\s*\**)\s*(kz_\w+)\s*\(([^)]*)\)\s*(?=;)", body, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        ret = re.sub(r"\s+", " ", ret).replace(" *", " *").strip()
+        ret = re.sub(r"\s*\*", " *", ret) if "*" in ret else ret
+        params = []
+        if args.strip() and args.strip() != "void":
+            for a in args.split(","):
+                a = re.sub(r"\s+", " ", a).strip()
+                mm = re.match(r"(.*?)(\w+)$", a)  # type, then the parameter name
+                ctype = mm.group(1).strip()
+                ctype = re.sub(r"\s*\*", "*", ctype)
+                stars = ctype.count("*")
+                ctype = ctype.replace("*", "").strip() + (" " + "*" * stars if stars else "")
+                params.append(ctype)
+        protos[name] = (ret, params)
+    return protos
+
+
+def rust_externs():
+    block = re.search(r'extern "C" \{(.*?)\n\}', HIP_RS, flags=re.S).group(1)
+    block = re.sub(r"//[^\n]*", "", block)
+    fns = {}
+    for m in re.finditer(r"fn\s+(kz_\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        name, args, ret = m.group(1), m.group(2), m.group(3)
+        params = [re.sub(r"\s+", " ", a.split(":", 1)[1]).strip() for a in args.split(",") if a.strip()]
+        fns[name] = (ret.strip() if ret else None, params)
+    return fns
+
+
+def test_every_header_function_is_bound_in_hip_rs_with_the_same_signature():
+    protos, fns = header_prototypes(), rust_externs()
+    assert len(protos) >= 30, sorted(protos)
+    assert set(protos) == set(fns), f"header only: {sorted(set(protos) - set(fns))}; hip.rs only: {sorted(set(fns) - set(protos))}"
+    for name, (ret, params) in protos.items():
+        r_ret, r_params = fns[name]
+        assert C_RET[ret] == r_ret, f"{name}: return {ret} vs {r_ret}"
+        assert len(params) == len(r_params), f"{name}: arity {len(params)} vs {len(r_params)}"
+        for i, (c, r) in enumerate(zip(params, r_params)):
+            assert c in C_TO_RUST, f"{name} arg {i}: unmapped C type '{c}'"
+            assert C_TO_RUST[c] == r, f"{name} arg {i}: {c} should be {C_TO_RUST[c]}, hip.rs has {r}"
+
+
+def test_capi_py_binds_the_same_set():
+    from kzero_amd import capi
+    assert set(capi.SIGNATURES) == set(header_prototypes())
+
+
+def test_model_info_struct_and_constants_match():
+    body = strip_c_comments(HEADER)
+    c_fields = re.search(r"typedef struct kz_model_info \{(.*?)\} kz_model_info;", body, flags=re.S).group(1)
+    c_fields = [(t, n) for t, n in re.findall(r"(int32_t|int64_t|double)\s+(\w+);", c_fields)]
+    r_struct = re.search(r"pub struct KzModelInfo \{(.*?)\}", HIP_RS, flags=re.S).group(1)
+    r_fields = re.findall(r"pub (\w+): (\w+),", r_struct)
+    tmap = {"int32_t": "i32", "int64_t": "i64", "double": "f64"}
+    assert [(n, tmap[t]) for t, n in c_fields] == r_fields
+    assert "#[repr(C)]" in HIP_RS.split("pub struct KzModelInfo")[0][-80:]
+    for name in ("KZ_DTYPE_F32", "KZ_DTYPE_F16", "KZ_DTYPE_F32_SPLIT16", "KZ_ENGINE_SLOTS"):
+        c_val = re.search(rf"#define {name} (\d+)", HEADER).group(1)
+        r_val = re.search(rf"pub const {name}: \w+ = (\d+);", HIP_RS).group(1)
+        assert c_val == r_val, name
+
+
+def _code_only(rs):
+    return "\n".join(ln for ln in rs.splitlines() if not ln.lstrip().startswith("//"))
+
+
+def test_server_hip_rs_is_self_consistent():
+    code = _code_only(SERVER_RS)
+    # the kn-cuda-sys device type is gone from the seam: only comments may mention it
+    assert "CudaDevice" not in code and "KZ_DTYPE_F16" not in code
+    # everything imported from kz_core::network::hip exists there as a public item
+    imported = re.search(r"use kz_core::network::hip::\{([^}]*)\};", code).group(1)
+    for item in [i.strip() for i in imported.split(",")]:
+        assert re.search(rf"pub (struct|enum|fn|const) {item}\b", HIP_RS), f"hip.rs does not define {item}"
+    # HipNetwork::new: same number of arguments at the call and at the definition, device and dtype typed as the seam's
+    defn = re.search(r"pub fn new\(([^)]*)\) -> Self", HIP_RS).group(1)
+    def_args = [a.strip() for a in defn.split(",") if a.strip()]
+    call = re.search(r"HipNetwork::new\(([^)]*)\)", code).group(1)
+    assert len([a for a in call.split(",") if a.strip()]) == len(def_args) == 5
+    assert "device: HipDevice" in defn and "dtype: HipDtype" in defn
+    # the trait items this impl provides are the ones the edited trait (documented at the top of the file) declares
+    for item in ("type G = HipModel;", "type Device = HipDevice;", "fn devices(indices: &[i32]) -> Vec<HipDevice>",
+                 "fn spawn_device_threads<'s>(", "fn load_graph(&self, path: &str, mapper: M, _: &StartupSettings) -> HipModel"):
+        assert item in code, item
+    # the default arithmetic is the <= 1e-4 path, f16 is opt-in
+    assert re.search(r'Err\(_\) \| Ok\("parity"\)[^\n]*=> HipDtype::Parity', HIP_RS)
+    assert "HipDtype::Parity =>" in HIP_RS and "KZ_DTYPE_F32_SPLIT16" in HIP_RS
+
+
+def test_integration_md_lists_every_edited_reference_line():
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    for cite in ("server.rs:16", "server.rs:47-53", "server.rs:105", "server.rs:207", "server.rs:249", "server.rs:293",
+                 "server.rs:306", "server_alphazero.rs:7", "server_alphazero.rs:35", "server_muzero.rs:26",
+                 "type Device", "KZ_HIP_DTYPE", "legacy"):
+        assert cite in text, f"INTEGRATION.md does not mention {cite}"
