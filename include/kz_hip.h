@@ -174,8 +174,9 @@ int kz_engine_launch_geometry(const kz_engine *engine, int batch, int *workgroup
 
 /* ---- debugging / parity: copy an intermediate activation of the last evaluation to the host as f32 NCHW.
  * name: "tower.<i>" as in python/lib/model/post_act.py's nn.Sequential indices (0 = stem, 1..d = blocks,
- * d+1 = final BN).  Only available when the engine was created with the generic per-layer path
- * (set KZ_FORCE_GENERIC=1 in the environment before kz_engine_create). */
+ * d+1 = final BN): only available when the engine was created with the generic per-layer path (set KZ_FORCE_GENERIC=1
+ * and KZ_KEEP_ACTIVATIONS=1 in the environment before kz_engine_create); or "tower.out", the tower's output (after the
+ * final BN), on every path that writes it to memory (all but "tower_resident_f16+heads"). */
 int kz_engine_read_activation(kz_engine *engine, const char *name, int batch, float *out_nchw);
 
 #ifdef __cplusplus

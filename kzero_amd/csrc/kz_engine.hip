@@ -372,6 +372,8 @@ struct kz_engine {
     }
     std::vector<void *> allocs, pinned;
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
+    bool nb4 = false;        // resident chess tower with four boards per workgroup (KZ_TOWER_NB=4)
+    void *xres = nullptr;    // its residual scratch
     std::string path;
 
     // activations
@@ -527,7 +529,8 @@ struct kz_engine {
             t.scalars = d_scalars; t.policy = d_policy;
             t.nonfinite_flag = nf_flag; t.epoch = nf_epoch;
             prof.begin("kz_tower_resident_f16", stream);
-            kz::launch_tower_resident(t, stream);
+            if (nb4) kz::launch_tower_resident4(t, xres, stream);
+            else kz::launch_tower_resident(t, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             tower_out = 0;
@@ -808,6 +811,9 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->fused_heads = e->resident && !(nofuse && nofuse[0] == '1') &&
                      kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,
                                                m.sh_fc0.out);
+    const char *nb_env = getenv("KZ_TOWER_NB");
+    e->nb4 = e->resident && nb_env && atoi(nb_env) == 4;
+    if (e->nb4) e->fused_heads = false;  // (the four-board launch has no fused heads yet)
     const char *noboard = getenv("KZ_NO_BOARD_CONV");
     // the board-tile kernel needs enough workgroups to fill the chip (two per CU when it is busy)
     const bool board_conv_ok = !e->resident && !(noboard && noboard[0] == '1') && m.depth >= 1 &&
@@ -864,6 +870,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         for (int i = 1; i < KZ_ENGINE_SLOTS; i++) HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[i], hipStreamNonBlocking));
     const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
     if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
+    if (e->nb4 && e->dmalloc(&e->xres, kz::tower4_scratch_bytes(max_batch))) return 1;
     const int nact = (e->resident || e->resident32 || e->pairs16) ? 1 : 3;
     for (int i = 0; i < nact; i++)
         if (e->dmalloc(&e->act[i], rows * e->cp * e->esz)) return 1;
@@ -925,7 +932,7 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     if ((batch < 0 || batch > e->max_batch ? fail("kz_engine_launch_geometry: batch out of range") : 0)) return 1;
     const Model &m = *e->model;
     int per = 0, wgs = 0;
-    if (e->resident) per = kz::tower_resident_boards_per_workgroup();
+    if (e->resident) per = e->nb4 ? 4 : kz::tower_resident_boards_per_workgroup();
     else if (e->split16 || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
     else if (e->resident32) per = kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
@@ -1257,18 +1264,23 @@ KZ_API int kz_engine_kernel_time(kz_engine *e, const char *prefix, double *total
 
 KZ_API int kz_engine_read_activation(kz_engine *e, const char *name, int batch, float *out_nchw) {
     if (!e || !name || !out_nchw) return fail("kz_engine_read_activation: null argument");
-    if (!e->keep)
+    // "tower.out": the tower output of the last evaluation, on every path that materialises it (all but the fused-heads
+    // launch)
+    const bool tower_out = std::string(name) == "tower.out" && !e->fused_heads;
+    if (!e->keep && !tower_out)
         return fail("kz_engine_read_activation: engine keeps no activations (create it with KZ_FORCE_GENERIC=1 and "
-                    "KZ_KEEP_ACTIVATIONS=1)");
+                    "KZ_KEEP_ACTIVATIONS=1; \"tower.out\" is available on every path without fused heads)");
     auto it = e->kept.find(name);
-    if (it == e->kept.end()) return fail(std::string("kz_engine_read_activation: no activation named '") + name + "'");
+    if (!tower_out && it == e->kept.end())
+        return fail(std::string("kz_engine_read_activation: no activation named '") + name + "'");
+    const void *src_act = tower_out ? e->act[e->tower_out] : it->second;
     if (check_batch(e, batch, "kz_engine_read_activation")) return 1;
     const Model &m = *e->model;
     const int hw = m.h * m.w, C = m.channels, cp = e->cp;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->sync_all()) return 1;
     std::vector<uint8_t> raw((size_t)batch * hw * cp * e->esz);
-    HIP_TRY(hipMemcpy(raw.data(), it->second, raw.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(raw.data(), src_act, raw.size(), hipMemcpyDeviceToHost));
     for (int b = 0; b < batch; b++)
         for (int c = 0; c < C; c++)
             for (int p = 0; p < hw; p++) {

@@ -212,5 +212,9 @@ void tower_pack_heads(const float *w_bulk, const float *b_bulk, const float *w_u
 // host-side packing: OIHW f32 (BN folded) -> MFMA A-fragment order f16; dst index for conv layer l (0 = stem)
 void tower_pack_weights(const float *oihw, int cout, int cin, int cin_p, uint16_t *dst);
 void launch_tower_resident(const TowerArgs &a, hipStream_t stream);
+// the same tower (no fused heads yet) with four boards per workgroup (kz_tower4.hip): single in-place LDS image, the
+// residual stream in a private global scratch slab of tower4_scratch_bytes(max batch)
+size_t tower4_scratch_bytes(int batch);
+void launch_tower_resident4(const TowerArgs &a, void *xres, hipStream_t stream);
 
 }  // namespace kz

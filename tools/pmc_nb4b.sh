@@ -1,0 +1,22 @@
+#!/bin/bash
+# clock / MFMA-busy of product vs no-weight-stream builds, NB=2 (batch 512) and NB=4 (batch 1024), tower only, full chip
+export TMPDIR=/tmp KZ_NO_FUSED_HEADS=1
+for v in "" _NOWLOAD; do for cfg in "2 512" "4 1024"; do set -- $cfg; nb=$1; batch=$2
+  out=$PWD/gpurun_out/pmc_nb${nb}${v}_clk
+  rm -rf $out
+  KZ_LIB_PATH=/root/repo/kzero_amd/libkzhip$v.so KZ_TOWER_NB=$nb rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $out -o run -- python3 bench.py --no-cpu-baseline --no-others --no-host-io --batch $batch --engines 1 --steps 200 --warmup 20 > $out.log 2>&1
+  python3 - "$out/run_counter_collection.csv" "lib$v NB=$nb batch $batch" <<'PY'
+import csv,sys,collections
+rows=list(csv.DictReader(open(sys.argv[1])))
+agg=collections.defaultdict(list)
+for r in rows:
+    if 'tower_resident' in r['Kernel_Name']:
+        agg[r['Counter_Name']].append((float(r['Counter_Value']), int(r['End_Timestamp'])-int(r['Start_Timestamp'])))
+def mean(name):
+    v=agg[name][len(agg[name])//2:]
+    return sum(x for x,_ in v)/len(v), sum(t for _,t in v)/len(v)
+g,t=mean('GRBM_GUI_ACTIVE'); m,_=mean('SQ_VALU_MFMA_BUSY_CYCLES')
+cyc=g/8
+print(sys.argv[2], 'launch_us %.1f clock_GHz %.3f cycles %.0f mfma_busy %.3f busyGHz %.3f' % (t/1e3, cyc/t, cyc, m/(cyc*1024), m/(cyc*1024)*cyc/t))
+PY
+done; done
