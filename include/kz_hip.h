@@ -119,10 +119,13 @@ int kz_engine_eval_packed_decoded(kz_engine *engine, const uint8_t *bits, size_t
                                   int batch, const int64_t *move_offsets, const int32_t *move_indices,
                                   float *values_out, float *probs_out);
 
-/* ---- asynchronous pair: >= 2 batches in flight per executor thread (replaces gpu_threads_per_device blocking
- * threads, rust/Readme.md:51).  slot in [0, KZ_ENGINE_SLOTS).  Inputs are copied to pinned staging before submit
- * returns; outputs are written to the caller's buffers by kz_engine_wait. */
-#define KZ_ENGINE_SLOTS 2
+/* ---- asynchronous pair: several batches in flight per executor thread (replaces gpu_threads_per_device blocking
+ * threads, rust/Readme.md:51).  slot in [0, KZ_ENGINE_SLOTS).  Inputs are copied to the slot's pinned staging before
+ * submit returns; outputs are written to the caller's buffers by kz_engine_wait.  On the one-launch chess path the slots
+ * alternate over two streams (a batch of 256 is half a chip of workgroups: two launches run side by side, the next launch
+ * of a stream starts when the previous one ends) and the launch reads and writes the pinned staging directly, so no copy
+ * operation sits between launches: keep all four slots submitted to keep both halves of the chip busy. */
+#define KZ_ENGINE_SLOTS 4
 int kz_engine_submit_packed(kz_engine *engine, int slot, const uint8_t *bits, size_t bits_stride,
                             const float *scalars_in, int batch);
 int kz_engine_wait(kz_engine *engine, int slot, float *scalars_out, float *policy_out);

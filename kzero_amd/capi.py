@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("KZ_LIB_PATH") or os.path.join(_HERE, "libkzhip.so")
 KZ_DTYPE_F32 = 0
 KZ_DTYPE_F16 = 1
 KZ_DTYPE_F32_SPLIT16 = 2
-KZ_ENGINE_SLOTS = 2
+KZ_ENGINE_SLOTS = 4
 
 POLICY_KINDS = {0: "ataxx_conv", 1: "conv", 2: "attention", 3: "dense"}
 

@@ -363,8 +363,13 @@ struct kz_engine {
     int device = 0, dtype = 0, max_batch = 0;
     size_t esz = 4;
     hipStream_t stream = nullptr;          // the stream the forward pass is currently enqueued on
-    hipStream_t slot_stream[KZ_ENGINE_SLOTS] = {};  // [0] = the main stream; [1..]: own streams on the fused path, where
-                                                    // a launch touches nothing but its slot's buffers
+    // [0] = the main stream.  On the fused path (one launch per batch, which touches nothing but its slot's buffers) slots
+    // alternate over TWO streams — a batch of 256 is half a chip of workgroups, so two launches run side by side and the
+    // next launch of a stream starts the moment the previous one ends — and the launch reads the packed boards from and
+    // writes the results to the slot's pinned host staging directly (zero copy): no H2D/D2H operation sits between two
+    // launches of a stream.  Otherwise all slots share the main stream and staging is copied.
+    hipStream_t slot_stream[KZ_ENGINE_SLOTS] = {};
+    bool zero_copy = false;
     int sync_all() {
         for (auto st : slot_stream)
             if (st) HIP_TRY(hipStreamSynchronize(st));
@@ -774,8 +779,8 @@ KZ_API void kz_engine_destroy(kz_engine *e) {
         if (s.done) (void)hipEventDestroy(s.done);
     for (void *p : e->allocs) (void)hipFree(p);
     for (void *p : e->pinned) (void)hipHostFree(p);
-    for (auto st : e->slot_stream)
-        if (st) (void)hipStreamDestroy(st);
+    for (int i = 0; i < KZ_ENGINE_SLOTS; i++)
+        if (e->slot_stream[i] && (i < 2 || e->slot_stream[i] != e->slot_stream[i & 1])) (void)hipStreamDestroy(e->slot_stream[i]);
     e->wts.reset();
     delete e;
 }
@@ -866,8 +871,12 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 
     HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[0], hipStreamNonBlocking));
     e->stream = e->slot_stream[0];
-    if (e->fused_heads)
-        for (int i = 1; i < KZ_ENGINE_SLOTS; i++) HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[i], hipStreamNonBlocking));
+    if (e->fused_heads) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[1], hipStreamNonBlocking));
+        for (int i = 2; i < KZ_ENGINE_SLOTS; i++) e->slot_stream[i] = e->slot_stream[i & 1];
+        const char *nzc = getenv("KZ_NO_ZERO_COPY");
+        e->zero_copy = !(nzc && nzc[0] == '1');
+    }
     const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
     if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
     if (e->nb4 && e->dmalloc(&e->xres, kz::tower4_scratch_bytes(max_batch))) return 1;
@@ -983,6 +992,15 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
         ~StreamSwap() { e->stream = saved; }
     } swap{e, e->stream};
     if (e->slot_stream[slot]) e->stream = e->slot_stream[slot];
+    if (e->zero_copy) {
+        // the one launch reads 136 B per board from pinned host memory and writes its 7.5 KB per board there
+        e->arm(s);
+        e->nf_flag = reinterpret_cast<int *>(s.h_sout);
+        if (e->forward_packed(s.h_bits, bits_bytes, s.h_sin, batch, s.h_sout + kz_engine::SOUT_HDR, s.h_pol)) return 1;
+        HIP_TRY(hipEventRecord(s.done, e->stream));
+        s.batch = batch;
+        return 0;
+    }
     HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
     e->arm(s);

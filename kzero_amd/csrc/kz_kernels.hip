@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
             act[o] = fmaxf(v, 0.0f);
         }
     }
-    if (bad && a.nonfinite_flag) atomicMax(a.nonfinite_flag, a.epoch);
+    if (bad && a.nonfinite_flag) *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may live in pinned host memory)
     __syncthreads();
     const int n_in = a.hc * a.hw;
     for (int j = wave; j < a.hs; j += 4) {

@@ -57,7 +57,8 @@ struct ScalarHeadArgs {
     const float *w2, *b2;  // [5][hs], [5]
     float *out;
     // range check: when a pre-activation sum of the head's 1x1 convolution (it reads every value of the tower output)
-    // is not finite, *nonfinite_flag = max(*nonfinite_flag, epoch).  An f16 overflow anywhere in the residual stream
+    // is not finite, *nonfinite_flag = epoch (a plain store: the flag may live in pinned host memory; every batch in
+    // flight has a flag of its own or, on the device-resident entry points, a larger epoch than what was checked last).  An f16 overflow anywhere in the residual stream
     // persists to the tower output (x + relu(..) never removes an inf/NaN), so this is where every path checks it.
     int *nonfinite_flag = nullptr;
     int epoch = 0;

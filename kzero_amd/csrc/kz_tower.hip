@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 }
                 // range check: this sum runs over every channel of one square of the tower output, and an f16 overflow
                 // anywhere in the residual stream persists to the tower output (x + relu(..) never removes an inf/NaN)
-                if (!(fabsf(s) <= 3.0e38f) && a.nonfinite_flag && board0 + b < a.batch) atomicMax(a.nonfinite_flag, a.epoch);
+                if (!(fabsf(s) <= 3.0e38f) && a.nonfinite_flag && board0 + b < a.batch)
+                    *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may be in pinned host memory)
                 act[o] = fmaxf(s, 0.0f);
             }
         }

@@ -46,7 +46,7 @@ pub const KZ_DTYPE_F32: c_int = 0;
 pub const KZ_DTYPE_F16: c_int = 1;
 /// f32 tensors and the same <= 1e-4 parity as KZ_DTYPE_F32, the tower's products as three f16 MFMAs on (hi, lo) pairs
 pub const KZ_DTYPE_F32_SPLIT16: c_int = 2;
-pub const KZ_ENGINE_SLOTS: usize = 2;
+pub const KZ_ENGINE_SLOTS: usize = 4;
 
 // The C ABI of include/kz_hip.h, declaration for declaration (tests/test_rust_shim_text.py compares the two files:
 // every function of the header is bound here with the same name, arity and pointer-ness).  `kz_model` / `kz_engine`

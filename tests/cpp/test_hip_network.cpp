@@ -174,11 +174,22 @@ int main(int argc, char **argv) {
         net.submit_batch(copy.data(), 3);
         net.submit_batch(copy.data() + 3, copy.size() - 3);
         CHECK(net.batches_in_flight() == 2);
+        // fill the remaining engine slots, then one more must be refused
+        std::vector<std::vector<PackedBoard>> extra;
+        while (net.batches_in_flight() < (size_t)KZ_ENGINE_SLOTS) {
+            extra.push_back(boards);
+            net.submit_batch(extra.back().data(), 1);
+        }
         bool threw = false;
         auto one = boards;
         try { net.submit_batch(one.data(), 1); } catch (const std::logic_error &) { threw = true; }
-        CHECK(threw);  // both engine slots are out
+        CHECK(threw);  // every engine slot is out
         auto y0 = net.wait_batch(), y1 = net.wait_batch();
+        for (size_t i = 0; i < extra.size(); i++) {  // results come back oldest first
+            auto ye = net.wait_batch();
+            CHECK(ye.size() == 1 && close_eval(ye[0], expect[0], 1e-4f));
+        }
+        CHECK(net.batches_in_flight() == 0);
         CHECK(y0.size() == 3 && y1.size() == boards.size() - 3);
         for (size_t i = 0; i < y0.size(); i++) CHECK(close_eval(y0[i], expect[i], 1e-4f));
         for (size_t i = 0; i < y1.size(); i++) CHECK(close_eval(y1[i], expect[3 + i], 1e-4f));

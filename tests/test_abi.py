@@ -141,7 +141,7 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     examples/eval_packed.c (model load -> engine -> submit / zero-copy wait) must link against libkzhip.so alone."""
     import subprocess
     src = tmp_path / "abi.c"
-    src.write_text('#include "kz_hip.h"\nint main(void) { return KZ_ENGINE_SLOTS == 2 && KZ_DTYPE_F32_SPLIT16 == 2 ? 0 : 1; }\n')
+    src.write_text('#include "kz_hip.h"\nint main(void) { return KZ_ENGINE_SLOTS == 4 && KZ_DTYPE_F32_SPLIT16 == 2 ? 0 : 1; }\n')
     REPO = O.REPO
     inc = os.path.join(REPO, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(tmp_path / "abi")])
