@@ -79,6 +79,7 @@ struct DeviceWeights {
 
     // scalar head
     float *sh_w0 = nullptr, *sh_b0 = nullptr, *sh_w1 = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
+    float *sh_w1t = nullptr;  // sh_w1 transposed: [inputs][outputs]
     // policy
     DevConv p_conv0;                                   // conv / ataxx_conv / dense hidden conv
     float *p_w1 = nullptr, *p_b1 = nullptr;            // last 1x1 conv of the conv heads
@@ -270,6 +271,12 @@ struct DeviceWeights {
         if (upload_f32(m.sh_conv.w, &sh_w0) || upload_f32(m.sh_conv.b, &sh_b0) || upload_f32(m.sh_fc0.w, &sh_w1) ||
             upload_f32(m.sh_fc0.b, &sh_b1) || upload_f32(m.sh_fc1.w, &sh_w2) || upload_f32(m.sh_fc1.b, &sh_b2))
             return 1;
+        {
+            std::vector<float> wt((size_t)m.sh_fc0.in * m.sh_fc0.out);
+            for (int o = 0; o < m.sh_fc0.out; o++)
+                for (int i = 0; i < m.sh_fc0.in; i++) wt[(size_t)i * m.sh_fc0.out + o] = m.sh_fc0.w[(size_t)o * m.sh_fc0.in + i];
+            if (upload_f32(wt, &sh_w1t)) return 1;
+        }
 
         if (fused_heads) return 0;  // the policy head lives in the tower's weight stream
         switch (m.policy_kind) {
@@ -591,7 +598,7 @@ struct kz_engine {
         {
             kz::ScalarHeadArgs a{x, cp, batch, hw, m.channels, m.sh_conv.cout, m.sh_fc0.out,
                                  wts->sh_w0, wts->sh_b0, wts->sh_w1, wts->sh_b1, wts->sh_w2, wts->sh_b2, d_scalars,
-                                 nf_flag, nf_epoch};
+                                 nf_flag, nf_epoch, wts->sh_w1t};
             prof.begin("kz_scalar_head", stream);
             kz::launch_scalar_head(dtype, a, stream);
             prof.end(stream);

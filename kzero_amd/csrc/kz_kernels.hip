@@ -466,6 +466,7 @@ struct ScalarHeadDev {
     float *out;
     int *nonfinite_flag;
     int epoch;
+    const float *w1t;
 };
 
 template <typename T>
@@ -497,11 +498,39 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
     if (bad && a.nonfinite_flag) *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may live in pinned host memory)
     __syncthreads();
     const int n_in = a.hc * a.hw;
-    for (int j = wave; j < a.hs; j += 4) {
-        float acc = 0.0f;
-        for (int i = lane; i < n_in; i += 64) acc += a.w1[(size_t)j * n_in + i] * act[i];
-        acc = wave_sum(acc);
-        if (lane == 0) hid[j] = fmaxf(acc + a.b1[j], 0.0f);
+    if (a.w1t && a.hs == 32) {
+        // Linear(n_in -> 32): every thread takes inputs tid, tid + 256, ... and all 32 outputs (the 32 weights of an input
+        // are 128 contiguous bytes of the transposed matrix: independent coalesced loads, no dependent chain), then the
+        // partial sums meet by wave butterfly and through LDS.  (One wave per output walking its 1444-long row — the
+        // loop below — is a chain of dependent L2 round trips: 589 us per call on Go 19x19 at batch 512.)
+        float part[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) part[j] = 0.0f;
+        for (int i = tid; i < n_in; i += 256) {
+            const float x = act[i];
+            const f32x4 *w = reinterpret_cast<const f32x4 *>(a.w1t + (size_t)i * 32);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x4 wv = w[q];
+#pragma unroll
+                for (int e = 0; e < 4; e++) part[q * 4 + e] += wv[e] * x;
+            }
+        }
+        __shared__ float red[4][32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const float s = wave_sum(part[j]);
+            if (lane == 0) red[wave][j] = s;
+        }
+        __syncthreads();
+        if (tid < 32) hid[tid] = fmaxf(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + a.b1[tid], 0.0f);
+    } else {
+        for (int j = wave; j < a.hs; j += 4) {
+            float acc = 0.0f;
+            for (int i = lane; i < n_in; i += 64) acc += a.w1[(size_t)j * n_in + i] * act[i];
+            acc = wave_sum(acc);
+            if (lane == 0) hid[j] = fmaxf(acc + a.b1[j], 0.0f);
+        }
     }
     __syncthreads();
     for (int j = wave; j < 5; j += 4) {
@@ -514,7 +543,7 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
 
 void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream) {
     ScalarHeadDev d{a.x, a.ldx, a.batch, a.hw, a.c, a.hc, a.hs, a.w0, a.b0, a.w1, a.b1, a.w2, a.b2, a.out,
-                    a.nonfinite_flag, a.epoch};
+                    a.nonfinite_flag, a.epoch, a.w1t};
     size_t shmem = sizeof(float) * ((size_t)a.hc * a.hw + a.hs);
     if (dtype == 0) kz_scalar_head<float><<<a.batch, 256, shmem, stream>>>(d);
     else kz_scalar_head<h16><<<a.batch, 256, shmem, stream>>>(d);

@@ -58,10 +58,12 @@ struct ScalarHeadArgs {
     float *out;
     // range check: when a pre-activation sum of the head's 1x1 convolution (it reads every value of the tower output)
     // is not finite, *nonfinite_flag = epoch (a plain store: the flag may live in pinned host memory; every batch in
-    // flight has a flag of its own or, on the device-resident entry points, a larger epoch than what was checked last).  An f16 overflow anywhere in the residual stream
-    // persists to the tower output (x + relu(..) never removes an inf/NaN), so this is where every path checks it.
+    // flight has a flag of its own or, on the device-resident entry points, a larger epoch than what was checked last).
+    // An f16 overflow anywhere in the residual stream persists to the tower output (x + relu(..) never removes an inf/NaN), so this is where every path checks it.
     int *nonfinite_flag = nullptr;
     int epoch = 0;
+    const float *w1t = nullptr;  // optional: w1 transposed to [hc*hw][hs] (used when hs == 32: every input's 32 weights are
+                                 // 128 contiguous bytes, so the first Linear reads coalesced and without dependent loops)
 };
 void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream);
 

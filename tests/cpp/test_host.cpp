@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <cstring>
 #include <set>
 #include <sstream>
 #include <thread>
@@ -105,6 +106,124 @@ static void test_mappers() {
         CHECK(full.size() == 21 * 64);
         CHECK(full[0] == 1 && full[63] == 1 && full[64] == 0 && full[2 * 64 + 5] == 1);
         CHECK(full[8 * 64 + 8] == 1 && full[8 * 64 + 0] == 0);
+    }
+    {
+        // Known-answer planes for ChessStdMapper::encode_input (chess.rs:125-171), derived BY HAND from three FENs: plane
+        // order = us P N B R Q K, them P N B R Q K, en passant; bit = square index (A1 = 0, file fastest); black to move
+        // sees every bitboard with the ranks flipped (pov_ranks, chess.rs:173-178); scalars = [pov white, pov black,
+        // castle us K, us Q, them K, them Q, repetitions, non-pawn-or-capture moves] (:136-155).
+        auto from_fen = [](const char *fen) {  // piece placement, side, castling and half-move clock of a FEN
+            ChessPosition p;
+            int rank = 7, file = 0;
+            const char *c = fen;
+            for (; *c != ' '; c++) {
+                if (*c == '/') { rank--; file = 0; continue; }
+                if (*c >= '1' && *c <= '8') { file += *c - '0'; continue; }
+                const char *kinds = "pnbrqk";
+                const int color = (*c >= 'a') ? 1 : 0;
+                const int piece = (int)(strchr(kinds, (char)tolower(*c)) - kinds);
+                p.pieces[color][piece] |= 1ull << (rank * 8 + file);
+                file++;
+            }
+            c++;
+            p.white_to_move = *c == 'w';
+            c += 2;
+            for (; *c != ' '; c++) {
+                if (*c == 'K') p.castle_kingside[0] = true;
+                if (*c == 'Q') p.castle_queenside[0] = true;
+                if (*c == 'k') p.castle_kingside[1] = true;
+                if (*c == 'q') p.castle_queenside[1] = true;
+            }
+            c++;
+            while (*c != ' ') c++;  // the en-passant field: set by the caller (what `inner.en_passant()` reports)
+            p.non_pawn_or_capture_moves = atoi(c + 1);
+            return p;
+        };
+        auto planes_of = [](const ChessPosition &p, std::vector<float> &scalars) {
+            ChessStdMapper m;
+            BitBuffer bools(input_bool_len(m));
+            m.encode_input(bools, scalars, p);
+            std::vector<std::vector<int>> planes(13);
+            for (int pl = 0; pl < 13; pl++)
+                for (int sq = 0; sq < 64; sq++)
+                    if (bools[pl * 64 + sq]) planes[pl].push_back(sq);
+            return planes;
+        };
+        using P = std::vector<std::vector<int>>;
+        {   // Ruy Lopez after 3...a6, white to move
+            auto p = from_fen("r1bqkbnr/1ppp1ppp/p1n5/1B2p3/4P3/5N2/PPPP1PPP/RNBQK2R w KQkq - 0 4");
+            std::vector<float> sc;
+            const P got = planes_of(p, sc);
+            const P want = {{8, 9, 10, 11, 13, 14, 15, 28}, {1, 21}, {2, 33}, {0, 7}, {3}, {4},
+                            {36, 40, 49, 50, 51, 53, 54, 55}, {42, 62}, {58, 61}, {56, 63}, {59}, {60}, {}};
+            CHECK(got == want);
+            CHECK((sc == std::vector<float>{1, 0, 1, 1, 1, 1, 0, 0}));
+        }
+        {   // French advance after 2...d5: the chess crate reports the capturable PAWN's square (d5 = 35) as en passant
+            auto p = from_fen("rnbqkbnr/ppp2ppp/4p3/3pP3/8/8/PPPP1PPP/RNBQKBNR w KQkq d6 0 3");
+            p.en_passant = 1ull << 35;
+            std::vector<float> sc;
+            const P got = planes_of(p, sc);
+            const P want = {{8, 9, 10, 11, 13, 14, 15, 36}, {1, 6}, {2, 5}, {0, 7}, {3}, {4},
+                            {35, 44, 48, 49, 50, 53, 54, 55}, {57, 62}, {58, 61}, {56, 63}, {59}, {60}, {35}};
+            CHECK(got == want);
+            CHECK((sc == std::vector<float>{1, 0, 1, 1, 1, 1, 0, 0}));
+        }
+        {   // 1. e4 e5 2. Ke2: BLACK to move, white has lost both castling rights, one reversible half-move
+            auto p = from_fen("rnbqkbnr/pppp1ppp/8/4p3/4P3/8/PPPPKPPP/RNBQ1BNR b kq - 1 2");
+            p.repetitions = 0;
+            std::vector<float> sc;
+            const P got = planes_of(p, sc);
+            // "us" = black, seen with the ranks flipped: rank 8 -> rank 1, e5 (36) -> e4 (28), e4 (28) -> e5 (36), e2 -> e7
+            const P want = {{8, 9, 10, 11, 13, 14, 15, 28}, {1, 6}, {2, 5}, {0, 7}, {3}, {4},
+                            {36, 48, 49, 50, 51, 53, 54, 55}, {57, 62}, {58, 61}, {56, 63}, {59}, {52}, {}};
+            CHECK(got == want);
+            CHECK((sc == std::vector<float>{0, 1, 1, 1, 0, 0, 0, 1}));
+        }
+    }
+    {
+        // Known answers for AtaxxStdMapper::encode_input (ataxx.rs:93-116) and GoStdMapper::encode_input (go.rs:64-113),
+        // derived by hand from position strings.  Ataxx 7x7 start "x5o/7/7/7/7/7/o5x x" with one gap at d4: the board-game
+        // crate's rank 1 is y = 0, so x (to move) owns a7 = (0,6) and g1 = (6,0), o owns g7 = (6,6) and a1 = (0,0); planes =
+        // next player's tiles, other player's tiles, gaps, each over full_mask() in y-major order; scalar = 30 / 100.
+        AtaxxStdMapper am(7);
+        AtaxxPosition ap;
+        ap.size = 7;
+        ap.tiles_next = (1ull << (6 * 7 + 0)) | (1ull << (0 * 7 + 6));
+        ap.tiles_other = (1ull << (6 * 7 + 6)) | (1ull << (0 * 7 + 0));
+        ap.gaps = 1ull << (3 * 7 + 3);
+        ap.moves_since_last_copy = 30;
+        BitBuffer ab(input_bool_len(am));
+        std::vector<float> as;
+        am.encode_input(ab, as, ap);
+        std::vector<int> on;
+        for (size_t i = 0; i < ab.len(); i++) if (ab[i]) on.push_back((int)i);
+        CHECK((on == std::vector<int>{6, 42, 49 + 0, 49 + 48, 98 + 24}));
+        CHECK(as.size() == 1 && std::fabs(as[0] - 0.3f) < 1e-7f);
+        // Go 5x5 inside 9x9 planes, white (Player::B) to move after a black pass, komi 6.5 for black: planes = stones of
+        // the player to move, stones of the other, in-board, ko/illegal, territory (mover, neither, other); scalars =
+        // [black to move, white to move, pass_1, pass_2, komi from the mover's side / 15, multi-stone suicide] (go.rs:89-112)
+        GoStdMapper gm(9, true);
+        GoPosition gp;
+        gp.size = 5;
+        gp.stones_next.assign(81, 0); gp.stones_other.assign(81, 0); gp.ko_illegal.assign(81, 0); gp.territory.assign(81, 1);
+        gp.stones_next[1 * 9 + 1] = 1;            // white stone at (1,1)
+        gp.stones_other[2 * 9 + 2] = 1;           // black stone at (2,2)
+        gp.ko_illegal[1 * 9 + 2] = 1;             // an empty point white may not play
+        gp.territory[0] = 0; gp.territory[4 * 9 + 4] = 2;
+        gp.next_is_black = false; gp.pass_1 = true; gp.komi_pov = -6.5f;
+        BitBuffer gb(input_bool_len(gm));
+        std::vector<float> gs;
+        gm.encode_input(gb, gs, gp);
+        CHECK(gb[0 * 81 + 10] && gb[1 * 81 + 20] && gb[3 * 81 + 11]);
+        int in_board = 0, own_next = 0, own_none = 0, own_other = 0;
+        for (int i = 0; i < 81; i++) {
+            in_board += gb[2 * 81 + i]; own_next += gb[4 * 81 + i]; own_none += gb[5 * 81 + i]; own_other += gb[6 * 81 + i];
+            CHECK(gb[2 * 81 + i] == (i % 9 < 5 && i / 9 < 5));
+        }
+        CHECK(in_board == 25 && own_next == 1 && own_other == 1 && gb[4 * 81 + 0] && gb[6 * 81 + 40]);
+        CHECK(gs.size() == 6 && gs[0] == 0 && gs[1] == 1 && gs[2] == 1 && gs[3] == 0 && gs[5] == 0);
+        CHECK(std::fabs(gs[4] - (-6.5f / 15.0f)) < 1e-7f);
     }
     {  // ChessHistoryMapper (chess.rs:26-124): shapes for every length (tests/mapper/chess/pairs.rs:366-368), contents
         ChessPosition p;
