@@ -772,3 +772,58 @@ def test_profiling_reports_kernel_time(dev):
     total, n = eng.kernel_time("kz_conv_igemm")
     assert n == 1 + 2 * 4 + 1 and total > 0  # stem + 2 per block + the policy head's 1x1
     eng.set_profiling(False)
+
+
+def test_four_board_tower_agrees_with_the_two_board_launch(dev, chess_full):
+    """kz_tower4.hip (KZ_TOWER_NB=4: four boards per workgroup, in-place LDS image, residual slab, asm-pinned
+    accumulators) against the product launch (two boards per workgroup) on the full 20x256 network, all 256 boards plus a
+    ragged batch: the tower outputs differ only by where the bias enters the f32 sum (after the products instead of
+    before), i.e. by single f16 roundings; and both against the oracle on a sample at the f16 tolerance."""
+    blob, bits, scalars_in = chess_full
+    model = capi.Model(blob=blob)
+    os.environ["KZ_NO_FUSED_HEADS"] = "1"
+    try:
+        two = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+        os.environ["KZ_TOWER_NB"] = "4"
+        four = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    finally:
+        os.environ.pop("KZ_TOWER_NB", None)
+        del os.environ["KZ_NO_FUSED_HEADS"]
+    assert two.tower_path == four.tower_path == "tower_resident_f16"
+    assert two.launch_geometry(256) == (128, 2) and four.launch_geometry(256) == (64, 4)
+    for n in (256, 7, 1):
+        s2, p2 = two.eval_packed(bits[:n], scalars_in[:n])
+        t2 = two.read_activation("tower.out", n)
+        s4, p4 = four.eval_packed(bits[:n], scalars_in[:n])
+        t4 = four.read_activation("tower.out", n)
+        assert_f16_paths_deep(t4, t2, f"tower output, {n} boards")
+        assert_f16_paths_deep(p4, p2, f"policy, {n} boards")
+        assert_f16_paths_deep(s4, s2, f"scalars, {n} boards")
+    net = O.OracleNet(blob)
+    pick = np.array([0, 1, 2, 3, 252, 253, 254, 255])
+    dense = O.encode_input_full(bits[pick], scalars_in[pick], net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    s4, p4 = four.eval_packed(bits, scalars_in)
+    assert_f16(s4[pick], s_ref, "four-board launch vs oracle, scalars")
+    assert_f16(p4[pick], p_ref, "four-board launch vs oracle, policy")
+
+
+def test_abi_helpers_on_the_device(dev):
+    """kz_device_pci_bus_id, kz_engine_launch_geometry, kz_model_supports_dtype, "tower.out"."""
+    bus = capi.device_pci_bus_id(dev)
+    assert len(bus.split(":")) == 3 and "." in bus, bus
+    blob = O.load_blob("chess_2x32_att")
+    model = capi.Model(blob=blob)
+    assert model.supports_dtype(capi.KZ_DTYPE_F32) and model.supports_dtype(capi.KZ_DTYPE_F16)
+    assert not model.supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)          # 32 channels: not a shape of the split launch
+    big = capi.Model(blob=synth.random_model("chess", 1, 256, "attention", seed=1))
+    assert big.supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)
+    fused = capi.Engine(big, dev, 256, capi.KZ_DTYPE_F16)
+    assert fused.launch_geometry(256) == (128, 2) and fused.launch_geometry(5) == (3, 2)
+    with pytest.raises(capi.KzError, match="tower.out"):
+        fused.read_activation("tower.out", 1)                              # the fused launch never writes the tower output
+    split = capi.Engine(big, dev, 256, capi.KZ_DTYPE_F32_SPLIT16)
+    assert split.launch_geometry(256) == (256, 1)
+    bits, scalars_in = synth.random_boards("chess", 3, seed=2)
+    split.eval_packed(bits, scalars_in)
+    assert split.read_activation("tower.out", 3).shape == (3, 256, 8, 8)
