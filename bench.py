@@ -84,6 +84,8 @@ def parse_args(argv=None):
                     help="seconds of untimed conditioning steps before the --warmup steps (0 to disable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the sub-records of the other BASELINE configs")
+    ap.add_argument("--no-seam", action="store_true", help="skip the whole-seam sub-record (generators -> executor loop); --no-others skips it too")
+    ap.add_argument("--seam-seconds", type=float, default=2.0)
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive timed region")
     ap.add_argument("--other-seconds", type=float, default=1.0, help="timed seconds per sub-record")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
@@ -349,6 +351,41 @@ def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm):
         w.close()
 
 
+def seam_record(blob, seconds):
+    """BASELINE configs[2] as the reference runs it: generator threads -> job channel -> executor loop
+    (`RunCondition::JobCount`, sizing of server_alphazero.rs:47-55) -> `HipNetwork::evaluate_batch` (host encode, the
+    engine over PCIe, host decode_output) -> replies, counted like the collector's `real` evals/s.  The host side is the
+    C++ mirror of the Rust seam (tests/cpp/bench_executor.cpp over kzero_amd/csrc/host/): one pipelined executor thread
+    with three batches in flight, search_batch 8 (the record carries the number of concurrent games the sizing rule
+    gives).  Built with g++ on first
+    use; any failure here is reported in the record, it never fails the bench."""
+    try:
+        exe = os.path.join(REPO, "tests", "cpp", "build", "bench_executor")
+        src = os.path.join(REPO, "tests", "cpp", "bench_executor.cpp")
+        lib_dir = os.path.join(REPO, "kzero_amd")
+        if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", src, "-o", exe, f"-L{lib_dir}", "-lkzhip",
+                                   f"-Wl,-rpath,{lib_dir}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        path = os.path.join("/tmp", f"kz_bench_seam_{os.getpid()}.kzm")
+        with open(path, "wb") as f:
+            f.write(blob)
+        try:
+            out = subprocess.run([exe, path, str(seconds), "1", "6", "256", "8", "f16", "3", "0"], capture_output=True,
+                                 text=True, timeout=120)
+        finally:
+            os.unlink(path)
+        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"metric": "NN evals/sec through generators -> job channel -> executor loop -> PCIe -> replies",
+                "value": rec["evals_per_s"], "unit": "evals/s", "fill": rec["fill"],
+                "executor_threads": rec["gpu_threads"], "pipeline_depth": rec["pipeline_depth"],
+                "generator_threads": rec["generator_threads"], "concurrent_games": rec["concurrent_games"],
+                "gpu_batch": rec["gpu_batch"], "search_batch": rec["search_batch"], "seconds": rec["seconds"],
+                "host": "C++ mirror of the Rust seam (kzero_amd/csrc/host), tests/cpp/bench_executor.cpp"}
+    except Exception as ex:  # noqa: BLE001 (diagnostic record only)
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
+
 def fake_main(args, benchlib, rank, world, dist):
     """--fake-step: the launcher and aggregation without a GPU (tests/test_bench_launcher.py)."""
     def step(i):
@@ -455,6 +492,8 @@ def main():
     w.close()
     if world == 1 and args.is_default_line and not args.no_others:
         out["others"] = [sub_record(capi, synth, n, d, device, args.other_seconds, args.prewarm) for n, d in OTHERS]
+    if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
+        out["seam"] = seam_record(blob, args.seam_seconds)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(blob, bits, scalars_in, args.cpu_seconds)
     print(json.dumps(out), flush=True)
