@@ -67,6 +67,8 @@ class PositionFileWriter {
     std::vector<uint64_t> game_starts_;
     std::vector<int64_t> lengths_;
     bool finished_ = false;
+    bool outcomes_known_ = true;
+    double root_wdl_sum_[3] = {0, 0, 0}, hit_move_limit_count_ = 0;
 
     static void put_u64(std::ofstream &f, uint64_t v) {
         unsigned char b[8];
@@ -97,8 +99,17 @@ class PositionFileWriter {
     const PositionFileMeta &meta() const { return meta_; }
 
     // all positions of one game, the terminal position last (includes_terminal_positions = true)
-    void append_game(const std::vector<PositionRecord> &records) {
+    // root_wdl: the game's outcome as (win, draw, loss) for the player to move in the start position
+    // (binary_output.rs:144), hit_move_limit: 1 when the game stopped without an outcome (:145), -1 / nullptr: unknown —
+    // the metadata then says NaN instead of an invented value
+    void append_game(const std::vector<PositionRecord> &records, const float *root_wdl = nullptr, int hit_move_limit = -1) {
         if (finished_) throw std::logic_error("This output is already finished");
+        if (!root_wdl || hit_move_limit < 0) {
+            outcomes_known_ = false;
+        } else {
+            for (int i = 0; i < 3; i++) root_wdl_sum_[i] += root_wdl[i];
+            hit_move_limit_count_ += hit_move_limit ? 1.0 : 0.0;
+        }
         game_starts_.push_back((uint64_t)meta_.position_count);
         lengths_.push_back((int64_t)records.size() - 1);
         for (const auto &r : records) append_position(r);
@@ -140,13 +151,24 @@ class PositionFileWriter {
             for (size_t i = 0; i < v.size(); i++) s += (i ? ", " : "") + std::to_string(v[i]);
             return s + "]";
         };
+        const bool known = outcomes_known_ && meta_.game_count > 0;
+        auto outcome_number = [&](double sum) {  // averages over the games (:276-277), NaN when a game came without them
+            std::ostringstream o;
+            if (known) o << sum / (double)meta_.game_count;
+            else o << "NaN";
+            return o.str();
+        };
+        auto outcome_list = [&] {
+            return "[" + outcome_number(root_wdl_sum_[0]) + ", " + outcome_number(root_wdl_sum_[1]) + ", " +
+                   outcome_number(root_wdl_sum_[2]) + "]";
+        };
         std::ostringstream js;
         js << "{\n  \"game\": \"" << meta_.game << "\",\n  \"input_bool_shape\": " << list(meta_.input_bool_shape)
            << ",\n  \"input_scalar_count\": " << meta_.input_scalar_count << ",\n  \"policy_shape\": " << list(meta_.policy_shape)
            << ",\n  \"game_count\": " << meta_.game_count << ",\n  \"position_count\": " << meta_.position_count
            << ",\n  \"includes_terminal_positions\": true,\n  \"includes_game_start_indices\": true"
            << ",\n  \"max_game_length\": " << meta_.max_game_length << ",\n  \"min_game_length\": " << meta_.min_game_length
-           << ",\n  \"root_wdl\": [0.3333333333333333, 0.3333333333333333, 0.3333333333333333],\n  \"hit_move_limit\": 0.0"
+           << ",\n  \"root_wdl\": " << outcome_list() << ",\n  \"hit_move_limit\": " << outcome_number(hit_move_limit_count_)
            << ",\n  \"scalar_names\": [";
         const auto &names = position_scalar_names();
         for (size_t i = 0; i < names.size(); i++) js << (i ? ", " : "") << '"' << names[i] << '"';

@@ -68,9 +68,21 @@ class PositionFileWriter:
         self._game_starts: List[int] = []
         self._lengths: List[int] = []
         self._finished = False
+        self._root_wdl_sum = np.zeros(3, np.float64)  # total_root_wdl, :58,144
+        self._hit_move_limit_count = 0.0              # hit_move_limit_count, :59,145
+        self._outcomes_known = True
 
-    def append_game(self, records: Sequence[PositionRecord]):
-        """All positions of one game, the terminal position last (includes_terminal_positions = true)."""
+    def append_game(self, records: Sequence[PositionRecord], root_wdl=None, hit_move_limit=None):
+        """All positions of one game, the terminal position last (includes_terminal_positions = true).
+        root_wdl: the game's outcome as (win, draw, loss) from the point of view of the player to move in the start
+        position (binary_output.rs:144); hit_move_limit: the game stopped without an outcome (:145).  finish() writes
+        their averages over the games like the reference (:276-277); when a game comes without them the metadata says NaN
+        instead of inventing a value."""
+        if root_wdl is None or hit_move_limit is None:
+            self._outcomes_known = False
+        else:
+            self._root_wdl_sum += np.asarray(root_wdl, np.float64)
+            self._hit_move_limit_count += float(bool(hit_move_limit))
         self._game_starts.append(self.meta.position_count)
         self._lengths.append(len(records) - 1)
         for r in records:
@@ -103,13 +115,17 @@ class PositionFileWriter:
         self._finished = True
         if self._lengths:
             self.meta.max_game_length, self.meta.min_game_length = max(self._lengths), min(self._lengths)
+        if self._outcomes_known and self.meta.game_count:
+            self.meta.root_wdl = [float(v) for v in self._root_wdl_sum / self.meta.game_count]
+            self.meta.hit_move_limit = self._hit_move_limit_count / self.meta.game_count
         meta = {
             "game": self.meta.game, "input_bool_shape": list(self.meta.input_bool_shape),
             "input_scalar_count": self.meta.input_scalar_count, "policy_shape": list(self.meta.policy_shape),
             "game_count": self.meta.game_count, "position_count": self.meta.position_count,
             "includes_terminal_positions": True, "includes_game_start_indices": True,
             "max_game_length": self.meta.max_game_length, "min_game_length": self.meta.min_game_length,
-            "root_wdl": [1 / 3, 1 / 3, 1 / 3], "hit_move_limit": 0.0, "scalar_names": list(SCALAR_NAMES),
+            "root_wdl": list(self.meta.root_wdl), "hit_move_limit": self.meta.hit_move_limit,
+            "scalar_names": list(SCALAR_NAMES),
         }
         self._off.write(np.asarray(self._game_starts, dtype="<u8").tobytes())
         self._bin.close()

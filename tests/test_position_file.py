@@ -45,6 +45,27 @@ def _write(path, games, shape, n_scalar, policy_shape, game="ataxx-7"):
     w.finish()
 
 
+def test_outcome_metadata_is_real_or_nan(tmp_path):
+    """root_wdl / hit_move_limit of the metadata are averages over the games as in the reference
+    (binary_output.rs:144-145,276-277) when the caller supplies the outcomes, and NaN — not an invented value — when not."""
+    import json
+    import math
+    games, shape, ns, pshape = _games(np.random.default_rng(7))
+    path = str(tmp_path / "games_7")
+    w = PositionFileWriter(path, "ataxx-7", shape, ns, pshape)
+    w.append_game(games[0], root_wdl=(1, 0, 0), hit_move_limit=False)
+    w.append_game(games[1], root_wdl=(0, 0, 1), hit_move_limit=False)
+    w.append_game(games[2], root_wdl=(0, 1, 0), hit_move_limit=True)
+    w.finish()
+    meta = json.load(open(path + ".json"))
+    assert meta["root_wdl"] == pytest.approx([1 / 3, 1 / 3, 1 / 3]) and meta["hit_move_limit"] == pytest.approx(1 / 3)
+    path2 = str(tmp_path / "games_8")
+    _write(path2, games, shape, ns, pshape)
+    meta2 = json.load(open(path2 + ".json"))
+    assert all(math.isnan(v) for v in meta2["root_wdl"]) and math.isnan(meta2["hit_move_limit"])
+    assert len(PositionFile(path2)) == sum(len(g) for g in games)
+
+
 def test_round_trip(tmp_path):
     games, shape, ns, pshape = _games(np.random.default_rng(1))
     path = str(tmp_path / "games_0")
