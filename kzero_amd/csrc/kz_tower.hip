@@ -329,10 +329,12 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 h16x8 af[4];
                 ring_take(stage, af);
                 // 4 x NT_ MFMAs on independent accumulators
+                // (output-channel tile outermost: the weight fragment is held for all pixel tiles and the activation
+                //  fragment changes — same sums, +0.4 % at a full chip against the other order in a same-box A/B)
 #pragma unroll
-                for (int mt = LO; mt < HI; mt++)
+                for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-                    for (int nt = 0; nt < 4; nt++)
+                    for (int mt = LO; mt < HI; mt++)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[cur][mt], acc[nt][mt], 0, 0, 0);
                 // issue order: every memory instruction rides in the shadow of one MFMA — first the 4 ring refills,
                 // then the LDS fragment reads, then the remaining MFMAs back to back.  (Same-box A/B: +0.5 % over a
