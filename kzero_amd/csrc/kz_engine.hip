@@ -60,6 +60,7 @@ struct DevConv {  // packed for kz_conv_igemm: [k*k][cout_p][cin_p] in T, bias f
     float *b = nullptr;
     int cin_p = 0, cout_p = 0, cout = 0, k = 1;
     void *bw = nullptr;  // instead of w: packed for kz_board_conv_f16 (3x3, f16, channels % 64 == 0)
+    bool bw2 = false;    // ... packed for kz_board_conv2_f16 (two Go-size boards per workgroup)
     void *sw = nullptr;  // in addition to w: (hi, lo) f16 pairs for kz_conv1x1_split (1x1 head convolutions, split16)
 };
 
@@ -121,7 +122,9 @@ struct DeviceWeights {
         d.cout = d.cout_p = cv.cout;
         d.cin_p = cv.cin;
         std::vector<uint16_t> packed(kz::board_conv_weight_elems(cv.cin, cv.cout));
-        kz::board_conv_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        d.bw2 = conv2;
+        if (conv2) kz::board_conv2_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        else kz::board_conv_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
         if (upload(packed.data(), packed.size() * 2, &d.bw)) return 1;
         return upload_f32(cv.b, &d.b);
     }
@@ -183,6 +186,7 @@ struct DeviceWeights {
     }
 
     bool use_board_conv = false;
+    bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
     int *bc_rowmap = nullptr;  // kz_board_conv_f16's tile-row map and halo-row list for this board size
     unsigned short *bc_halo = nullptr;
     int bc_n_halo = 0;
@@ -255,7 +259,11 @@ struct DeviceWeights {
             if (use_board_conv && !(noboard && noboard[0] == '1')) {
                 std::vector<int> rowmap;
                 std::vector<unsigned short> halo;
-                kz::board_conv_tables(m.h, m.w, rowmap, halo);
+                const char *c2 = getenv("KZ_BOARD_CONV2");
+                // (experiment, opt-in: the second organisation measured 26.2k against 33.5k evals/s on Go-19 40x256)
+                conv2 = c2 && c2[0] == '1' && kz::board_conv2_supported(dtype, m.h, m.w, m.channels, m.channels);
+                if (conv2) kz::board_conv2_tables(m.h, m.w, rowmap, halo);
+                else kz::board_conv_tables(m.h, m.w, rowmap, halo);
                 bc_n_halo = (int)halo.size();
                 if (upload(rowmap.data(), rowmap.size() * sizeof(int), (void **)&bc_rowmap)) return 1;
                 if (upload(halo.data(), halo.size() * sizeof(unsigned short), (void **)&bc_halo)) return 1;
@@ -483,7 +491,8 @@ struct kz_engine {
             b.boards = M / (h * wd); b.h = h; b.w = wd; b.cin = w.cin_p; b.cout = w.cout; b.relu = relu;
             b.rowmap = wts->bc_rowmap; b.halo = wts->bc_halo; b.n_halo = wts->bc_n_halo;
             prof.begin("kz_board_conv_f16", stream);
-            kz::launch_board_conv(b, stream);
+            if (w.bw2) kz::launch_board_conv2(b, stream);
+            else kz::launch_board_conv(b, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             return 0;
@@ -860,7 +869,9 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0),
+        const char *c2 = getenv("KZ_BOARD_CONV2");  // (the opt-in board-conv organisation has its own weight packing)
+        auto key = std::make_tuple(model->m.get(), device,
+                                   dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + (c2 && c2[0] == '1' ? 400 : 0),
                                    e->resident || e->resident32,
                                    e->fused_heads, board_conv);
         auto it = g_cache.find(key);
@@ -952,7 +963,8 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     else if (e->split16 || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
     else if (e->resident32) per = kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
-    else if (e->path == "board_conv_f16") wgs = kz::board_conv_workgroups(batch, m.h, m.w, m.channels);
+    else if (e->path == "board_conv_f16")
+        wgs = e->wts->conv2 ? kz::board_conv2_workgroups(batch, m.channels) : kz::board_conv_workgroups(batch, m.h, m.w, m.channels);
     else wgs = kz::conv_workgroups(e->dtype, batch * m.h * m.w, e->cp);
     *workgroups = wgs;
     *boards_per_workgroup = per;

@@ -128,6 +128,13 @@ size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
 void board_conv_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo);
 void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);
+// second organisation for boards of 193..384 squares (Go 19x19): two boards per workgroup, one workgroup per CU, staging
+// under the MFMAs (kz_board_conv2.hip).  Same BoardConvArgs, with its own weight packing and tables.
+bool board_conv2_supported(int dtype, int h, int w, int cin, int cout);
+int board_conv2_workgroups(int boards, int cout);
+void board_conv2_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
+void board_conv2_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo);
+void launch_board_conv2(const BoardConvArgs &a, hipStream_t stream);
 
 // ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----
 // Requirements: f32, channels 256 with h*w <= 64, or channels 128 with h*w <= 96; depth >= 1.

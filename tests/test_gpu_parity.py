@@ -827,3 +827,31 @@ def test_abi_helpers_on_the_device(dev):
     bits, scalars_in = synth.random_boards("chess", 3, seed=2)
     split.eval_packed(bits, scalars_in)
     assert split.read_activation("tower.out", 3).shape == (3, 256, 8, 8)
+
+
+def test_board_conv2_experiment_agrees_with_the_product_kernel(dev):
+    """kz_board_conv2.hip (opt-in KZ_BOARD_CONV2=1: two Go boards per workgroup, staging under the MFMAs) against
+    kz_board_conv.hip on Go-19 256-channel layers, odd batch included: identical operands and rounding points, so they
+    agree to summation order; and against the oracle on one board."""
+    blob = synth.random_model("go-19", 2, 256, "conv", seed=5)
+    model = capi.Model(blob=blob)
+    ref = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
+    os.environ["KZ_BOARD_CONV2"] = "1"
+    try:
+        exp = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
+    finally:
+        del os.environ["KZ_BOARD_CONV2"]
+    assert ref.tower_path == exp.tower_path == "board_conv_f16"
+    assert ref.launch_geometry(512) == (2048, 0) and exp.launch_geometry(512) == (1024, 0)
+    for n in (7, 64):
+        bits, scalars_in = synth.random_boards("go-19", n, seed=6 + n)
+        s0, p0 = ref.eval_packed(bits, scalars_in)
+        t0 = ref.read_activation("tower.out", n)
+        s1, p1 = exp.eval_packed(bits, scalars_in)
+        t1 = exp.read_activation("tower.out", n)
+        assert np.abs(t1 - t0).max() < F16_PATHS_ATOL and np.abs(p1 - p0).max() < F16_PATHS_ATOL and np.abs(s1 - s0).max() < F16_PATHS_ATOL
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits[:1], scalars_in[:1], net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    assert_f16(s1[:1], s_ref, "board_conv2 vs oracle, scalars")
+    assert_f16(p1[:1], p_ref, "board_conv2 vs oracle, policy")
