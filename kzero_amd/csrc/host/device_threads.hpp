@@ -45,9 +45,13 @@ struct EvalCounters {
     std::atomic<uint64_t> real{0}, potential{0};
 };
 
-template <class B, class M>
+// Net: the network an executor thread builds from a graph, `Net(mapper, graph, max_batch, device, dtype)` with
+// evaluate_batch / submit_batch / wait_batch / set_device_decode / max_in_flight (HipNetwork<B, M>; the tests put a fake
+// in its place to run several "devices" without a GPU).  GraphT: what the commander sends (`Arc<G>`).
+template <class B, class M, class Net = HipNetwork<B, M>, class GraphT = std::shared_ptr<const HipModel>>
 struct DeviceExecutors {
-    using Graph = std::shared_ptr<const HipModel>;
+    using Graph = GraphT;
+    int device = 0;
     JobClient<B, ZeroEvaluation> eval_client;
     std::vector<Sender<std::optional<Graph>>> graph_senders;  // one per executor thread (commander.rs:19-25)
     std::vector<std::thread> threads;
@@ -65,20 +69,20 @@ struct DeviceExecutors {
 };
 
 // server_alphazero.rs:89-121
-template <class B, class M>
-std::unique_ptr<DeviceExecutors<B, M>> spawn_device_executors(int device, const StartupSettings &startup, M mapper,
-                                                               int dtype, EvalCounters *counters) {
+template <class B, class M, class Net = HipNetwork<B, M>, class GraphT = std::shared_ptr<const HipModel>>
+std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int device, const StartupSettings &startup,
+                                                                           M mapper, int dtype, EvalCounters *counters) {
     const DeviceSizing sizing(startup);
-    auto dev = std::make_unique<DeviceExecutors<B, M>>();
+    auto dev = std::make_unique<DeviceExecutors<B, M, Net, GraphT>>();
+    dev->device = device;
     auto [client, server] = job_pair<B, ZeroEvaluation>(sizing.job_buffer_size);
     dev->eval_client = client;
     const size_t gpu_batch_size = startup.gpu_batch_size;
     for (size_t local_id = 0; local_id < startup.gpu_threads_per_device; local_id++) {
-        auto [gtx, grx] = bounded<std::optional<typename DeviceExecutors<B, M>::Graph>>(1);  // :90
+        auto [gtx, grx] = bounded<std::optional<GraphT>>(1);  // :90
         dev->graph_senders.push_back(gtx);
         dev->threads.emplace_back([=, srv = server, rx = std::move(grx)]() mutable {
-            using Net = HipNetwork<B, M>;
-            using Graph = typename DeviceExecutors<B, M>::Graph;
+            using Graph = GraphT;
             const bool device_decode = startup.device_decode;
             auto load = [=](Graph g) {
                 Net net(mapper, std::move(g), gpu_batch_size, device, dtype);
@@ -112,6 +116,19 @@ std::unique_ptr<DeviceExecutors<B, M>> spawn_device_executors(int device, const 
         });
     }
     return dev;
+}
+
+// The per-device loop of selfplay_start (rust/kz-selfplay/src/server/server.rs:323-331): one spawn_device_threads per
+// device, each with its own job channel, executors and (the caller's) generators; nothing is shared between devices but
+// the immutable graph and the counters.
+template <class B, class M, class Net = HipNetwork<B, M>, class GraphT = std::shared_ptr<const HipModel>>
+std::vector<std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>>> spawn_all_devices(const std::vector<int> &devices,
+                                                                                     const StartupSettings &startup, M mapper,
+                                                                                     int dtype, EvalCounters *counters) {
+    if (devices.empty()) throw std::invalid_argument("No devices found");  // server.rs:53, :314
+    std::vector<std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>>> all;
+    for (int device : devices) all.push_back(spawn_device_executors<B, M, Net, GraphT>(device, startup, mapper, dtype, counters));
+    return all;
 }
 
 }  // namespace kz::host

@@ -14,6 +14,7 @@
 #include <thread>
 #include <tuple>
 
+#include "../../kzero_amd/csrc/host/device_threads.hpp"
 #include "../../kzero_amd/csrc/host/executor.hpp"
 #include "../../kzero_amd/csrc/host/mapping.hpp"
 #include "../../kzero_amd/csrc/host/network.hpp"
@@ -870,6 +871,114 @@ static void test_symmetry(const std::string &golden_dir) {
     CHECK(ev.policy[0] == (float)AtaxxStdMapper(7).move_to_index((*b.moves)[0]));
 }
 
+// ---- per-device spawn (server.rs:323-331, server_alphazero.rs:89-121) over several devices, without a GPU: a fake network
+// that remembers which device it was built for and answers with it ----
+struct FakeGraph {
+    int generation;
+};
+static std::mutex g_fake_mu;
+static std::vector<std::tuple<int, int, std::thread::id>> g_fake_built;  // (device, generation, thread)
+struct FakeDeviceNet {
+    PackedMapper mapper;
+    std::shared_ptr<const FakeGraph> graph;
+    size_t max_batch;
+    int device;
+    std::vector<std::vector<PackedBoard>> pending;
+    FakeDeviceNet(PackedMapper m, std::shared_ptr<const FakeGraph> g, size_t max_batch, int device, int /*dtype*/)
+        : mapper(m), graph(std::move(g)), max_batch(max_batch), device(device) {
+        std::lock_guard<std::mutex> lock(g_fake_mu);
+        g_fake_built.emplace_back(device, graph->generation, std::this_thread::get_id());
+    }
+    void set_device_decode(bool) {}
+    static constexpr size_t max_in_flight() { return 2; }
+    ZeroEvaluation answer(const PackedBoard &b) const {
+        ZeroEvaluation e;
+        e.values.value = (float)device;                           // which device answered
+        e.values.moves_left = (float)graph->generation;           // with which network
+        e.values.wdl = {b.scalars.empty() ? 0.f : b.scalars[0], 0.f, 0.f};  // and for which board
+        return e;
+    }
+    std::vector<ZeroEvaluation> evaluate_batch(const PackedBoard *x, size_t n) {
+        if (n > max_batch) throw std::logic_error("batch too large");
+        std::vector<ZeroEvaluation> y;
+        for (size_t i = 0; i < n; i++) y.push_back(answer(x[i]));
+        return y;
+    }
+    void submit_batch(PackedBoard *x, size_t n) { pending.emplace_back(x, x + n); }
+    std::vector<ZeroEvaluation> wait_batch() {
+        auto boards = std::move(pending.front());
+        pending.erase(pending.begin());
+        return evaluate_batch(boards.data(), boards.size());
+    }
+};
+
+static void test_spawn_all_devices() {
+    for (size_t depth : {1, 2}) {
+        {
+            std::lock_guard<std::mutex> lock(g_fake_mu);
+            g_fake_built.clear();
+        }
+        StartupSettings st;
+        st.gpu_threads_per_device = 2;
+        st.gpu_batch_size = 8;
+        st.search_batch_size = 8;  // one job = one batch (RunCondition::JobCount(1)): with several jobs per batch the last
+                                   // ones of a finite test would strand on two executor threads, as in the reference
+        st.pipeline_depth = depth;
+        EvalCounters counters;
+        PackedMapper mapper{1, 2, 4, 1, 3};
+        const std::vector<int> devices = {0, 1, 5};  // (device ordinals need not be contiguous: `--device 0 1 5`)
+        auto all = spawn_all_devices<PackedBoard, PackedMapper, FakeDeviceNet, std::shared_ptr<const FakeGraph>>(
+            devices, st, mapper, 0, &counters);
+        CHECK(all.size() == 3);
+        CHECK(throws([&] {
+            spawn_all_devices<PackedBoard, PackedMapper, FakeDeviceNet, std::shared_ptr<const FakeGraph>>({}, st, mapper, 0, nullptr);
+        }));
+        auto graph1 = std::make_shared<const FakeGraph>(FakeGraph{1});
+        for (auto &dev : all) dev->send_graph(graph1);
+        // every device has its own job channel: a job sent to device d is answered by a network built for device d
+        auto run = [&](int generation) {
+            std::vector<std::thread> gens;
+            std::atomic<int> wrong{0};
+            for (size_t dg = 0; dg < all.size() * 2; dg++)
+                gens.emplace_back([&, d = dg / 2] {
+                    auto client = all[d]->eval_client;
+                    for (int round = 0; round < 40; round++) {
+                        std::vector<PackedBoard> x(st.search_batch_size);
+                        for (size_t k = 0; k < x.size(); k++) {
+                            x[k].bits.assign(1, 0);
+                            x[k].scalars = {(float)(round * 10 + (int)k)};
+                        }
+                        auto y = client.map_blocking(std::move(x));
+                        if (y.size() != st.search_batch_size) { wrong++; continue; }
+                        for (size_t k = 0; k < y.size(); k++)
+                            if (y[k].values.value != (float)devices[d] || y[k].values.moves_left != (float)generation ||
+                                y[k].values.wdl.win != (float)(round * 10 + (int)k))
+                                wrong++;
+                    }
+                });
+            for (auto &g : gens) g.join();
+            return wrong.load();
+        };
+        CHECK(run(1) == 0);
+        CHECK(counters.real == 3 * 2 * 40 * st.search_batch_size);
+        // NewNetwork reaches every executor of every device (commander.rs:36-45)
+        auto graph2 = std::make_shared<const FakeGraph>(FakeGraph{2});
+        for (auto &dev : all) dev->send_graph(graph2);
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        CHECK(run(2) == 0);
+        for (auto &dev : all) dev->join();
+        std::lock_guard<std::mutex> lock(g_fake_mu);
+        for (int device : devices)
+            for (int generation : {1, 2}) {
+                std::set<std::thread::id> threads;
+                for (auto &[d, g, t] : g_fake_built)
+                    if (d == device && g == generation) threads.insert(t);
+                CHECK(threads.size() == st.gpu_threads_per_device);  // one network per executor thread, built ON that thread
+            }
+        CHECK(g_fake_built.size() == devices.size() * 2 * st.gpu_threads_per_device);
+    }
+}
+
 int main(int argc, char **argv) {
     const std::string golden = argc > 1 ? argv[1] : "tests/golden";
     std::fputs("bitbuffer\n", stderr); test_bitbuffer();
@@ -885,6 +994,7 @@ int main(int argc, char **argv) {
     std::fputs("pipelined\n", stderr); test_pipelined_loop();
     std::fputs("pipelined job_count\n", stderr); test_pipelined_job_count();
     std::fputs("symmetry\n", stderr); test_symmetry(golden);
+    std::fputs("devices\n", stderr); test_spawn_all_devices();
     if (g_failed) {
         std::fprintf(stderr, "%d check(s) failed\n", g_failed);
         return 1;
