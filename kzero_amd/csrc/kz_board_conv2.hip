@@ -8,6 +8,10 @@
 // ~5 us) and epilogue (~4 us) around 26 us of MFMA work, and the k-loop alone runs at ~70 % — the two co-resident
 // workgroups of kz_board_conv.hip cover each other's phases better than this single one pipelines its own.  What it
 // would take is a persistent workgroup that prefetches the next item under the current epilogue.
+// In-kernel stamps (-DKZ_BC2_STAMPS, tools/board_conv2_stamps.py), cycles per workgroup of 119.5k: set-up 5.1k, first
+// half-chunk 4.3k, eight k-loops 78.7k (9.3k each against 6.9k of MFMA time: a single wave per SIMD pays ~265 cycles of
+// issue per k-step for its 12 fragment reads, 12 address adds and 4 loads — what the co-resident wave hides in
+// kz_board_conv.hip), stage writes + barriers 8k, epilogue 24k (tile writes 10.4k, stores 13.5k).
 //
 // Why: in kz_board_conv.hip a wave owns 64 output channels x 6 pixel tiles and two workgroups share a CU, so the CU's
 // eight waves pull the same 4 KB of weight fragments per k-step through L1 eight times: 53 of the 64 B/clk L1 delivers
@@ -25,6 +29,7 @@
 //               fragment reads, LDS is not what bounds this kernel: 12 reads per 48 MFMAs)
 //   epilogue  = as kz_board_conv.hip (residual in the accumulators' layout, result through LDS so that HBM sees whole
 //               128-byte lines), one board at a time through the dead image buffers
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -61,6 +66,21 @@ __device__ __forceinline__ h16x8 lds_frag(int addr) {
 #endif
 }
 
+// Diagnostic build only (-DKZ_BC2_STAMPS): s_memtime stamps at the phase boundaries of every wave, dumped by the
+// launcher to $KZ_BC_STAMP_FILE after the 20th launch.  No stamp executes in the real kernel.
+#ifdef KZ_BC2_STAMPS
+#define KZ_STAMP2(slot)                                                                        \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (slot)] = t_;           \
+    } while (0)
+#else
+#define KZ_STAMP2(slot) do { } while (0)
+#endif
+
 struct BoardConv2Dev {
     const h16 *x;
     const uint4 *w;     // [n_quarter][k-step = (chunk, ks, tap)][nt 4][lane 64] x 16 B
@@ -71,6 +91,7 @@ struct BoardConv2Dev {
     const int *rowmap;             // [768] tile row -> board << 20 | pixel << 10 | image row, or -1
     const unsigned short *halo;   // image rows that are halo
     int n_halo, pitch, buf_bytes;
+    unsigned long long *stamps;  // diagnostic build only
     int ablate;  // timing experiments only (KZ_BC_ABLATE): 1 no staging loads, 2 no residual/output traffic, 4 no k-loop barrier
 };
 
@@ -80,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv2_f16(BoardConv2Dev a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int fr = lane & 15, kq = lane >> 4;
+    KZ_STAMP2(0);
     // XCD-aware order as kz_board_conv.hip: the nq channel quarters of a board pair take consecutive slots of one XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nquarter = slot % a.nq, group = (slot / a.nq) * 8 + xcd;
@@ -145,6 +167,7 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv2_f16(BoardConv2Dev a) {
         }
     }
 
+    KZ_STAMP2(1);
     // ---- first half-chunk into buffer 0 ----
     u32x4 stage[12];
 #pragma unroll
@@ -153,6 +176,7 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv2_f16(BoardConv2Dev a) {
     for (int i = 0; i < 12; i++)
         if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + ls[i]) = stage[i];  // never into the halo
     __syncthreads();
+    KZ_STAMP2(2);
 
     constexpr int HT = MTW / 2;
     for (int hc = 0; hc < halves; hc++) {
@@ -215,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv2_f16(BoardConv2Dev a) {
             __builtin_amdgcn_sched_barrier(0);
             g++;
         }
+        KZ_STAMP2(3 + 2 * (hc & 7));
         // the staged pieces -> the other buffer (last read during the previous half-chunk, which ended with a barrier)
         if (more) {
             const int nbuf = ((hc + 1) & 1) * a.buf_bytes;
@@ -223,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv2_f16(BoardConv2Dev a) {
                 if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + nbuf + ls[i]) = stage[i];
         }
         __syncthreads();
+        KZ_STAMP2(4 + 2 * (hc & 7));
     }
 
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory, one board at a time ----
@@ -274,7 +300,9 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv2_f16(BoardConv2Dev a) {
             }
         }
     }
+    KZ_STAMP2(19);
     __syncthreads();
+    KZ_STAMP2(20);
 #pragma unroll
     for (int b = 0; b < BPW; b++) {
         const unsigned char *tile = lds + b * a.buf_bytes;
@@ -288,6 +316,7 @@ __global__ __launch_bounds__(256, 1) void kz_board_conv2_f16(BoardConv2Dev a) {
                                                    nquarter * OCW * 2, 0);  // a padding row's store is out of range: dropped
         }
     }
+    KZ_STAMP2(21);
 }
 
 struct Geometry2 {
@@ -377,7 +406,28 @@ void launch_board_conv2(const BoardConvArgs &t, hipStream_t stream) {
         done_mask |= 1ull << (dev & 63);
     }
     const int grid = ((d.groups + 7) / 8) * 8 * d.nq;
+#ifdef KZ_BC2_STAMPS
+    static unsigned long long *stamp_buf = nullptr;
+    static int launches = 0;
+    const size_t stamp_bytes = (size_t)grid * 4 * 32 * sizeof(unsigned long long);
+    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, (size_t)8192 * 4 * 32 * 8);
+    d.stamps = stamp_buf;
+    if (launches == 20) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, stream);
+#else
+    d.stamps = nullptr;
+#endif
     kz_board_conv2_f16<<<grid, 256, 2 * geo.buf_bytes, stream>>>(d);
+#ifdef KZ_BC2_STAMPS
+    if (launches++ == 20 && getenv("KZ_BC_STAMP_FILE")) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> host(stamp_bytes / 8);
+        (void)hipMemcpy(host.data(), stamp_buf, stamp_bytes, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("KZ_BC_STAMP_FILE"), "wb")) {
+            fwrite(host.data(), 1, stamp_bytes, f);
+            fclose(f);
+        }
+    }
+#endif
 }
 
 }  // namespace kz
