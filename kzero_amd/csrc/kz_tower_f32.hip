@@ -13,8 +13,8 @@
 //               stride is an odd number of 16-byte slots: conflict-free for every tap.  MFMA k-step s pairs element s of
 //               the activation fragment with element s of the weight fragment, which the host packed in the same order.
 //   weights   = streamed L2 -> registers in fragment order (16 B per lane per step and 16-channel output tile) through
-//               a two-step ring; a step is 4 * (C/64) * NT MFMAs of 32 cycles, so the ring has > 1 us of cover
-//   epilogue  = bias-initialised accumulators; [ReLU]; [+ residual, in place in the out image]; [final BN]; 16-byte
+//               a four-step ring that runs on across layer boundaries; a step is 4 * (C/64) * NT MFMAs of 32 cycles
+//   epilogue  = bias-initialised accumulators (the next layer's bias is fetched a layer ahead); [ReLU]; [+ residual, in place in the out image]; [final BN]; 16-byte
 //               stores (4 consecutive output channels of a pixel row per lane)
 //
 // Arithmetic follows python/lib/model/post_act.py:201-239 with Conv+BN folded on the host (kz_model.cpp).
@@ -168,40 +168,77 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
         out = IMG0;
     }
 
-    // ---- 2*depth tower convolutions: 9 G steps each, weights and fragments one step ahead ----
+    // ---- 2*depth tower convolutions: 9 G steps each.  Weights run FOUR steps ahead through a register ring (a step is
+    // 4*OT*NT MFMAs of 32 cycles = 0.75 us at A1: two steps of cover were less than an L2 round trip under load), the
+    // activation fragments one step ahead in the other of two buffers; inside a step every fragment read and ring refill
+    // is placed in the shadow of MFMAs (24 free issue cycles per f32 MFMA) instead of in a burst between two blocks of
+    // MFMAs.  Round 2, A1 at a full chip: MFMA-busy 83.7 % -> see DESIGN.md §5.2a. ----
     const int koff = plane_of<C>(kq);
-    for (int layer = 1; layer <= 2 * a.depth; layer++) {
-        constexpr int S = 9 * G;
-        f32x4 wA[OT], wB[OT], bA[NT], bB[NT];
-        auto issue_w = [&](f32x4(&wf)[OT], int t) {
-            const f32x4 *p = wl + (size_t)t * STEP;
+    constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
+    constexpr int S = 9 * G;
+    static_assert(S % 4 == 0, "the ring stage of a step is a compile-time constant");
+    // the ring runs across layer boundaries (the stream is contiguous): step index ts counts from the first tower layer
+    const int total_steps = 2 * a.depth * S;
+    int ts = 0;
+    f32x4 wring[4][OT];
+    auto issue_w = [&](f32x4(&wf)[OT], int t) {  // t: step of the whole tower, clamped at the end of the stream
+        const f32x4 *p = wl + (size_t)(t < total_steps ? t : total_steps - 1) * STEP;
 #pragma unroll
-            for (int ot = 0; ot < OT; ot++) wf[ot] = p[ot * 64];
-        };
+        for (int ot = 0; ot < OT; ot++) wf[ot] = p[ot * 64];
+    };
+#pragma unroll
+    for (int u = 0; u < 4; u++) issue_w(wring[u], u);
+    // the bias of the next layer is fetched while this one computes
+    f32x4 bias_next[OT];
+    auto fetch_bias = [&](int layer) {
+        const int l = layer <= 2 * a.depth ? layer : 2 * a.depth;
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++)
+            bias_next[ot] = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)l * C + (wave * OT + ot) * 16 + kq * 4);
+    };
+    fetch_bias(1);
+    for (int layer = 1; layer <= 2 * a.depth; layer++) {
+        f32x4 bA[NT], bB[NT];
         auto issue_b = [&](f32x4(&bf)[NT], int t) {
             const int tap = t / G, g = t % G;
             if (g == 0) tap_rows(tap, koff);
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) bf[nt] = *reinterpret_cast<const f32x4 *>(lds + T[nt] + g * 16);
         };
-        issue_w(wA, 0);
-        issue_w(wB, 1);
-        init_acc(layer);
+#pragma unroll
+        for (int ot = 0; ot < OT; ot++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[ot][nt] = bias_next[ot];
+        fetch_bias(layer + 1);
         issue_b(bA, 0);
 #pragma unroll 1
-        for (int t = 0; t < S; t += 2) {
-            issue_b(bB, t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(wA, bA);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_w(wA, t + 2 < S ? t + 2 : S - 1);
-            issue_b(bA, t + 2 < S ? t + 2 : S - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step(wB, bB);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_w(wB, t + 3 < S ? t + 3 : S - 1);
+        for (int t = 0; t < S; t += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int tn = t + u + 1 < S ? t + u + 1 : S - 1, tw = ts + 4;
+                if (u & 1) {
+                    issue_b(bA, tn);
+                    mfma_step(wring[u], bB);
+                } else {
+                    issue_b(bB, tn);
+                    mfma_step(wring[u], bA);
+                }
+                issue_w(wring[u], tw);  // (this stage's fragments have been issued to the MFMAs)
+                ts++;
+#pragma unroll
+                for (int i = 0; i < NT; i++) {
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4 * OT * NT - 4 * NT - 4 * OT, 0);
+#pragma unroll
+                for (int i = 0; i < OT; i++) {
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_VMEM_READ, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        wl += (size_t)S * STEP;
         const bool second = (layer & 1) == 0;  // the block's second conv: residual add, and the final BN on the last
         epilogue(true, second, second && layer == 2 * a.depth);
         __syncthreads();
