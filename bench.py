@@ -42,7 +42,7 @@ WORKLOADS = {
                          engines={"f16": 2, "f32": 2, "f32split16": 2},
                          label="Chess 20x256 ResNet b=256"),
     "ataxx-8x128": dict(game="ataxx-7", depth=8, channels=128, head="ataxx_conv", batch=256, steps=10000,
-                        engines={"f16": 3, "f32": 3, "f32split16": 3},
+                        engines={"f16": 3, "f32": 2, "f32split16": 3},
                         label="Ataxx 7x7 8x128 ResNet b=256"),
     "go19-40x256": dict(game="go-19", depth=40, channels=256, head="conv", batch=512, steps=400,
                         engines={"f16": 1, "f32": 1, "f32split16": 1},
@@ -53,7 +53,8 @@ OTHERS = [("ataxx-8x128", "f32"), ("go19-40x256", "f16"), ("chess-20x256", "f32s
 
 KERNEL_OF_PATH = {
     "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
-    "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_split16": "kz_tower_resident_split",
+    "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_f32+heads": "kz_tower_resident_f32",
+    "tower_resident_split16": "kz_tower_resident_split",
     "tower_resident_f16g": "kz_tower_resident_f16g", "board_conv_f16": "kz_board_conv_f16",
     "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32",
 }
@@ -228,7 +229,7 @@ class Workload:
         # host-pointer loop: on the fused path an engine's two slots own a stream each, so ONE executor thread keeps
         # both half-chip launches in flight; more launches than the chip holds at once (engines x slots x 128 workgroups
         # > 256 CUs) only queue, and on a cold start that queueing has been seen to stall a stream for ~8 ms
-        self.host_engines = self.engines[:1] if self.tower_path == "tower_resident_f16+heads" else self.engines
+        self.host_engines = self.engines[:1] if self.tower_path.endswith("+heads") else self.engines
 
     def step_resident(self, i):
         e = i % len(self.engines)
@@ -283,7 +284,7 @@ class Workload:
         hw, C = info.board_h * info.board_w, info.tower_channels
         tower = 2.0 * hw * 9 * C * (info.input_channels + 2 * info.tower_depth * C)  # per board, direct conv
         p = self.tower_path
-        if p == "tower_resident_f16+heads":
+        if p.endswith("+heads"):
             return info.flops_per_eval * B  # one launch = tower + heads for one batch
         if p.startswith("tower_resident"):
             return tower * B  # one launch = the whole tower for one batch

@@ -73,6 +73,7 @@ struct DeviceWeights {
 
     // resident tower
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
+    float *h32_small = nullptr;  // the fused f32 heads' small 1x1 convolutions (tower32_pack_small_weights)
     void *res32_w = nullptr;  // f32 resident launch (exact f32, or split f16 pairs): one packed weight stream
     void *res_w_stem = nullptr, *res_w_tower = nullptr;
     float *res_bias = nullptr;
@@ -222,14 +223,29 @@ struct DeviceWeights {
             if (upload(packed.data(), packed.size() * 2, &res32_w)) return 1;
             if (upload_f32(bias, &res_bias)) return 1;
         } else if (resident32) {
-            std::vector<float> packed(kz::tower32_weight_elems(m.c_in, C, m.depth));
+            // (the conv policy head's first 1x1 conv rides at the end of the stream whenever the launch can fuse the
+            // heads; a launch without heads never reads it)
+            const bool heads32 = kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves,
+                                                             m.policy_conv_channels, m.h, m.w, C, m.sh_conv.cout, m.sh_fc0.out);
+            const size_t tower_elems = kz::tower32_weight_elems(m.c_in, C, m.depth);
+            std::vector<float> packed(tower_elems + (heads32 ? kz::tower32_heads_weight_elems(C) : 0) +
+                                      kz::tower32_weight_pad_elems(C), 0.0f);
             const size_t stem_elems = (size_t)9 * ((m.c_in + 15) / 16) * 16 * C, layer_elems = (size_t)9 * C * C;
             kz::tower32_pack_weights(m.tower[0].w.data(), C, m.c_in, true, packed.data());
             for (int l = 0; l < 2 * m.depth; l++)
                 kz::tower32_pack_weights(m.tower[1 + l].w.data(), C, C, false, packed.data() + stem_elems + layer_elems * l);
-            std::vector<float> bias((size_t)(1 + 2 * m.depth) * C);
+            std::vector<float> bias((size_t)(1 + 2 * m.depth + (heads32 ? 1 : 0)) * C);
             for (int l = 0; l < 1 + 2 * m.depth; l++)
                 for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
+            if (heads32) {
+                kz::tower32_pack_head_weights(m.p_conv0.w.data(), C, packed.data() + tower_elems);
+                for (int o = 0; o < C; o++) bias[(size_t)(1 + 2 * m.depth) * C + o] = m.p_conv0.b[o];
+                std::vector<float> small(kz::tower32_small_weight_elems(C));
+                kz::tower32_pack_small_weights(m.sh_conv.w.data(), m.sh_conv.cout,
+                                               m.policy_extra_moves ? m.p_extra_conv.w.data() : nullptr, m.p_conv1.w.data(),
+                                               m.policy_conv_channels, C, small.data());
+                if (upload_f32(small, &h32_small)) return 1;
+            }
             if (upload(packed.data(), packed.size() * 4, &res32_w)) return 1;
             if (upload_f32(bias, &res_bias)) return 1;
         } else if (resident) {
@@ -392,6 +408,7 @@ struct kz_engine {
     }
     std::vector<void *> allocs, pinned;
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
+    bool fused32 = false;  // the exact-f32 resident launch with the conv policy head and the scalar head inside
     bool nb4 = false;        // resident chess tower with four boards per workgroup (KZ_TOWER_NB=4)
     void *xres = nullptr;    // its residual scratch
     std::string path;
@@ -563,12 +580,27 @@ struct kz_engine {
             t.post_scale = wts->post_scale; t.post_shift = wts->post_shift;
             t.y = (float *)act[0]; t.ldy = cp; t.batch = batch; t.h = m.h; t.w = m.w; t.channels = m.channels;
             t.depth = m.depth;
-            if (packed) {  // (only asked for by forward_packed on the split / f16g launches)
+            if (packed) {  // fused board encode
                 t.bits = (const uint8_t *)packed->bits;
                 t.bits_stride = packed->stride;
                 t.scalars_in = (const float *)packed->scalars;
                 t.n_scalar = m.n_scalar;
                 t.n_bool = m.n_bool;
+            }
+            if (fused32) {
+                kz::Tower32Args::Heads &hd = t.heads;
+                hd.on = true;
+                hd.hc = m.sh_conv.cout; hd.hs = m.sh_fc0.out;
+                hd.small_w = wts->h32_small; hd.sh_b0 = wts->sh_b0; hd.sh_w1t = wts->sh_w1t; hd.sh_b1 = wts->sh_b1;
+                hd.sh_w2 = wts->sh_w2; hd.sh_b2 = wts->sh_b2;
+                hd.pc = m.policy_conv_channels; hd.p_b1 = wts->p_b1;
+                hd.policy_len = m.policy_len; hd.zero_tail = m.policy_kind == kz::POLICY_ATAXX_CONV ? 1 : 0;
+                if (m.policy_kind == kz::POLICY_CONV && m.policy_extra_moves) {
+                    hd.extra = m.policy_extra_moves;
+                    hd.pe_bc = wts->pe_bc; hd.pe_wl = wts->pe_wl; hd.pe_bl = wts->pe_bl;
+                }
+                hd.scalars = d_scalars; hd.policy = d_policy;
+                hd.nonfinite_flag = nf_flag; hd.epoch = nf_epoch;
             }
             prof.begin(split16 ? "kz_tower_resident_split" : pairs16 ? "kz_tower_resident_f16g" : "kz_tower_resident_f32", stream);
             if (split16) kz::launch_tower_split(t, stream);
@@ -600,7 +632,7 @@ struct kz_engine {
     }
 
     int run_heads(int batch, float *d_scalars, float *d_policy) {
-        if (fused_heads) return 0;  // written by the tower launch
+        if (fused_heads || fused32) return 0;  // written by the tower launch
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         const void *x = act[tower_out];
@@ -676,7 +708,7 @@ struct kz_engine {
 
     int forward_packed(const void *d_bits, size_t stride, const void *d_sin, int batch, void *d_sout, void *d_pol) {
         const Model &m = *model;
-        if (resident || split16 || pairs16) {  // encode is fused into the tower launch
+        if (resident || resident32 || pairs16) {  // encode is fused into the tower launch
             const PackedIn in{d_bits, stride, d_sin};
             if (run_tower(batch, (float *)d_sout, (float *)d_pol, &in)) return 1;
             return run_heads(batch, (float *)d_sout, (float *)d_pol);
@@ -859,9 +891,13 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                  !(nopairs && nopairs[0] == '1') && e->cin_p == 32 &&
                  kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
     const bool board_conv = board_conv_ok && !e->pairs16;
+    e->fused32 = e->resident32 && !e->split16 && !(nofuse && nofuse[0] == '1') &&
+                 kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
+                                             m.channels, m.sh_conv.cout, m.sh_fc0.out);
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
               : e->split16   ? "tower_resident_split16"
+              : e->fused32   ? "tower_resident_f32+heads"
               : e->resident32 ? "tower_resident_f32"
               : e->pairs16   ? "tower_resident_f16g"
               : board_conv   ? "board_conv_f16"
@@ -889,7 +925,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 
     HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[0], hipStreamNonBlocking));
     e->stream = e->slot_stream[0];
-    if (e->fused_heads) {
+    if (e->fused_heads || e->fused32) {  // one launch per batch that touches nothing but its slot's buffers
         HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[1], hipStreamNonBlocking));
         for (int i = 2; i < KZ_ENGINE_SLOTS; i++) e->slot_stream[i] = e->slot_stream[i & 1];
         const char *nzc = getenv("KZ_NO_ZERO_COPY");
@@ -1303,7 +1339,7 @@ KZ_API int kz_engine_read_activation(kz_engine *e, const char *name, int batch, 
     if (!e || !name || !out_nchw) return fail("kz_engine_read_activation: null argument");
     // "tower.out": the tower output of the last evaluation, on every path that materialises it (all but the fused-heads
     // launch)
-    const bool tower_out = std::string(name) == "tower.out" && !e->fused_heads;
+    const bool tower_out = std::string(name) == "tower.out" && !e->fused_heads && !e->fused32;
     if (!e->keep && !tower_out)
         return fail("kz_engine_read_activation: engine keeps no activations (create it with KZ_FORCE_GENERIC=1 and "
                     "KZ_KEEP_ACTIVATIONS=1; \"tower.out\" is available on every path without fused heads)");

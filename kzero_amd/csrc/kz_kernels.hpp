@@ -152,10 +152,35 @@ struct Tower32Args {
     size_t bits_stride = 0;
     const float *scalars_in = nullptr;
     int n_scalar = 0, n_bool = 0;
+    // launch_tower32 only: the conv policy head (Conv1x1 C->C + ReLU in the weight stream as one more centre-tap layer,
+    // then Conv1x1 C->pc, post_act.py:75-110) and the scalar head (post_act.py:8-31) in the same launch — the tower
+    // output never leaves LDS and `y` is not written.  tower32_heads_supported says for which models.
+    struct Heads {
+        bool on = false;
+        int hc = 0, hs = 0;  // scalar head: 1x1 conv channels, hidden size
+        const float *small_w = nullptr;  // tower32_pack_small_weights: scalar-head conv (+ extra-move conv), policy conv
+        const float *sh_b0 = nullptr, *sh_w1t = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
+        int pc = 0;          // policy: output channels of the second 1x1 conv
+        const float *p_b1 = nullptr;
+        int policy_len = 0, zero_tail = 0;
+        int extra = 0;       // ConvPolicyHead's extra moves (post_act.py:86-96): Conv1x1 C->1 on the tower output, Linear hw->extra
+        const float *pe_bc = nullptr, *pe_wl = nullptr, *pe_bl = nullptr;
+        float *scalars = nullptr, *policy = nullptr;  // [batch][5], [batch][policy_len]
+        int *nonfinite_flag = nullptr;                // range check, see ScalarHeadArgs
+        int epoch = 0;
+    } heads;
 };
 bool tower32_supported(int dtype, int h, int w, int channels, int depth);
+// conv / ataxx_conv policy head + a scalar head whose activations fit the launch's spare LDS
+bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs);
+size_t tower32_small_weight_elems(int channels);
+void tower32_pack_small_weights(const float *sh_w0, int hc, const float *pe_wc /* or null */, const float *p_w1, int pc,
+                                int channels, float *dst);
+size_t tower32_heads_weight_elems(int channels);           // the C->C 1x1 conv as channels/16 more steps
+void tower32_pack_head_weights(const float *oi, int channels, float *dst);  // [C][C] 1x1 conv -> fragment order
 int tower32_boards_per_workgroup(int h, int w, int channels);
 size_t tower32_weight_elems(int c_in, int channels, int depth);
+size_t tower32_weight_pad_elems(int channels);  // zeros the stream must end with (the launch's weight ring reads ahead)
 void tower32_pack_weights(const float *oihw, int cout, int cin, bool stem, float *dst);
 void launch_tower32(const Tower32Args &a, hipStream_t stream);
 

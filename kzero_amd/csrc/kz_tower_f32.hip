@@ -16,8 +16,18 @@
 //               a four-step ring that runs on across layer boundaries; a step is 4 * (C/64) * NT MFMAs of 32 cycles
 //   epilogue  = bias-initialised accumulators (the next layer's bias is fetched a layer ahead); [ReLU]; [+ residual, in place in the out image]; [final BN]; 16-byte
 //               stores (4 consecutive output channels of a pixel row per lane)
+//   encode    = packed boards (bit planes + scalar planes) are decoded while the stem input is staged
+//   heads     = (HEADS launches: conv / ataxx_conv policy head + scalar head) the policy head's Conv1x1 C->C + ReLU is
+//               one more layer of the centre tap only, at the end of the same weight stream; the remaining head layers
+//               are a few hundred FMAs per thread on the two images in LDS — the tower output never reaches HBM and a
+//               batch is ONE launch
 //
-// Arithmetic follows python/lib/model/post_act.py:201-239 with Conv+BN folded on the host (kz_model.cpp).
+// Arithmetic follows python/lib/model/post_act.py:201-239 (tower), :8-31 (scalar head), :75-110 (conv policy heads) with
+// Conv+BN folded on the host (kz_model.cpp).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "kz_kernels.hpp"
 
 namespace kz {
@@ -25,6 +35,22 @@ namespace kz {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// Diagnostic build only (-DKZ_T32_STAMPS): s_memtime stamps at the phase boundaries of every wave, dumped by the
+// launcher to $KZ_T32_STAMP_FILE after the 20th launch (tools/tower32_stamps.py reads them).  No stamp executes in the
+// real kernel.
+#ifdef KZ_T32_STAMPS
+#define KZ_STAMP(slot)                                                                         \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (lane == 0 && (slot) < 64) a.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + (slot)] = t_; \
+    } while (0)
+#else
+#define KZ_STAMP(slot) do { } while (0)
+#endif
 
 struct TowerF32Dev {
     const float *x0;    // encoded input [batch*hw][ldx0]
@@ -34,6 +60,18 @@ struct TowerF32Dev {
     float *y;           // tower output [batch*hw][ldy]
     int ldx0, ldy, batch, h, w_, hw, depth, stem_groups, nb;
     unsigned inv_w, inv_hw;  // ceil(65536 / w), ceil(65536 / hw): exact quotients for values < 512
+    // fused board encode (bits != nullptr: x0 is not read)
+    const uint8_t *bits;
+    size_t bits_stride;
+    const float *scalars_in;
+    int n_scalar, n_bool;
+    // fused heads (HEADS launches)
+    int hc, hs, pc, policy_len, zero_tail, extra, epoch;
+    const float *sh_b0, *sh_w1t, *sh_b1, *sh_w2, *sh_b2, *p_b1, *pe_bc, *pe_wl, *pe_bl;
+    const f32x4 *small_w;  // tower32_pack_small_weights: [over x: scalar-head conv rows, extra-move conv row][over hidden: policy conv]
+    float *scalars, *policy;
+    int *nonfinite_flag;
+    unsigned long long *stamps;  // (diagnostic build)
 };
 
 template <int C>
@@ -41,7 +79,7 @@ __device__ __forceinline__ int plane_of(int kq) {  // byte offset of lane group 
     return C == 256 ? 256 * kq : 256 * (kq & 1) + 128 * (kq >> 1);
 }
 
-template <int C, int NT>
+template <int C, int NT, bool HEADS>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
     constexpr int OT = C / 64;           // 16-channel output tiles per wave
     constexpr int G = C / 16;            // steps per tap in a tower layer
@@ -57,6 +95,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
     const int board0 = blockIdx.x * a.nb;
     const int boards = min(a.nb, a.batch - board0);
     const int rows_valid = boards * a.hw;
+    KZ_STAMP(0);
 
     // zero rows; padding rows of image 0 (their outputs are never stored, but keep them finite)
     for (int i = tid; i < 16 * RS / 16; i += 256) *reinterpret_cast<f32x4 *>(lds + ZERO + i * 16) = f32x4{0, 0, 0, 0};
@@ -66,7 +105,25 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
         for (int i = tid; i < ROWS * pieces; i += 256) {
             const int r = i / pieces, p = i - r * pieces;
             f32x4 v = f32x4{0, 0, 0, 0};
-            if (r < rows_valid) v = *reinterpret_cast<const f32x4 *>(a.x0 + ((size_t)board0 * a.hw + r) * a.ldx0 + p * 4);
+            if (r < rows_valid) {
+                if (a.bits) {  // F0 (rust/kz-core/src/mapping/bit_buffer.rs + cuda_network.rs:110-123): scalar planes, then bit planes
+                    const int bb = (int)(((unsigned)r * a.inv_hw) >> 16), q = r - bb * a.hw;
+                    const uint8_t *bits = a.bits + (size_t)(board0 + bb) * a.bits_stride;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int c = p * 4 + j;
+                        float f = 0.0f;
+                        if (c < a.n_scalar) f = a.scalars_in[(size_t)(board0 + bb) * a.n_scalar + c];
+                        else if (c < a.n_scalar + a.n_bool) {
+                            const unsigned bit = (unsigned)(c - a.n_scalar) * a.hw + q;
+                            f = (float)((bits[bit >> 3] >> (bit & 7)) & 1);
+                        }
+                        v[j] = f;
+                    }
+                } else {
+                    v = *reinterpret_cast<const f32x4 *>(a.x0 + ((size_t)board0 * a.hw + r) * a.ldx0 + p * 4);
+                }
+            }
             *reinterpret_cast<f32x4 *>(lds + IMG0 + r * RS + p * 16) = v;
         }
     }
@@ -86,6 +143,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
         for (int tap = 0; tap < 9; tap++) okmask[tap] |= (valid & ym[tap / 3] & xm[tap % 3]) << nt;
     }
     __syncthreads();
+    KZ_STAMP(1);
 
     const f32x4 *wl = a.w + wave * OT * 64 + lane;  // this lane's fragment of step 0
     int in = IMG0, out = IMG1;
@@ -161,12 +219,12 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
                 mfma_step(wf, bf);
             }
         }
-        wl += (size_t)9 * a.stem_groups * STEP;
         epilogue(false, false, a.depth == 0);
         __syncthreads();
         in = IMG1;
         out = IMG0;
     }
+    KZ_STAMP(2);
 
     // ---- 2*depth tower convolutions: 9 G steps each.  Weights run FOUR steps ahead through a register ring (a step is
     // 4*OT*NT MFMAs of 32 cycles = 0.75 us at A1: two steps of cover were less than an L2 round trip under load), the
@@ -175,56 +233,70 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
     // MFMAs.  Round 2, A1 at a full chip: MFMA-busy 83.7 % -> see DESIGN.md §5.2a. ----
     const int koff = plane_of<C>(kq);
     constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
-    constexpr int S = 9 * G;
-    static_assert(S % 4 == 0, "the ring stage of a step is a compile-time constant");
-    // the ring runs across layer boundaries (the stream is contiguous): step index ts counts from the first tower layer
-    const int total_steps = 2 * a.depth * S;
-    int ts = 0;
-    f32x4 wring[4][OT];
-    auto issue_w = [&](f32x4(&wf)[OT], int t) {  // t: step of the whole tower, clamped at the end of the stream
-        const f32x4 *p = wl + (size_t)(t < total_steps ? t : total_steps - 1) * STEP;
+    static_assert(G % 4 == 0 && G % 2 == 0, "the ring stage and the fragment buffer of a step are compile-time constants");
+    // The ring runs across layer boundaries (the stream is contiguous, and the host pads it with four steps so the ring
+    // may run past the end).  HEADS: the policy head's Conv1x1 C->C + ReLU rides as one more layer of the centre tap
+    // only (G steps).
+    // A tap (G steps) is unrolled: the ring stage, the fragment buffer and the channel offset of every read are
+    // compile-time, the weight address is a uniform base advanced once per step plus a constant lane offset — every
+    // instruction that is not an MFMA costs ~6 cycles of the (single wave's) matrix pipe, measured with in-kernel
+    // stamps: 27 of them per step were 8 % of the loop.
+    const int n_layers = 2 * a.depth + (HEADS ? 1 : 0);
+#ifndef KZ_T32_RING
+#define KZ_T32_RING 4
+#endif
+    constexpr int RING = KZ_T32_RING;
+    static_assert(G % RING == 0, "the ring stage of a step is a compile-time constant");
+    f32x4 wring[RING][OT];
+    const int wlane = wave * OT * 64 + lane;
+    const f32x4 *wnext = a.w + (size_t)9 * a.stem_groups * STEP;  // uniform
+    auto issue_w = [&](f32x4(&wf)[OT]) {
 #pragma unroll
-        for (int ot = 0; ot < OT; ot++) wf[ot] = p[ot * 64];
+        for (int ot = 0; ot < OT; ot++) wf[ot] = wnext[wlane + ot * 64];
+        wnext += STEP;
     };
 #pragma unroll
-    for (int u = 0; u < 4; u++) issue_w(wring[u], u);
+    for (int u = 0; u < RING; u++) issue_w(wring[u]);
     // the bias of the next layer is fetched while this one computes
     f32x4 bias_next[OT];
     auto fetch_bias = [&](int layer) {
-        const int l = layer <= 2 * a.depth ? layer : 2 * a.depth;
+        const int l = layer <= n_layers ? layer : n_layers;
 #pragma unroll
         for (int ot = 0; ot < OT; ot++)
             bias_next[ot] = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)l * C + (wave * OT + ot) * 16 + kq * 4);
     };
     fetch_bias(1);
-    for (int layer = 1; layer <= 2 * a.depth; layer++) {
+    for (int layer = 1; layer <= n_layers; layer++) {
+        const bool head = HEADS && layer > 2 * a.depth;
+        const int tap_first = head ? 4 : 0, tap_last = head ? 4 : 8;
         f32x4 bA[NT], bB[NT];
-        auto issue_b = [&](f32x4(&bf)[NT], int t) {
-            const int tap = t / G, g = t % G;
-            if (g == 0) tap_rows(tap, koff);
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) bf[nt] = *reinterpret_cast<const f32x4 *>(lds + T[nt] + g * 16);
-        };
 #pragma unroll
         for (int ot = 0; ot < OT; ot++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) acc[ot][nt] = bias_next[ot];
         fetch_bias(layer + 1);
-        issue_b(bA, 0);
-#pragma unroll 1
-        for (int t = 0; t < S; t += 4) {
+        tap_rows(tap_first, koff);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int tn = t + u + 1 < S ? t + u + 1 : S - 1, tw = ts + 4;
-                if (u & 1) {
-                    issue_b(bA, tn);
-                    mfma_step(wring[u], bB);
-                } else {
-                    issue_b(bB, tn);
-                    mfma_step(wring[u], bA);
+        for (int nt = 0; nt < NT; nt++) bA[nt] = *reinterpret_cast<const f32x4 *>(lds + T[nt]);
+#pragma unroll 1
+        for (int tap = tap_first; tap <= tap_last; tap++) {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                f32x4(&cur)[NT] = (g & 1) ? bB : bA;
+                f32x4(&nxt)[NT] = (g & 1) ? bA : bB;
+                // this step's fragments were requested early in the previous step: ONE wait here instead of one in front
+                // of every tile's first MFMA (lgkmcnt(0), vmcnt/expcnt untouched)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                if (g + 1 < G) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) nxt[nt] = *reinterpret_cast<const f32x4 *>(lds + T[nt] + (g + 1) * 16);
+                } else {  // first step of the next tap (after the last tap: a read nobody uses)
+                    tap_rows(tap < tap_last ? tap + 1 : tap_last, koff);
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) nxt[nt] = *reinterpret_cast<const f32x4 *>(lds + T[nt]);
                 }
-                issue_w(wring[u], tw);  // (this stage's fragments have been issued to the MFMAs)
-                ts++;
+                mfma_step(wring[g % RING], cur);
+                issue_w(wring[g % RING]);  // (this stage's fragments have been issued to the MFMAs)
 #pragma unroll
                 for (int i = 0; i < NT; i++) {
                     __builtin_amdgcn_sched_group_barrier(SG_MFMA, 4, 0);
@@ -239,20 +311,170 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        KZ_STAMP(3 * layer);
         const bool second = (layer & 1) == 0;  // the block's second conv: residual add, and the final BN on the last
         epilogue(true, second, second && layer == 2 * a.depth);
+        KZ_STAMP(3 * layer + 1);
         __syncthreads();
+        KZ_STAMP(3 * layer + 2);
         const int tmp = in;
         in = out;
         out = tmp;
     }
 
-    // ---- the tower's output (the last `out`, now `in`) -> global, 16 bytes per lane, whole rows ----
-    for (int i = tid; i < rows_valid * (C / 4); i += 256) {
-        const int r = i / (C / 4), p = i - r * (C / 4);
-        *reinterpret_cast<f32x4 *>(a.y + ((size_t)board0 * a.hw + r) * a.ldy + p * 4) =
-            *reinterpret_cast<const f32x4 *>(lds + in + r * RS + p * 16);
+    if constexpr (!HEADS) {
+        // ---- the tower's output (the last `out`, now `in`) -> global, 16 bytes per lane, whole rows ----
+        for (int i = tid; i < rows_valid * (C / 4); i += 256) {
+            const int r = i / (C / 4), p = i - r * (C / 4);
+            *reinterpret_cast<f32x4 *>(a.y + ((size_t)board0 * a.hw + r) * a.ldy + p * 4) =
+                *reinterpret_cast<const f32x4 *>(lds + in + r * RS + p * 16);
+        }
+    } else {
+        // ---- heads on the images in LDS: `out` holds the tower output, `in` the policy head's hidden layer ----
+        const int xin = out, hin = in;
+        // A 1x1 convolution with at most 32 output channels (two 16-channel tiles, zero-padded by the host) on the MFMAs:
+        // the row tiles are split over the waves (wave w: tiles w and w + 4), every wave streams the whole (small)
+        // weight fragment set: 16 * C/16 MFMAs per wave.  emit(oc, row, value) for this lane's 2 x 2 x 4 results.
+        auto small_conv = [&](int img, const f32x4 *wfrag /* [G][2][64] */, auto emit) {
+            f32x4 sa[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) sa[mt][t] = f32x4{0, 0, 0, 0};
+            const bool two = wave + 4 < NT;
+            const int base0 = img + (wave * 16 + fr) * RS + koff;
+            const int base1 = two ? base0 + 64 * RS : base0;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const f32x4 w0 = wfrag[(g * 2 + 0) * 64 + lane], w1 = wfrag[(g * 2 + 1) * 64 + lane];
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(lds + base0 + g * 16);
+                const f32x4 b1 = *reinterpret_cast<const f32x4 *>(lds + base1 + g * 16);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    sa[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], b0[q], sa[0][0], 0, 0, 0);
+                    sa[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], b0[q], sa[1][0], 0, 0, 0);
+                    sa[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], b1[q], sa[0][1], 0, 0, 0);
+                    sa[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], b1[q], sa[1][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int row = (wave + 4 * t) * 16 + fr;
+                if ((t == 0 || two) && row < rows_valid) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) emit(mt, q, row, sa[mt][t][q]);
+                }
+            }
+        };
+        // the zero rows are dead by now: scratch for the scalar head
+        const int n_in = a.hc * a.hw, nseg = 256 / a.hs;
+        float *sact = reinterpret_cast<float *>(lds + ZERO);  // [nb][hc*hw] channel-major like nn.Flatten on NCHW (post_act.py:16)
+        float *sext = sact + a.nb * n_in;                     // [nb][hw] extra-move plane
+        float *shid = sext + a.nb * a.hw;                     // [nb][hs]
+        float *sw2 = shid + a.nb * a.hs;                      // [5][hs]
+        float *sred = sw2 + 5 * a.hs;                         // [nseg][nb*hs]
+        // Everything the tail reads from global memory is requested up front — a dependent L2 round trip per use costs
+        // ~1 us with one wave per SIMD, and there were forty of them in a row: the biases of the two small convolutions
+        // for this lane's output channels, the first 32 of this thread's Linear weights, the hidden layer's bias
+        float sb[2][4], pb[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int oc = mt * 16 + kq * 4 + q;
+                sb[mt][q] = oc < a.hc ? a.sh_b0[oc] : (oc == a.hc && a.extra) ? a.pe_bc[0] : 0.0f;
+                pb[mt][q] = oc < a.pc ? a.p_b1[oc] : 0.0f;
+            }
+        const int fseg = tid / a.hs, fj = tid - fseg * a.hs;
+        constexpr int WPRE = 32;
+        float wpre[WPRE];
+#pragma unroll
+        for (int k = 0; k < WPRE; k++) {
+            const int i = fseg + k * nseg;
+            wpre[k] = (fseg < nseg && i < n_in) ? a.sh_w1t[(size_t)i * a.hs + fj] : 0.0f;
+        }
+        const float b1v = tid < a.nb * a.hs ? a.sh_b1[tid % a.hs] : 0.0f;
+        const float b2v = tid < boards * 5 ? a.sh_b2[tid % 5] : 0.0f;
+        for (int i = tid; i < 5 * a.hs; i += 256) sw2[i] = a.sh_w2[i];
+        // scalar head Conv1x1 C->hc + ReLU and the extra moves' Conv1x1 C->1 (post_act.py:8-31, :86-96): one small conv over x
+        bool bad = false;  // a non-finite sum = a non-finite value somewhere in this board's tower output
+        small_conv(xin, a.small_w, [&](int mt, int q, int row, float v) {
+            const int oc = mt * 16 + kq * 4 + q;
+            const int bb = (int)(((unsigned)row * a.inv_hw) >> 16), p = row - bb * a.hw;
+            if (oc < a.hc) {
+                bad |= !(fabsf(v) <= 3.0e38f);
+                sact[bb * n_in + oc * a.hw + p] = fmaxf(v + sb[mt][q], 0.0f);
+            } else if (oc == a.hc && a.extra) {
+                sext[row] = v + sb[mt][q];
+            }
+        });
+        if (bad && a.nonfinite_flag) *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may live in pinned host memory)
+        // policy (post_act.py:75-110): Conv1x1 C->pc on the hidden layer, channel-major flatten
+        small_conv(hin, a.small_w + G * 2 * 64, [&](int mt, int q, int row, float v) {
+            const int oc = mt * 16 + kq * 4 + q;
+            const int bb = (int)(((unsigned)row * a.inv_hw) >> 16), p = row - bb * a.hw;
+            if (oc < a.pc) a.policy[(size_t)(board0 + bb) * a.policy_len + oc * a.hw + p] = v + pb[mt][q];
+        });
+        // AtaxxConvPolicyHead appends a constant-zero pass logit (post_act.py:106-110)
+        if (a.zero_tail && tid < boards) a.policy[(size_t)(board0 + tid) * a.policy_len + a.pc * a.hw] = 0.0f;
+        KZ_STAMP(60);
+        __syncthreads();
+        // Linear(n_in -> hs): thread (segment, output) walks every nseg-th input of the transposed matrix (the hs weights of
+        // one input are contiguous) for all boards of the workgroup at once; the segments meet through LDS
+        {
+            const int seg = fseg, j = fj;
+            float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (seg < nseg) {
+#pragma unroll
+                for (int k = 0; k < WPRE; k++) {
+                    const int i = seg + k * nseg;
+                    if (i < n_in) {
+#pragma unroll
+                        for (int bb = 0; bb < 4; bb++)
+                            if (bb < a.nb) part[bb] += wpre[k] * sact[bb * n_in + i];
+                    }
+                }
+#pragma unroll 8
+                for (int i = seg + WPRE * nseg; i < n_in; i += nseg) {
+                    const float w = a.sh_w1t[(size_t)i * a.hs + j];
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++)
+                        if (bb < a.nb) part[bb] += w * sact[bb * n_in + i];
+                }
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+                    if (bb < a.nb) sred[(seg * a.nb + bb) * a.hs + j] = part[bb];
+            }
+        }
+        if (a.extra) {  // Linear(hw -> extra) behind the policy planes
+            for (int o = tid >> 2; o < boards * a.extra; o += 64) {
+                const int bb = o / a.extra, j = o - bb * a.extra, seg = tid & 3;
+                float s = 0.0f;
+#pragma unroll 8
+                for (int p = seg; p < a.hw; p += 4) s += a.pe_wl[(size_t)j * a.hw + p] * sext[bb * a.hw + p];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (seg == 0) a.policy[(size_t)(board0 + bb) * a.policy_len + a.pc * a.hw + j] = s + a.pe_bl[j];
+            }
+        }
+        __syncthreads();
+        if (tid < a.nb * a.hs) {
+            float s = b1v;
+            for (int seg = 0; seg < nseg; seg++) s += sred[seg * a.nb * a.hs + tid];
+            shid[tid] = fmaxf(s, 0.0f);
+        }
+        __syncthreads();
+        if (tid < boards * 5) {
+            const int bb = tid / 5, j = tid - bb * 5;
+            float s = b2v;
+            for (int i = 0; i < a.hs; i++) s += sw2[j * a.hs + i] * shid[bb * a.hs + i];
+            a.scalars[(size_t)(board0 + bb) * 5 + j] = s;
+        }
+        KZ_STAMP(61);
     }
+    KZ_STAMP(62);
 }
 
 int tiles_for(int hw, int channels) {
@@ -261,18 +483,44 @@ int tiles_for(int hw, int channels) {
     return 0;
 }
 
-template <int C, int NT>
-void launch(const TowerF32Dev &d, int grid, hipStream_t stream) {
+template <int C, int NT, bool HEADS>
+void launch1(const TowerF32Dev &d, int grid, hipStream_t stream) {
     constexpr int LDS_BYTES = (16 + 2 * NT * 16) * (C * 4 + 16);
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done_mask >> (dev & 63)) & 1)) {
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident_f32<C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident_f32<C, NT, HEADS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         done_mask |= 1ull << (dev & 63);
     }
-    kz_tower_resident_f32<C, NT><<<grid, 256, LDS_BYTES, stream>>>(d);
+#ifdef KZ_T32_STAMPS
+    static unsigned long long *stamp_buf = nullptr;
+    static int launches = 0;
+    const size_t stamp_bytes = (size_t)grid * 4 * 64 * sizeof(unsigned long long);
+    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, (size_t)4096 * 4 * 64 * 8);
+    TowerF32Dev ds = d;
+    ds.stamps = stamp_buf;
+    if (launches == 20) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, stream);
+    kz_tower_resident_f32<C, NT, HEADS><<<grid, 256, LDS_BYTES, stream>>>(ds);
+    if (launches++ == 20 && getenv("KZ_T32_STAMP_FILE")) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> host(stamp_bytes / 8);
+        (void)hipMemcpy(host.data(), stamp_buf, stamp_bytes, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("KZ_T32_STAMP_FILE"), "wb")) {
+            fwrite(host.data(), 1, stamp_bytes, f);
+            fclose(f);
+        }
+    }
+#else
+    kz_tower_resident_f32<C, NT, HEADS><<<grid, 256, LDS_BYTES, stream>>>(d);
+#endif
+}
+
+template <int C, int NT>
+void launch(const TowerF32Dev &d, bool heads, int grid, hipStream_t stream) {
+    if (heads) launch1<C, NT, true>(d, grid, stream);
+    else launch1<C, NT, false>(d, grid, stream);
 }
 
 }  // namespace
@@ -281,10 +529,70 @@ bool tower32_supported(int dtype, int h, int w, int channels, int depth) {
     return dtype == 0 && depth >= 1 && h >= 2 && w >= 2 && w <= 32 && tiles_for(h * w, channels) != 0;
 }
 
+bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs) {
+    const int nt = tiles_for(h * w, channels), hw = h * w;
+    if (!nt || (policy_kind != 0 && policy_kind != 1) || extra_moves < 0 || hc < 1 || hs < 1 || hs > 256) return false;
+    if (policy_kind == 0 && extra_moves) return false;
+    if (pc < 1 || pc > 32 || hc + (extra_moves ? 1 : 0) > 32) return false;  // two 16-channel tiles per small conv
+    const int nb = nt * 16 / hw, nseg = 256 / hs;
+    if (nb > 4) return false;
+    // the zero rows' LDS: conv activations, extra-move plane, hidden, last Linear's weights, partial sums
+    const size_t floats = (size_t)nb * hc * hw + (size_t)nb * hw + (size_t)nb * hs + (size_t)5 * hs + (size_t)nseg * nb * hs;
+    return floats * 4 <= (size_t)16 * (channels * 4 + 16);
+}
+
+size_t tower32_heads_weight_elems(int channels) { return (size_t)channels * channels; }
+
+// [C][C] 1x1 conv -> the fragment order of one tap of a tower layer
+void tower32_pack_head_weights(const float *oi, int channels, float *dst) {
+    const int groups = channels / 16, ot_n = channels / 64;
+    size_t o = 0;
+    for (int g = 0; g < groups; g++)
+        for (int wave = 0; wave < 4; wave++)
+            for (int ot = 0; ot < ot_n; ot++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int s = 0; s < 4; s++) {
+                        const int fr = lane & 15, kq = lane >> 4;
+                        const int oc = 16 * (wave * ot_n + ot) + fr;
+                        const int plane = channels == 256 ? 256 * kq : 256 * (kq & 1) + 128 * (kq >> 1);
+                        dst[o++] = oi[(size_t)oc * channels + plane / 4 + 4 * g + s];
+                    }
+}
+
+size_t tower32_small_weight_elems(int channels) { return (size_t)2 * (channels / 16) * 2 * 64 * 4; }
+
+// The two small 1x1 convolutions of the heads, each as [g][tile 2][lane 64][4] (32 output rows, zero-padded): first the
+// one over the tower output (rows: the scalar head's hc conv filters, then the extra moves' single filter if any), then
+// the policy conv over the hidden layer (pc rows).  Fragment element order of a tower layer's tap.
+void tower32_pack_small_weights(const float *sh_w0, int hc, const float *pe_wc, const float *p_w1, int pc, int channels,
+                                float *dst) {
+    const int groups = channels / 16;
+    size_t o = 0;
+    for (int conv = 0; conv < 2; conv++)
+        for (int g = 0; g < groups; g++)
+            for (int mt = 0; mt < 2; mt++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int s = 0; s < 4; s++) {
+                        const int fr = lane & 15, kq = lane >> 4, oc = 16 * mt + fr;
+                        const int plane = channels == 256 ? 256 * kq : 256 * (kq & 1) + 128 * (kq >> 1);
+                        const int ch = plane / 4 + 4 * g + s;
+                        float v = 0.0f;
+                        if (conv == 0) {
+                            if (oc < hc) v = sh_w0[(size_t)oc * channels + ch];
+                            else if (oc == hc && pe_wc) v = pe_wc[ch];
+                        } else if (oc < pc) {
+                            v = p_w1[(size_t)oc * channels + ch];
+                        }
+                        dst[o++] = v;
+                    }
+}
+
 int tower32_boards_per_workgroup(int h, int w, int channels) {
     const int nt = tiles_for(h * w, channels);
     return nt ? nt * 16 / (h * w) : 0;
 }
+
+size_t tower32_weight_pad_elems(int channels) { return (size_t)8 * channels * 16; }  // the ring's depth past the end of the stream
 
 size_t tower32_weight_elems(int c_in, int channels, int depth) {
     const int stem_groups = (c_in + 15) / 16;
@@ -335,11 +643,24 @@ void launch_tower32(const Tower32Args &t, hipStream_t stream) {
     d.nb = nt * 16 / d.hw;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
+    d.bits = t.bits;
+    d.bits_stride = t.bits_stride;
+    d.scalars_in = t.scalars_in;
+    d.n_scalar = t.n_scalar;
+    d.n_bool = t.n_bool;
+    const Tower32Args::Heads &hd = t.heads;
+    d.hc = hd.hc; d.hs = hd.hs; d.pc = hd.pc; d.policy_len = hd.policy_len; d.zero_tail = hd.zero_tail; d.epoch = hd.epoch;
+    d.sh_b0 = hd.sh_b0; d.sh_w1t = hd.sh_w1t; d.sh_b1 = hd.sh_b1; d.sh_w2 = hd.sh_w2; d.sh_b2 = hd.sh_b2;
+    d.p_b1 = hd.p_b1;
+    d.extra = hd.extra; d.pe_bc = hd.pe_bc; d.pe_wl = hd.pe_wl; d.pe_bl = hd.pe_bl;
+    d.small_w = static_cast<const f32x4 *>(static_cast<const void *>(hd.small_w));
+    d.stamps = nullptr;
+    d.scalars = hd.scalars; d.policy = hd.policy; d.nonfinite_flag = hd.nonfinite_flag;
     const int grid = (t.batch + d.nb - 1) / d.nb;
-    if (t.channels == 256) launch<256, 4>(d, grid, stream);
-    else if (nt == 7) launch<128, 7>(d, grid, stream);
-    else if (nt == 6) launch<128, 6>(d, grid, stream);
-    else launch<128, 4>(d, grid, stream);
+    if (t.channels == 256) launch<256, 4>(d, hd.on, grid, stream);
+    else if (nt == 7) launch<128, 7>(d, hd.on, grid, stream);
+    else if (nt == 6) launch<128, 6>(d, hd.on, grid, stream);
+    else launch<128, 4>(d, hd.on, grid, stream);
 }
 
 }  // namespace kz

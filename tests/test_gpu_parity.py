@@ -606,7 +606,14 @@ def test_resident_f32_tower_vs_oracle(dev, game, depth, channels, head, batches)
     net = O.OracleNet(blob)
     model = capi.Model(blob=blob)
     eng = capi.Engine(model, dev, 16, capi.KZ_DTYPE_F32)
-    assert eng.tower_path == "tower_resident_f32"
+    # conv policy heads (and the scalar head) ride in the same launch; the attention head keeps its own kernels
+    assert eng.tower_path == ("tower_resident_f32+heads" if head in ("ataxx_conv", "conv") else "tower_resident_f32")
+    os.environ["KZ_NO_FUSED_HEADS"] = "1"
+    try:
+        unfused = capi.Engine(model, dev, 16, capi.KZ_DTYPE_F32)
+    finally:
+        del os.environ["KZ_NO_FUSED_HEADS"]
+    assert unfused.tower_path == "tower_resident_f32"
     os.environ["KZ_FORCE_GENERIC"] = "1"
     try:
         gen = capi.Engine(model, dev, 16, capi.KZ_DTYPE_F32)
@@ -625,6 +632,15 @@ def test_resident_f32_tower_vs_oracle(dev, game, depth, channels, head, batches)
         sg, pg = gen.eval_packed(bits, scalars_in)
         assert_f32(sg, s, f"generic vs resident scalars b={batch}")
         assert_f32(pg, p, f"generic vs resident policy b={batch}")
+        su, pu = unfused.eval_packed(bits, scalars_in)
+        assert_f32(su, s, f"separate head launches vs one launch, scalars b={batch}")
+        assert_f32(pu, p, f"separate head launches vs one launch, policy b={batch}")
+        # the async pair (on the one-launch path: zero-copy staging, slots alternating over two streams)
+        for slot in range(capi.KZ_ENGINE_SLOTS):
+            eng.submit_packed(slot, bits, scalars_in)
+        for slot in range(capi.KZ_ENGINE_SLOTS):
+            sa, pa = eng.wait(slot, batch)
+            assert np.array_equal(sa, s) and np.array_equal(pa, p), f"slot {slot} b={batch}"
 
 
 @pytest.mark.parametrize("game,depth,channels,head,batches", [
@@ -650,7 +666,8 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     eng = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32_SPLIT16)
     assert eng.tower_path == "tower_resident_split16"
     exact = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32)
-    assert exact.tower_path == ("tower_resident_f32" if channels >= 128 else "conv_igemm_f32")
+    assert exact.tower_path == ("conv_igemm_f32" if channels < 128 else
+                                "tower_resident_f32+heads" if head in ("ataxx_conv", "conv") else "tower_resident_f32")
     for batch in batches:
         bits, scalars_in = synth.random_boards(game, batch, seed=82 + batch)
         dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
