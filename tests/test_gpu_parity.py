@@ -643,6 +643,51 @@ def test_resident_f32_tower_vs_oracle(dev, game, depth, channels, head, batches)
             assert np.array_equal(sa, s) and np.array_equal(pa, p), f"slot {slot} b={batch}"
 
 
+def test_one_launch_f32_network_decode_and_range_check(dev):
+    """The exact-f32 launch with the heads inside (tower_resident_f32+heads, BASELINE configs[1]'s network): the
+    device-side decode_output entry points (rust/kz-core/src/network/common.rs:16-100) against the oracle, and the range
+    check — a non-finite input plane reaches every output, which must come back as an error on the call that returns
+    the batch, on the synchronous, the asynchronous and the device-resident entry points; the engine stays usable."""
+    game = "ataxx-7"
+    blob = synth.random_model(game, 8, 128, "ataxx_conv", seed=91)
+    net = O.OracleNet(blob)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 64, capi.KZ_DTYPE_F32)
+    assert eng.tower_path == "tower_resident_f32+heads"
+    bits, scalars_in = synth.random_boards(game, 37, seed=92)  # 19 workgroups, the last one with one board
+    s_ref, p_ref = net.forward(O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w),
+                               threads=os.cpu_count() or 1)
+    rng = np.random.default_rng(93)
+    moves = [rng.permutation(net.policy_len)[:int(n)].astype(np.int32) for n in rng.integers(0, 60, size=37)]
+    v_ref, probs_ref = O.decode_output(s_ref, p_ref, moves)
+    v, probs = eng.eval_packed_decoded(bits, scalars_in, moves)
+    np.testing.assert_allclose(v, v_ref, rtol=1e-4, atol=1e-5)
+    for a, b in zip(probs, probs_ref):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
+    offs = [eng.submit_packed_decoded(slot, bits, scalars_in, moves) for slot in range(capi.KZ_ENGINE_SLOTS)]
+    for slot, off in enumerate(offs):
+        v2, probs2 = eng.wait_decoded(slot, off)
+        assert np.array_equal(v2, v) and all(np.array_equal(a, b) for a, b in zip(probs2, probs))
+    s_ok, p_ok = eng.eval_packed(bits, scalars_in)
+    assert_f32(s_ok, s_ref, "scalars")
+    assert_f32(p_ok, p_ref, "policy")
+    if net.n_scalar == 0:
+        return
+    bad = scalars_in.copy()
+    bad[5, 0] = np.inf  # one board of the batch
+    with pytest.raises(capi.KzError, match="non-finite activation"):
+        eng.eval_packed(bits, bad)
+    with pytest.raises(capi.KzError, match="non-finite activation"):
+        eng.wait_view(0, eng.submit_packed(0, bits, bad))
+    d_s, d_p = capi.DeviceBuffer(dev, 37 * 5 * 4), capi.DeviceBuffer(dev, 37 * net.policy_len * 4)
+    eng.enqueue_packed_device(capi.DeviceBuffer.from_host(dev, bits), bits.shape[1],
+                              capi.DeviceBuffer.from_host(dev, bad), 37, d_s, d_p)
+    with pytest.raises(capi.KzError, match="non-finite activation"):
+        eng.synchronize()
+    eng.synchronize()
+    s_again, p_again = eng.eval_packed(bits, scalars_in)
+    assert np.array_equal(s_again, s_ok) and np.array_equal(p_again, p_ok)
+
+
 @pytest.mark.parametrize("game,depth,channels,head,batches", [
     ("chess", 1, 256, "attention", (1, 3)),           # one board per workgroup
     ("chess", 3, 256, "attention", (5, 17)),
