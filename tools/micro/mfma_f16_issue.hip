@@ -86,17 +86,26 @@ template <int V, int NVM, int NDS>
 void run(const char *name, int wgs_per_cu, const h16x8 *w, unsigned long long *out, float *sink) {
     const int iters = 3000, lds_bytes = wgs_per_cu == 1 ? 131072 : 65536, grid = 256 * wgs_per_cu;
     (void)hipFuncSetAttribute((const void *)k<V, NVM, NDS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float ms = 0;
     for (int rep = 0; rep < 2; rep++) {
+        (void)hipEventRecord(e0, 0);
         k<V, NVM, NDS><<<grid, 256, lds_bytes>>>(w, out, iters, sink);
+        (void)hipEventRecord(e1, 0);
         (void)hipDeviceSynchronize();
+        (void)hipEventElapsedTime(&ms, e0, e1);
     }
+    // wall-clock rate: every wave does iters slices of 24 x 16384 (or 12 x 32768) FLOP
+    const double tflops = (double)grid * 4 * iters * 24 * 16384 / (ms * 1e-3) / 1e12;
     std::vector<unsigned long long> h(grid * 4);
     (void)hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
     double sum = 0;
     for (auto v : h) sum += (double)v;
     const double per = sum / h.size() / iters;
-    printf("%-44s %d WG/CU: %7.1f cycles/slice per wave -> %5.1f %% of the MFMA peak\n", name, wgs_per_cu, per,
-           100.0 * 384.0 * wgs_per_cu / per);
+    printf("%-44s %d WG/CU: %7.1f s_memtime ticks/slice per wave; wall clock %.3f ms = %.0f TFLOP/s (%4.1f %% of 2500)\n", name,
+           wgs_per_cu, per, ms, tflops, tflops / 25.0);
 }
 
 int main() {
