@@ -858,8 +858,9 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->cin_p = round_up(m.c_in, 32);
     e->cp = round_up(m.channels, 32);
     const char *force = getenv("KZ_FORCE_GENERIC");
+    const char *notower = getenv("KZ_NO_TOWER_F16");  // (experiments: chess f16 through the generic one-launch f16 tower)
     e->resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth) && e->cin_p == 32 &&
-                  !(force && force[0] == '1');
+                  !(force && force[0] == '1') && !(notower && notower[0] == '1');
     const char *nofuse = getenv("KZ_NO_FUSED_HEADS");
     e->fused_heads = e->resident && !(nofuse && nofuse[0] == '1') &&
                      kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,

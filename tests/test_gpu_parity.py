@@ -917,3 +917,45 @@ def test_board_conv2_experiment_agrees_with_the_product_kernel(dev):
     s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
     assert_f16(s1[:1], s_ref, "board_conv2 vs oracle, scalars")
     assert_f16(p1[:1], p_ref, "board_conv2 vs oracle, policy")
+
+
+@pytest.mark.parametrize("dtype_name,env", [("split16", "KZ_SPLIT_MFMA32"), ("f16", "KZ_F16G_MFMA32")])
+def test_mfma_32x32_experiment_agrees_with_the_product_kernel(dev, tmp_path, dtype_name, env):
+    """kz_tower_resident_split32 (opt-in: the 256-channel, 64-row launch on v_mfma_f32_32x32x16_f16; the switch is read
+    once per process, hence the child process): the same sums as the 16x16x32 launch in another order — split16 within the
+    1e-4 of the oracle, plain f16 within the f16 path tolerance of the product launch."""
+    import subprocess
+    import sys
+    game, depth, head = ("chess", 3, "attention") if dtype_name == "split16" else ("ataxx-7", 3, "ataxx_conv")
+    out = str(tmp_path / "out.npz")
+    code = f"""
+import numpy as np
+from kzero_amd import capi, synth
+blob = synth.random_model({game!r}, {depth}, 256, {head!r}, seed=44)
+eng = capi.Engine(capi.Model(blob=blob), {dev}, 16, capi.KZ_DTYPE_F32_SPLIT16 if {dtype_name!r} == "split16" else capi.KZ_DTYPE_F16)
+bits, sc = synth.random_boards({game!r}, 11, seed=45)
+s, p = eng.eval_packed(bits, sc)
+np.savez({out!r}, s=s, p=p, path=eng.tower_path)
+"""
+    child_env = dict(os.environ, **{env: "1"})
+    r = subprocess.run([sys.executable, "-c", code], env=child_env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr
+    got = np.load(out)
+    blob = synth.random_model(game, depth, 256, head, seed=44)
+    bits, sc = synth.random_boards(game, 11, seed=45)
+    code_dtype = capi.KZ_DTYPE_F32_SPLIT16 if dtype_name == "split16" else capi.KZ_DTYPE_F16
+    eng = capi.Engine(capi.Model(blob=blob), dev, 16, code_dtype)
+    assert str(got["path"]) == eng.tower_path == ("tower_resident_split16" if dtype_name == "split16" else "tower_resident_f16g")
+    s, p = eng.eval_packed(bits, sc)
+    if dtype_name == "split16":
+        net = O.OracleNet(blob)
+        s_ref, p_ref = net.forward(O.encode_input_full(bits, sc, net.n_scalar, net.n_bool, net.h, net.w),
+                                   threads=os.cpu_count() or 1)
+        assert_f32(got["s"], s_ref, "32x32x16 split launch vs oracle, scalars")
+        assert_f32(got["p"], p_ref, "32x32x16 split launch vs oracle, policy")
+        assert_f32(got["s"], s, "32x32x16 vs 16x16x32 split launch, scalars")
+        assert_f32(got["p"], p, "32x32x16 vs 16x16x32 split launch, policy")
+        assert not (np.array_equal(got["p"], p) and np.array_equal(got["s"], s)), "the child did not run the other kernel"
+    else:
+        assert np.abs(got["p"] - p).max() < F16_PATHS_ATOL and np.abs(got["s"] - s).max() < F16_PATHS_ATOL
