@@ -168,7 +168,8 @@ int kz_engine_set_profiling(kz_engine *engine, int enable);
 int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_ms, int64_t *launches);
 /* Name of the path the engine chose.  One launch for the whole tower: "tower_resident_f16+heads" (chess attention
  * network, heads included), "tower_resident_f16", "tower_resident_f16g" (other board-resident f16 shapes),
- * "tower_resident_f32" (exact f32), "tower_resident_split16" (KZ_DTYPE_F32_SPLIT16).  One launch per layer:
+ * "tower_resident_f32+heads" (exact f32, conv policy heads: decode, tower and heads in one launch), "tower_resident_f32"
+ * (exact f32, other heads), "tower_resident_split16" (KZ_DTYPE_F32_SPLIT16).  One launch per layer:
  * "board_conv_f16" (whole boards as LDS tiles, Go-size boards), "conv_igemm_f16", "conv_igemm_f32". */
 const char *kz_engine_tower_path(const kz_engine *engine);
 /* How the dominant launch of that path covers the chip for a batch of `batch` boards: workgroups per launch and boards
@@ -179,7 +180,8 @@ int kz_engine_launch_geometry(const kz_engine *engine, int batch, int *workgroup
  * name: "tower.<i>" as in python/lib/model/post_act.py's nn.Sequential indices (0 = stem, 1..d = blocks,
  * d+1 = final BN): only available when the engine was created with the generic per-layer path (set KZ_FORCE_GENERIC=1
  * and KZ_KEEP_ACTIVATIONS=1 in the environment before kz_engine_create); or "tower.out", the tower's output (after the
- * final BN), on every path that writes it to memory (all but "tower_resident_f16+heads"). */
+ * final BN), on every path that writes it to memory (all but the "...+heads" paths; KZ_NO_FUSED_HEADS=1 in the
+ * environment before kz_engine_create gives the separate head launches back). */
 int kz_engine_read_activation(kz_engine *engine, const char *name, int batch, float *out_nchw);
 
 #ifdef __cplusplus
