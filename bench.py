@@ -253,6 +253,8 @@ class Workload:
         self.capi.check(self.capi.load().kz_device_synchronize(self.device))
 
     def profiling(self, on):
+        if on and os.environ.get("KZ_BENCH_NO_KERNEL_TIMING") == "1":
+            return  # (A/B runs of KZ_HIP_GRAPH=1: a forward pass bracketed by events is not replayed from a graph)
         for e in self.engines:
             e.set_profiling(on)
 

@@ -166,7 +166,11 @@ int kz_device_synchronize(int device);
  * profiling was last enabled (it synchronizes the stream first). */
 int kz_engine_set_profiling(kz_engine *engine, int enable);
 int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_ms, int64_t *launches);
-/* Name of the path the engine chose.  One launch for the whole tower: "tower_resident_f16+heads" (chess attention
+/* Environment switches read by kz_engine_create (all off by default; none changes results beyond summation order):
+ * KZ_HIP_GRAPH=1 replays the multi-launch paths' forward pass from a captured hipGraph (measured: no gain on this
+ * runtime); KZ_NO_FUSED_HEADS=1, KZ_FORCE_GENERIC=1, KZ_TOWER_NB, KZ_NO_ZERO_COPY=1 select the
+ * alternative launches described in DESIGN.md 5.
+ * Name of the path the engine chose.  One launch for the whole tower: "tower_resident_f16+heads" (chess attention
  * network, heads included), "tower_resident_f16", "tower_resident_f16g" (other board-resident f16 shapes),
  * "tower_resident_f32+heads" (exact f32, conv policy heads: decode, tower and heads in one launch), "tower_resident_f32"
  * (exact f32, other heads), "tower_resident_split16" (KZ_DTYPE_F32_SPLIT16).  One launch per layer:

@@ -448,6 +448,50 @@ struct kz_engine {
     int nf_epoch = 0;
     int *d_devflag = nullptr;  // flag of the device-resident entry points, checked by kz_engine_synchronize
     int dev_epoch_checked = 0;
+
+    // hipGraph replay of the forward pass (KZ_HIP_GRAPH=1; multi-launch paths only — the one-launch paths have nothing to
+    // replay): the launches of one (entry point, batch size, buffers) are captured once from the engine's own stream and
+    // replayed with one hipGraphLaunch.  A captured kernel argument cannot change, so the range check of a replayed pass
+    // reports a CONSTANT epoch: per slot the flag word is cleared by a captured memset, for the device-resident entry
+    // points kz_engine_synchronize clears it after reporting.
+    static constexpr int GRAPH_EPOCH = 0x7fffffff;
+    bool use_graph = false, graph_warm = false;
+    struct GraphEntry {
+        int kind, batch;  // kind: slot index, or -1 for the device-resident entry point
+        const void *bits;
+        size_t stride;
+        const void *sin;
+        void *sout, *pol;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
+    bool graph_mode() const { return use_graph && graph_warm && !prof.on && !keep; }
+    // runs `body` (which enqueues on `stream`) through the graph of this key: captured at first sight
+    template <class Body>
+    int replay(int kind, int batch, const void *bits, size_t stride, const void *sin, void *sout, void *pol, Body body) {
+        for (const GraphEntry &g : graphs)
+            if (g.kind == kind && g.batch == batch && g.bits == bits && g.stride == stride && g.sin == sin && g.sout == sout &&
+                g.pol == pol) {
+                HIP_TRY(hipGraphLaunch(g.exec, stream));
+                return 0;
+            }
+        if (graphs.size() >= 32) return body();  // (a caller cycling through many shapes: eager)
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        const int rc = body();
+        const hipError_t end = hipStreamEndCapture(stream, &graph);
+        if (rc || end != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc ? rc : fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(end));
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (inst != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(inst));
+        graphs.push_back({kind, batch, bits, stride, sin, sout, pol, exec});
+        HIP_TRY(hipGraphLaunch(exec, stream));
+        return 0;
+    }
     void arm(Slot &s) {  // the forward pass enqueued next reports into this slot's header
         s.epoch = ++epoch;
         nf_flag = reinterpret_cast<int *>(s.d_sout);
@@ -460,6 +504,7 @@ struct kz_engine {
         HIP_TRY(hipMemcpy(&v, d_devflag, 4, hipMemcpyDeviceToHost));
         const int since = dev_epoch_checked;
         dev_epoch_checked = epoch;
+        if (v == GRAPH_EPOCH) HIP_TRY(hipMemset(d_devflag, 0, 4));  // (a replayed pass cannot carry a fresh epoch)
         if (v > since) return fail(nonfinite_message("kz_engine_synchronize"));
         return 0;
     }
@@ -823,6 +868,7 @@ KZ_API void kz_engine_destroy(kz_engine *e) {
     for (auto st : e->slot_stream)
         if (st) (void)hipStreamSynchronize(st);
     e->prof.destroy();
+    for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &s : e->slots)
         if (s.done) (void)hipEventDestroy(s.done);
     for (void *p : e->allocs) (void)hipFree(p);
@@ -924,6 +970,10 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         }
     }
 
+    {
+        const char *hg = getenv("KZ_HIP_GRAPH");
+        e->use_graph = hg && hg[0] == '1' && !e->fused_heads && !e->fused32;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[0], hipStreamNonBlocking));
     e->stream = e->slot_stream[0];
     if (e->fused_heads || e->fused32) {  // one launch per batch that touches nothing but its slot's buffers
@@ -1059,8 +1109,20 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
     }
     HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
-    e->arm(s);
-    if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol)) return 1;
+    if (e->graph_mode()) {
+        s.epoch = kz_engine::GRAPH_EPOCH;
+        e->nf_flag = reinterpret_cast<int *>(s.d_sout);
+        e->nf_epoch = s.epoch;
+        if (e->replay(slot, batch, s.d_bits, bits_bytes, s.d_sin, s.d_sout, s.d_pol, [&]() -> int {
+                HIP_TRY(hipMemsetAsync(s.d_sout, 0, 4, e->stream));
+                return e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol);
+            }))
+            return 1;
+    } else {
+        e->arm(s);
+        if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol)) return 1;
+        e->graph_warm = true;  // (the first pass runs eagerly: lazy per-kernel set-up must not land in a capture)
+    }
     HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, ((size_t)batch * 5 + kz_engine::SOUT_HDR) * 4, hipMemcpyDeviceToHost,
                            e->stream));
     HIP_TRY(hipMemcpyAsync(s.h_pol, s.d_pol, (size_t)batch * m.policy_len * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1256,7 +1318,15 @@ KZ_API int kz_engine_enqueue_packed_device(kz_engine *e, const void *d_bits, siz
     HIP_TRY(hipSetDevice(e->device));
     e->nf_flag = e->d_devflag;
     e->nf_epoch = ++e->epoch;
-    return e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
+    if (e->graph_mode()) {
+        e->nf_epoch = kz_engine::GRAPH_EPOCH;
+        return e->replay(-1, batch, d_bits, bits_stride, d_scalars_in, d_scalars_out, d_policy_out, [&]() -> int {
+            return e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
+        });
+    }
+    const int rc = e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
+    e->graph_warm = true;
+    return rc;
 }
 
 KZ_API int kz_engine_enqueue_dense_device(kz_engine *e, const void *d_input_nchw, int batch, void *d_scalars_out,

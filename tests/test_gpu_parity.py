@@ -959,3 +959,56 @@ np.savez({out!r}, s=s, p=p, path=eng.tower_path)
         assert not (np.array_equal(got["p"], p) and np.array_equal(got["s"], s)), "the child did not run the other kernel"
     else:
         assert np.abs(got["p"] - p).max() < F16_PATHS_ATOL and np.abs(got["s"] - s).max() < F16_PATHS_ATOL
+
+
+@pytest.mark.parametrize("game,depth,channels,head,dtype,path,env", [
+    ("go-9", 2, 128, "conv", "f16", "board_conv_f16", {"KZ_NO_RESIDENT_F16G": "1"}),
+    ("go-9", 2, 128, "conv", "f16", "conv_igemm_f16", {"KZ_NO_RESIDENT_F16G": "1", "KZ_NO_BOARD_CONV": "1"}),
+    ("ataxx-7", 2, 128, "ataxx_conv", "f16", "tower_resident_f16g", {}),
+    ("chess", 2, 256, "attention", "split16", "tower_resident_split16", {}),
+    ("chess", 2, 64, "attention", "f32", "conv_igemm_f32", {}),
+])
+def test_hip_graph_replay_is_the_same_forward_pass(dev, game, depth, channels, head, dtype, path, env):
+    """KZ_HIP_GRAPH=1 (the multi-launch paths' forward pass captured once per (entry point, batch,
+    buffers) and replayed with one hipGraphLaunch): bitwise the outputs of the eager engine on the asynchronous pair and on
+    the device-resident entry point, for several batch sizes and repeated replays; the range check still reports."""
+    blob = synth.random_model(game, depth, channels, head, seed=61)
+    code = {"f16": capi.KZ_DTYPE_F16, "f32": capi.KZ_DTYPE_F32, "split16": capi.KZ_DTYPE_F32_SPLIT16}[dtype]
+    os.environ.update(env)
+    try:
+        eager = capi.Engine(capi.Model(blob=blob), dev, 512, code)
+        os.environ["KZ_HIP_GRAPH"] = "1"
+        graph = capi.Engine(capi.Model(blob=blob), dev, 512, code)
+        big = capi.Engine(capi.Model(blob=_scaled_stem(blob, 3.0e5)), dev, 512, code) if dtype != "f32" else None
+    finally:
+        for k in list(env) + ["KZ_HIP_GRAPH"]:
+            os.environ.pop(k, None)
+    assert eager.tower_path == graph.tower_path == path
+    for batch in (7, 32, 7):  # the second 7 replays the first 7's graphs
+        bits, sc = synth.random_boards(game, batch, seed=62 + batch)
+        s_ref, p_ref = eager.eval_packed(bits, sc)
+        for rep in range(3):  # first pass eager (warm-up), second captures, third replays
+            for slot in range(capi.KZ_ENGINE_SLOTS):
+                graph.submit_packed(slot, bits, sc)
+            for slot in range(capi.KZ_ENGINE_SLOTS):
+                s, p = graph.wait(slot, batch)
+                assert np.array_equal(s, s_ref) and np.array_equal(p, p_ref), f"slot {slot} batch {batch} rep {rep}"
+        d_bits, d_sc = capi.DeviceBuffer.from_host(dev, bits), capi.DeviceBuffer.from_host(dev, sc)
+        d_s, d_p = capi.DeviceBuffer(dev, batch * 5 * 4), capi.DeviceBuffer(dev, batch * graph.model.info.policy_len * 4)
+        for rep in range(3):
+            graph.enqueue_packed_device(d_bits, bits.shape[1], d_sc, batch, d_s, d_p)
+            graph.synchronize()
+            assert np.array_equal(d_s.to_host(np.float32, (batch, 5)), s_ref), f"device-resident batch {batch} rep {rep}"
+            assert np.array_equal(d_p.to_host(np.float32, p_ref.shape), p_ref)
+    if big is not None:
+        bits, sc = synth.random_boards(game, 9, seed=70)
+        for rep in range(3):  # eager, captured, replayed: all report
+            with pytest.raises(capi.KzError, match="non-finite activation"):
+                big.wait_view(0, big.submit_packed(0, bits, sc))
+        d_s, d_p = capi.DeviceBuffer(dev, 9 * 5 * 4), capi.DeviceBuffer(dev, 9 * big.model.info.policy_len * 4)
+        d_bits, d_sc = capi.DeviceBuffer.from_host(dev, bits), capi.DeviceBuffer.from_host(dev, sc)
+        for rep in range(3):
+            big.enqueue_packed_device(d_bits, bits.shape[1], d_sc, 9, d_s, d_p)
+            with pytest.raises(capi.KzError, match="non-finite activation"):
+                big.synchronize()
+            big.synchronize()  # reported once
