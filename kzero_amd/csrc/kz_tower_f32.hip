@@ -14,12 +14,13 @@
 //               the activation fragment with element s of the weight fragment, which the host packed in the same order.
 //   weights   = streamed L2 -> registers in fragment order (16 B per lane per step and 16-channel output tile) through
 //               a four-step ring that runs on across layer boundaries; a step is 4 * (C/64) * NT MFMAs of 32 cycles
-//   epilogue  = bias-initialised accumulators (the next layer's bias is fetched a layer ahead); [ReLU]; [+ residual, in place in the out image]; [final BN]; 16-byte
-//               stores (4 consecutive output channels of a pixel row per lane)
+//   epilogue  = bias-initialised accumulators (the next layer's bias is fetched a layer ahead); [ReLU]; [+ residual, in
+//               place in the out image]; [final BN]; 16-byte stores (4 consecutive output channels of a pixel row per lane)
 //   encode    = packed boards (bit planes + scalar planes) are decoded while the stem input is staged
 //   heads     = (HEADS launches: conv / ataxx_conv policy head + scalar head) the policy head's Conv1x1 C->C + ReLU is
-//               one more layer of the centre tap only, at the end of the same weight stream; the remaining head layers
-//               are a few hundred FMAs per thread on the two images in LDS — the tower output never reaches HBM and a
+//               one more layer of the centre tap only, at the end of the same weight stream; the 1x1 convolutions with
+//               few output channels (scalar head, extra moves, policy planes) are two small MFMA passes over the two
+//               images in LDS, the Linears a few hundred FMAs per thread — the tower output never reaches HBM and a
 //               batch is ONE launch
 //
 // Arithmetic follows python/lib/model/post_act.py:201-239 (tower), :8-31 (scalar head), :75-110 (conv policy heads) with
