@@ -287,6 +287,8 @@ def test_config_a1_ataxx_8x128_f32_batch256(dev):
     dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
     s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
     eng = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F32)
+    assert eng.tower_path == "tower_resident_f32+heads"  # the whole network in one launch (128 workgroups of two boards)
+    assert eng.launch_geometry(256) == (128, 2)
     s, p = eng.eval_packed(bits, scalars_in)
     assert_f32(s, s_ref, "scalars")
     assert_f32(p, p_ref, "policy")
