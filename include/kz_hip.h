@@ -166,10 +166,20 @@ int kz_device_synchronize(int device);
  * profiling was last enabled (it synchronizes the stream first). */
 int kz_engine_set_profiling(kz_engine *engine, int enable);
 int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_ms, int64_t *launches);
-/* Environment switches read by kz_engine_create (all off by default; none changes results beyond summation order):
- * KZ_HIP_GRAPH=1 replays the multi-launch paths' forward pass from a captured hipGraph (measured: no gain on this
- * runtime); KZ_NO_FUSED_HEADS=1, KZ_FORCE_GENERIC=1, KZ_TOWER_NB, KZ_NO_ZERO_COPY=1 select the
- * alternative launches described in DESIGN.md 5.
+/* Environment switches read by kz_engine_create.  This is the COMPLETE list for libkzhip.so (tests/test_abi.py compares
+ * it with the strings in the built library); each selects between product paths that are parity-tested against the
+ * oracle, none changes results beyond summation order, all are off by default:
+ *   KZ_FORCE_GENERIC=1      no one-launch tower: one launch per layer ("board_conv_f16" / "conv_igemm_*")
+ *   KZ_NO_BOARD_CONV=1      per-layer f16 convolutions through the implicit-GEMM kernel instead of the board-tile kernel
+ *   KZ_NO_RESIDENT_F16G=1   no "tower_resident_f16g" launch (f16 shapes other than the chess network go per layer)
+ *   KZ_NO_FUSED_HEADS=1     the "...+heads" launches without their heads: tower launch + separate head kernels
+ *   KZ_TOWER_NB=1|2         boards per workgroup of the chess f16 launch (default 2; 1 = twice the workgroups: the better
+ *                           choice for ONE engine at batch <= 256)
+ *   KZ_KEEP_ACTIVATIONS=1   with KZ_FORCE_GENERIC=1: keep every layer's output for kz_engine_read_activation
+ * The kernel organisations that were measured and rejected (four boards per workgroup, two Go boards per workgroup,
+ * 32x32x16 tiles, hipGraph replay, ablation knobs) are NOT in this library: `KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh`
+ * builds them into a separate libkzhip_exp.so for tests/test_gpu_experiments.py and tools/.
+ *
  * Name of the path the engine chose.  One launch for the whole tower: "tower_resident_f16+heads" (chess attention
  * network, heads included), "tower_resident_f16", "tower_resident_f16g" (other board-resident f16 shapes),
  * "tower_resident_f32+heads" (exact f32, conv policy heads: decode, tower and heads in one launch), "tower_resident_f32"

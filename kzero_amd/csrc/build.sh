@@ -1,15 +1,35 @@
 #!/bin/bash
-# Builds kzero_amd/libkzhip.so for gfx950 (cross-compiles without a GPU).
+# Builds kzero_amd/libkzhip.so for gfx950 (cross-compiles without a GPU): the PRODUCT library.
+#
+#   KZ_EXPERIMENTS=1 build.sh   builds kzero_amd/libkzhip_exp.so instead: the same sources with -DKZ_EXPERIMENTS plus the
+#                               measured-and-rejected kernel organisations (kz_tower4.hip, kz_board_conv2.hip, the 32x32x16
+#                               variants, hipGraph replay) and their environment switches.  Only tests/test_gpu_experiments.py
+#                               and tools/ load it; nothing of it is compiled into the product.
+#   diagnostic builds:          KZ_OUT=../libkzhip_diag.so KZ_BUILD_DIR=build_diag KZ_EXTRA_FLAGS=-DKZ_BC_STAMPS build.sh
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-OUT=${KZ_OUT:-../libkzhip.so}   # diagnostic builds: KZ_OUT=../libkzhip_diag.so KZ_BUILD_DIR=build_diag KZ_EXTRA_FLAGS=-DKZ_BC_STAMPS
-B=${KZ_BUILD_DIR:-build}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mcode-object-version=5 -Wall -Wno-unused-result ${KZ_EXTRA_FLAGS:-}"
+EXP=${KZ_EXPERIMENTS:-0}
+if [ "$EXP" = "1" ]; then
+  OUT=${KZ_OUT:-../libkzhip_exp.so}
+  B=${KZ_BUILD_DIR:-build_exp}
+  DEFS="-DKZ_EXPERIMENTS"
+  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower4.hip kz_tower_f32.hip kz_tower_split.hip kz_board_conv.hip kz_board_conv2.hip kz_engine.hip"
+else
+  OUT=${KZ_OUT:-../libkzhip.so}
+  B=${KZ_BUILD_DIR:-build}
+  DEFS=""
+  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower_f32.hip kz_tower_split.hip kz_board_conv.hip kz_engine.hip"
+fi
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mcode-object-version=5 -Wall -Wno-unused-result $DEFS ${KZ_EXTRA_FLAGS:-}"
 mkdir -p $B
+# a change of flags rebuilds everything
+if [ "$(cat $B/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f $B/*.o; echo "$FLAGS" > $B/.flags; fi
 pids=()
-for src in kz_kernels.hip kz_tower.hip kz_tower4.hip kz_tower_f32.hip kz_tower_split.hip kz_board_conv.hip kz_board_conv2.hip kz_engine.hip; do
+objs=()
+for src in $HIP_SRCS; do
   obj=$B/${src%.hip}.o
+  objs+=("$obj")
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_kernels.hpp -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ] || [ ../../include/kz_hip.h -nt "$obj" ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
@@ -17,12 +37,14 @@ for src in kz_kernels.hip kz_tower.hip kz_tower4.hip kz_tower_f32.hip kz_tower_s
 done
 for src in kz_model.cpp kz_onnx.cpp; do
   obj=$B/${src%.cpp}.o
+  objs+=("$obj")
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ]; then
     g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $B/kz_kernels.o $B/kz_tower.o $B/kz_tower4.o $B/kz_tower_f32.o $B/kz_tower_split.o $B/kz_board_conv.o $B/kz_board_conv2.o $B/kz_engine.o $B/kz_model.o $B/kz_onnx.o \
-  -Wl,-rpath,/opt/rocm/lib -Wl,--no-undefined
+rc=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
+[ $rc = 0 ] || { echo "compile failed" >&2; exit 1; }
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}" -Wl,-rpath,/opt/rocm/lib -Wl,--no-undefined
 echo "built $(realpath $OUT)"

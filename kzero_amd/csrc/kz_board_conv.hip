@@ -99,8 +99,6 @@ struct BoardConvDev {
     int n_halo;
     int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
     unsigned long long *stamps;  // diagnostic build only
-    int ablate;        // timing experiments only (KZ_BC_ABLATE): 1 no staging loads, 2 no residual/output traffic,
-                       // 16 no issue priority
 };
 
 __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     // both multiply, both store at the same time and nothing overlaps.  Giving ONE of them issue priority (the one
     // whose LDS allocation starts at 0) lets it run its k-loops at full rate and reach its staging/epilogue phases
     // while the other multiplies: the pair falls into complementary phases.
-    if (!(a.ablate & 16)) {
+    {
         const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);  // HW_REG_LDS_ALLOC.LDS_BASE
         if (lds_base == 0) __builtin_amdgcn_s_setprio(3);
     }
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
             u32x4 v[12];
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                v[i] = (a.ablate & 1) ? u32x4{0, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], chunk * CH * 2, 0);
+                v[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], chunk * CH * 2, 0);
 #pragma unroll
             for (int i = 0; i < 12; i++)
                 if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + ls[i]) = v[i];  // never into the halo
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     // dead now) so that HBM sees whole 128-byte lines (this workgroup's 64 output channels of a pixel) instead of
     // 8-byte pieces: O[row][64 oc] f16, row stride 144 B.
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    const bool with_res = a.res && !(a.ablate & 2);
+    const bool with_res = a.res != nullptr;
     u32x2 resv[NTW][MTW];
     if (with_res) {
         const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.res), 0, a.bytes, 0x00020000);
@@ -376,7 +374,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     __syncthreads();
     KZ_STAMP(19);
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
-    if (!(a.ablate & 2))
 #pragma unroll
     for (int i = 0; i < 12; i++)  // a padding row's store is out of range and dropped
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
@@ -476,8 +473,6 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.plane = geo.plane;
     d.cin = t.cin;
     d.relu = t.relu;
-    static const int ablate = getenv("KZ_BC_ABLATE") ? atoi(getenv("KZ_BC_ABLATE")) : 0;
-    d.ablate = ablate;
     d.groups = (t.boards + d.bpw - 1) / d.bpw;
     d.nq = t.cout / OCW;
     static thread_local unsigned long long done_mask = 0;
@@ -501,10 +496,7 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
 #else
     d.stamps = nullptr;
 #endif
-    // KZ_BC_LDS_MIN (timing experiments only): a larger allocation forces one workgroup per CU
-    static const int lds_min = getenv("KZ_BC_LDS_MIN") ? atoi(getenv("KZ_BC_LDS_MIN")) : 0;
-    const int lds_bytes = geo.lds_bytes > lds_min ? geo.lds_bytes : (lds_min < 160 * 1024 ? lds_min : 160 * 1024);
-    kz_board_conv_f16<<<grid, 256, lds_bytes, stream>>>(d);
+    kz_board_conv_f16<<<grid, 256, geo.lds_bytes, stream>>>(d);
 #ifdef KZ_BC_STAMPS
     if (launches++ == 20 && getenv("KZ_BC_STAMP_FILE")) {
         (void)hipStreamSynchronize(stream);

@@ -123,9 +123,12 @@ struct DeviceWeights {
         d.cout = d.cout_p = cv.cout;
         d.cin_p = cv.cin;
         std::vector<uint16_t> packed(kz::board_conv_weight_elems(cv.cin, cv.cout));
+#ifdef KZ_EXPERIMENTS
         d.bw2 = conv2;
         if (conv2) kz::board_conv2_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
-        else kz::board_conv_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        else
+#endif
+        kz::board_conv_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
         if (upload(packed.data(), packed.size() * 2, &d.bw)) return 1;
         return upload_f32(cv.b, &d.b);
     }
@@ -213,9 +216,9 @@ struct DeviceWeights {
             std::vector<uint16_t> packed(kz::tower_split_weight_elems(C, m.depth, split16));
             const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = 9 * step_elems,
                          layer_elems = (size_t)9 * (C / 32) * step_elems;
-            kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, true, split16, packed.data());
+            kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, hw, true, split16, packed.data());
             for (int l = 0; l < 2 * m.depth; l++)
-                kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, false, split16,
+                kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, hw, false, split16,
                                              packed.data() + stem_elems + layer_elems * l);
             std::vector<float> bias((size_t)(1 + 2 * m.depth) * C);
             for (int l = 0; l < 1 + 2 * m.depth; l++)
@@ -275,11 +278,14 @@ struct DeviceWeights {
             if (use_board_conv && !(noboard && noboard[0] == '1')) {
                 std::vector<int> rowmap;
                 std::vector<unsigned short> halo;
+#ifdef KZ_EXPERIMENTS
                 const char *c2 = getenv("KZ_BOARD_CONV2");
                 // (experiment, opt-in: the second organisation measured 26.2k against 33.5k evals/s on Go-19 40x256)
                 conv2 = c2 && c2[0] == '1' && kz::board_conv2_supported(dtype, m.h, m.w, m.channels, m.channels);
                 if (conv2) kz::board_conv2_tables(m.h, m.w, rowmap, halo);
-                else kz::board_conv_tables(m.h, m.w, rowmap, halo);
+                else
+#endif
+                kz::board_conv_tables(m.h, m.w, rowmap, halo);
                 bc_n_halo = (int)halo.size();
                 if (upload(rowmap.data(), rowmap.size() * sizeof(int), (void **)&bc_rowmap)) return 1;
                 if (upload(halo.data(), halo.size() * sizeof(unsigned short), (void **)&bc_halo)) return 1;
@@ -443,11 +449,35 @@ struct kz_engine {
     static constexpr int SOUT_HDR = 4;  // floats in front of the scalars
     // range check (see kz::ScalarHeadArgs): every submission gets a new epoch; a kernel that meets a non-finite
     // activation raises the flag it was given to that epoch.  No reset between batches is needed.
+    // Epochs run 1 .. GRAPH_EPOCH-1 and start over (0 is the cleared word, GRAPH_EPOCH the replayed passes' constant):
+    // at ~2k submissions/s an int would overflow after 12 days of self-play.
     int epoch = 0;
     int *nf_flag = nullptr;  // what the running forward pass writes to
     int nf_epoch = 0;
     int *d_devflag = nullptr;  // flag of the device-resident entry points, checked by kz_engine_synchronize
+    int dev_epoch_enqueued = 0;  // epoch of the last device-resident enqueue (slot submissions do not touch d_devflag)
     int dev_epoch_checked = 0;
+    int next_epoch() {
+        if (epoch >= GRAPH_EPOCH - 1) {  // start over: settle the device-resident flag first (slot flags compare for equality)
+            (void)sync_all();
+            (void)check_devflag_pending();
+            if (d_devflag) (void)hipMemset(d_devflag, 0, 4);
+            epoch = dev_epoch_enqueued = dev_epoch_checked = 0;
+        }
+        return ++epoch;
+    }
+    bool wrap_nonfinite_pending = false;  // a non-finite batch seen while starting the epochs over: reported by the next synchronize
+    int check_devflag_pending() {
+        if (!d_devflag || dev_epoch_checked == dev_epoch_enqueued) return 0;
+        int v = 0;
+        if (hipMemcpy(&v, d_devflag, 4, hipMemcpyDeviceToHost) == hipSuccess && v != GRAPH_EPOCH && v > dev_epoch_checked)
+            wrap_nonfinite_pending = true;
+        return 0;
+    }
+    void arm_device() {  // the forward pass enqueued next reports into the device-resident flag
+        nf_flag = d_devflag;
+        nf_epoch = dev_epoch_enqueued = next_epoch();
+    }
 
     // hipGraph replay of the forward pass (KZ_HIP_GRAPH=1; multi-launch paths only — the one-launch paths have nothing to
     // replay): the launches of one (entry point, batch size, buffers) are captured once from the engine's own stream and
@@ -455,6 +485,9 @@ struct kz_engine {
     // reports a CONSTANT epoch: per slot the flag word is cleared by a captured memset, for the device-resident entry
     // points kz_engine_synchronize clears it after reporting.
     static constexpr int GRAPH_EPOCH = 0x7fffffff;
+#ifndef KZ_EXPERIMENTS
+    static constexpr bool graph_mode() { return false; }  // the replay is an experiment build's switch (no gain measured)
+#else
     bool use_graph = false, graph_warm = false;
     struct GraphEntry {
         int kind, batch;  // kind: slot index, or -1 for the device-resident entry point
@@ -492,18 +525,24 @@ struct kz_engine {
         HIP_TRY(hipGraphLaunch(exec, stream));
         return 0;
     }
+#endif
     void arm(Slot &s) {  // the forward pass enqueued next reports into this slot's header
-        s.epoch = ++epoch;
+        s.epoch = next_epoch();
         nf_flag = reinterpret_cast<int *>(s.d_sout);
         nf_epoch = s.epoch;
     }
     static bool slot_nonfinite(const Slot &s) { return *reinterpret_cast<const int *>(s.h_sout) == s.epoch; }
     int check_devflag() {
-        if (!d_devflag || dev_epoch_checked == epoch) return 0;
+        if (wrap_nonfinite_pending) {
+            wrap_nonfinite_pending = false;
+            return fail(nonfinite_message("kz_engine_synchronize"));
+        }
+        // nothing device-resident enqueued since the last check: no blocking copy (slot submissions report per slot)
+        if (!d_devflag || dev_epoch_checked == dev_epoch_enqueued) return 0;
         int v = 0;
         HIP_TRY(hipMemcpy(&v, d_devflag, 4, hipMemcpyDeviceToHost));
         const int since = dev_epoch_checked;
-        dev_epoch_checked = epoch;
+        dev_epoch_checked = dev_epoch_enqueued;
         if (v == GRAPH_EPOCH) HIP_TRY(hipMemset(d_devflag, 0, 4));  // (a replayed pass cannot carry a fresh epoch)
         if (v > since) return fail(nonfinite_message("kz_engine_synchronize"));
         return 0;
@@ -553,8 +592,11 @@ struct kz_engine {
             b.boards = M / (h * wd); b.h = h; b.w = wd; b.cin = w.cin_p; b.cout = w.cout; b.relu = relu;
             b.rowmap = wts->bc_rowmap; b.halo = wts->bc_halo; b.n_halo = wts->bc_n_halo;
             prof.begin("kz_board_conv_f16", stream);
+#ifdef KZ_EXPERIMENTS
             if (w.bw2) kz::launch_board_conv2(b, stream);
-            else kz::launch_board_conv(b, stream);
+            else
+#endif
+            kz::launch_board_conv(b, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             return 0;
@@ -612,8 +654,11 @@ struct kz_engine {
             t.scalars = d_scalars; t.policy = d_policy;
             t.nonfinite_flag = nf_flag; t.epoch = nf_epoch;
             prof.begin("kz_tower_resident_f16", stream);
+#ifdef KZ_EXPERIMENTS
             if (nb4) kz::launch_tower_resident4(t, xres, stream);
-            else kz::launch_tower_resident(t, stream);
+            else
+#endif
+            kz::launch_tower_resident(t, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             tower_out = 0;
@@ -868,7 +913,9 @@ KZ_API void kz_engine_destroy(kz_engine *e) {
     for (auto st : e->slot_stream)
         if (st) (void)hipStreamSynchronize(st);
     e->prof.destroy();
+#ifdef KZ_EXPERIMENTS
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+#endif
     for (auto &s : e->slots)
         if (s.done) (void)hipEventDestroy(s.done);
     for (void *p : e->allocs) (void)hipFree(p);
@@ -904,16 +951,21 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->cin_p = round_up(m.c_in, 32);
     e->cp = round_up(m.channels, 32);
     const char *force = getenv("KZ_FORCE_GENERIC");
-    const char *notower = getenv("KZ_NO_TOWER_F16");  // (experiments: chess f16 through the generic one-launch f16 tower)
     e->resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth) && e->cin_p == 32 &&
-                  !(force && force[0] == '1') && !(notower && notower[0] == '1');
+                  !(force && force[0] == '1');
+#ifdef KZ_EXPERIMENTS
+    const char *notower = getenv("KZ_NO_TOWER_F16");  // (chess f16 through the generic one-launch f16 tower)
+    if (notower && notower[0] == '1') e->resident = false;
+#endif
     const char *nofuse = getenv("KZ_NO_FUSED_HEADS");
     e->fused_heads = e->resident && !(nofuse && nofuse[0] == '1') &&
                      kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,
                                                m.sh_fc0.out);
+#ifdef KZ_EXPERIMENTS
     const char *nb_env = getenv("KZ_TOWER_NB");
     e->nb4 = e->resident && nb_env && atoi(nb_env) == 4;
     if (e->nb4) e->fused_heads = false;  // (the four-board launch has no fused heads yet)
+#endif
     const char *noboard = getenv("KZ_NO_BOARD_CONV");
     // the board-tile kernel needs enough workgroups to fill the chip (two per CU when it is busy)
     const bool board_conv_ok = !e->resident && !(noboard && noboard[0] == '1') && m.depth >= 1 &&
@@ -952,9 +1004,12 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
+        int variant = 0;
+#ifdef KZ_EXPERIMENTS
         const char *c2 = getenv("KZ_BOARD_CONV2");  // (the opt-in board-conv organisation has its own weight packing)
-        auto key = std::make_tuple(model->m.get(), device,
-                                   dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + (c2 && c2[0] == '1' ? 400 : 0),
+        variant = c2 && c2[0] == '1' ? 400 : 0;
+#endif
+        auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + variant,
                                    e->resident || e->resident32,
                                    e->fused_heads, board_conv);
         auto it = g_cache.find(key);
@@ -970,21 +1025,28 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         }
     }
 
+#ifdef KZ_EXPERIMENTS
     {
         const char *hg = getenv("KZ_HIP_GRAPH");
         e->use_graph = hg && hg[0] == '1' && !e->fused_heads && !e->fused32;
     }
+#endif
     HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[0], hipStreamNonBlocking));
     e->stream = e->slot_stream[0];
     if (e->fused_heads || e->fused32) {  // one launch per batch that touches nothing but its slot's buffers
         HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[1], hipStreamNonBlocking));
         for (int i = 2; i < KZ_ENGINE_SLOTS; i++) e->slot_stream[i] = e->slot_stream[i & 1];
-        const char *nzc = getenv("KZ_NO_ZERO_COPY");
-        e->zero_copy = !(nzc && nzc[0] == '1');
+        e->zero_copy = true;
+#ifdef KZ_EXPERIMENTS
+        const char *nzc = getenv("KZ_NO_ZERO_COPY");  // (the staged-copy variant of the one-launch paths, for A/B timing)
+        if (nzc && nzc[0] == '1') e->zero_copy = false;
+#endif
     }
     const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
     if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
+#ifdef KZ_EXPERIMENTS
     if (e->nb4 && e->dmalloc(&e->xres, kz::tower4_scratch_bytes(max_batch))) return 1;
+#endif
     const int nact = (e->resident || e->resident32 || e->pairs16) ? 1 : 3;
     for (int i = 0; i < nact; i++)
         if (e->dmalloc(&e->act[i], rows * e->cp * e->esz)) return 1;
@@ -1051,7 +1113,11 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     else if (e->resident32) per = kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
     else if (e->path == "board_conv_f16")
+#ifdef KZ_EXPERIMENTS
         wgs = e->wts->conv2 ? kz::board_conv2_workgroups(batch, m.channels) : kz::board_conv_workgroups(batch, m.h, m.w, m.channels);
+#else
+        wgs = kz::board_conv_workgroups(batch, m.h, m.w, m.channels);
+#endif
     else wgs = kz::conv_workgroups(e->dtype, batch * m.h * m.w, e->cp);
     *workgroups = wgs;
     *boards_per_workgroup = per;
@@ -1109,6 +1175,7 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
     }
     HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
+#ifdef KZ_EXPERIMENTS
     if (e->graph_mode()) {
         s.epoch = kz_engine::GRAPH_EPOCH;
         e->nf_flag = reinterpret_cast<int *>(s.d_sout);
@@ -1118,10 +1185,14 @@ KZ_API int kz_engine_submit_packed(kz_engine *e, int slot, const uint8_t *bits, 
                 return e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol);
             }))
             return 1;
-    } else {
+    } else
+#endif
+    {
         e->arm(s);
         if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol)) return 1;
+#ifdef KZ_EXPERIMENTS
         e->graph_warm = true;  // (the first pass runs eagerly: lazy per-kernel set-up must not land in a capture)
+#endif
     }
     HIP_TRY(hipMemcpyAsync(s.h_sout, s.d_sout, ((size_t)batch * 5 + kz_engine::SOUT_HDR) * 4, hipMemcpyDeviceToHost,
                            e->stream));
@@ -1316,17 +1387,17 @@ KZ_API int kz_engine_enqueue_packed_device(kz_engine *e, const void *d_bits, siz
     if (bits_stride < (size_t)(m.n_bool * m.h * m.w + 7) / 8)
         return fail("kz_engine_enqueue_packed_device: bits_stride too small");
     HIP_TRY(hipSetDevice(e->device));
-    e->nf_flag = e->d_devflag;
-    e->nf_epoch = ++e->epoch;
+    e->arm_device();
+#ifdef KZ_EXPERIMENTS
     if (e->graph_mode()) {
         e->nf_epoch = kz_engine::GRAPH_EPOCH;
         return e->replay(-1, batch, d_bits, bits_stride, d_scalars_in, d_scalars_out, d_policy_out, [&]() -> int {
             return e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
         });
     }
-    const int rc = e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
     e->graph_warm = true;
-    return rc;
+#endif
+    return e->forward_packed(d_bits, bits_stride, d_scalars_in, batch, d_scalars_out, d_policy_out);
 }
 
 KZ_API int kz_engine_enqueue_dense_device(kz_engine *e, const void *d_input_nchw, int batch, void *d_scalars_out,
@@ -1335,8 +1406,7 @@ KZ_API int kz_engine_enqueue_dense_device(kz_engine *e, const void *d_input_nchw
     if (batch == 0) return 0;
     if (!d_input_nchw || !d_scalars_out || !d_policy_out) return fail("kz_engine_enqueue_dense_device: null argument");
     HIP_TRY(hipSetDevice(e->device));
-    e->nf_flag = e->d_devflag;
-    e->nf_epoch = ++e->epoch;
+    e->arm_device();
     return e->forward_dense(d_input_nchw, batch, d_scalars_out, d_policy_out);
 }
 

@@ -190,7 +190,7 @@ void launch_tower32(const Tower32Args &a, hipStream_t stream);
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split);
 int tower_split_boards_per_workgroup(int h, int w, int channels, bool split);
 size_t tower_split_weight_elems(int channels, int depth, bool split = true);  // f16 elements
-void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, bool split, uint16_t *dst);
+void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool stem, bool split, uint16_t *dst);
 void launch_tower_split(const Tower32Args &a, hipStream_t stream);
 // the same launch without the lo halves (split = false): plain f16 arithmetic, x0 and y are f16 tensors behind the
 // float pointers of Tower32Args — the board-resident f16 tower for the shapes kz_tower.hip does not take

@@ -389,8 +389,9 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     }
 }
 
+#ifdef KZ_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (opt-in: KZ_SPLIT_MFMA32=1 for KZ_DTYPE_F32_SPLIT16, KZ_F16G_MFMA32=1 for the plain-f16 launch; read once,
+// EXPERIMENT (libkzhip_exp.so only; opt-in: KZ_SPLIT_MFMA32=1 for KZ_DTYPE_F32_SPLIT16, KZ_F16G_MFMA32=1 for the plain-f16 launch; read once,
 // the weight packing and the launch must agree): the 256-channel launch on 64 pixel rows on v_mfma_f32_32x32x16_f16.
 // The f16 matrix cores are power-limited on this data, and in a loop of nothing but MFMAs on
 // register-resident operands a 32x32x16 stream sustains 1.79 PFLOP/s against 1.63 for 16x16x32
@@ -728,9 +729,9 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split32(SplitDev a) 
     }
 }
 
-// KZ_SPLIT_MFMA16=1: the 256-channel split launch through the 16x16x32 kernel (same-box A/B); read once — the weight
-// packing and the launch must agree
-bool split_uses_32x32(int channels, bool split) {
+// KZ_SPLIT_MFMA32=1 / KZ_F16G_MFMA32=1: the 256-channel, 64-row launch (nt == 4) through the 32x32x16 kernel (same-box
+// A/B); read once — the weight packing and the launch must agree, so both ask with the same (channels, nt)
+bool split_uses_32x32(int channels, int nt, bool split) {
     static const bool split_on = [] {
         const char *e = getenv("KZ_SPLIT_MFMA32");
         return e && e[0] == '1';
@@ -739,7 +740,7 @@ bool split_uses_32x32(int channels, bool split) {
         const char *e = getenv("KZ_F16G_MFMA32");
         return e && e[0] == '1';
     }();
-    return channels == 256 && (split ? split_on : plain_on);
+    return channels == 256 && nt == 4 && (split ? split_on : plain_on);
 }
 
 template <bool SPLIT>
@@ -754,6 +755,7 @@ void launch32(const SplitDev &d, int grid, hipStream_t stream) {
     }
     kz_tower_resident_split32<SPLIT><<<grid, 256, Geo<256, 4, SPLIT>::LDS_BYTES, stream>>>(d);
 }
+#endif  // KZ_EXPERIMENTS
 
 int split_tiles_for(int hw, int channels, bool split) {
     // (the plain-f16 launch has half the LDS footprint: 256 channels fit up to 96 squares — Go 9x9)
@@ -914,11 +916,13 @@ size_t tower_split_weight_elems(int channels, int depth, bool split) {  // f16 e
 // OIHW f32 (BN folded) -> k-steps of [hi | lo][wave 4][ot C/64][lane 64][8] f16; element j of lane (fr, kq) of (wave, ot)
 // is W[oc = 16*(wave*C/64 + ot) + fr][channel][tap], channel = 8*chunk + {0, C/2, C/4, 3C/4}[kq] + j for a tower layer (one
 // k-step per tap and chunk of 32 channels) and 8*kq + j for the stem (one k-step per tap, 32 padded input channels).
-void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, bool split, uint16_t *dst) {
+void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool stem, bool split, uint16_t *dst) {
     const int kq_base[4] = {0, cout / 2, cout / 4, 3 * cout / 4};  // tower layers: cin == cout
     const int nchunk = stem ? 1 : cin / 32, ot_n = cout / 64;
     const size_t part = (size_t)cout * 32;  // f16 elements of the hi (or lo) half of a k-step
-    if (split_uses_32x32(cout, split)) {
+    (void)hw;
+#ifdef KZ_EXPERIMENTS
+    if (split_uses_32x32(cout, split_tiles_for(hw, cout, split), split)) {
         // kz_tower_resident_split32: [hi | lo][wave 4][f 4][lane 64][8]; fragment f = 2 o + half, lane (n, kg): output
         // channel 64 wave + 32 o + n, piece q = 2 half + kg of the k-step: channel 8 chunk + kq_base[q] + j (stem: 8 q + j)
         for (int tap = 0; tap < 9; tap++)
@@ -944,6 +948,7 @@ void tower_split_pack_weights(const float *oihw, int cout, int cin, bool stem, b
             }
         return;
     }
+#endif
     for (int tap = 0; tap < 9; tap++)
         for (int chunk = 0; chunk < nchunk; chunk++) {
             uint16_t *step = dst + ((size_t)tap * nchunk + chunk) * (split ? 2 : 1) * part;
@@ -995,8 +1000,11 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
     const int grid = (t.batch + d.nb - 1) / d.nb;
     if (split) {
-        if (t.channels == 256 && split_uses_32x32(256, true)) launch32<true>(d, grid, stream);
-        else if (t.channels == 256) launch<256, 4, true>(d, grid, stream);
+#ifdef KZ_EXPERIMENTS
+        if (split_uses_32x32(t.channels, nt, true)) launch32<true>(d, grid, stream);
+        else
+#endif
+        if (t.channels == 256) launch<256, 4, true>(d, grid, stream);
         else if (t.channels == 128 && nt == 7) launch<128, 7, true>(d, grid, stream);
         else if (t.channels == 128 && nt == 6) launch<128, 6, true>(d, grid, stream);
         else if (t.channels == 128) launch<128, 4, true>(d, grid, stream);
@@ -1004,8 +1012,11 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else if (nt == 6) launch<64, 6, true>(d, grid, stream);
         else launch<64, 4, true>(d, grid, stream);
     } else {
-        if (t.channels == 256 && nt == 4 && split_uses_32x32(256, false)) launch32<false>(d, grid, stream);
-        else if (t.channels == 256 && nt == 6) launch<256, 6, false>(d, grid, stream);
+#ifdef KZ_EXPERIMENTS
+        if (split_uses_32x32(t.channels, nt, false)) launch32<false>(d, grid, stream);
+        else
+#endif
+        if (t.channels == 256 && nt == 6) launch<256, 6, false>(d, grid, stream);
         else if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 7) launch<128, 7, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 6) launch<128, 6, false>(d, grid, stream);

@@ -55,6 +55,22 @@ def test_flops_match_baseline_md():
     assert abs(go.info.flops_per_eval / 34.13e9 - 1) < 3e-3
 
 
+def test_environment_switches_are_exactly_the_documented_ones():
+    """include/kz_hip.h promises a complete list of the environment switches libkzhip.so reads: compare it with the
+    KZ_* strings of the built library.  Experiments and ablation knobs live in libkzhip_exp.so only."""
+    import subprocess
+    text = open(HEADER).read()
+    block = text[text.index("Environment switches read by kz_engine_create"):text.index("Name of the path the engine chose")]
+    documented = set(re.findall(r"^ \*   (KZ_[A-Z0-9_]+)=", block, flags=re.M))
+    out = subprocess.run(["strings", "-n", "4", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    constants = {"KZ_DTYPE_F32", "KZ_DTYPE_F16", "KZ_DTYPE_F32_SPLIT16"}  # named in error messages, not read from the environment
+    in_library = set(re.findall(r"\bKZ_[A-Z0-9_]+\b", out)) - constants
+    assert documented == in_library, (sorted(documented), sorted(in_library))
+    assert len(documented) <= 6
+    for needle in ("ABLATE", "LDS_MIN", "KZ_HIP_GRAPH", "KZ_BOARD_CONV2", "MFMA32", "launch_tower_resident4", "kz_board_conv2"):
+        assert needle not in out, needle
+
+
 def test_model_load_from_path(tmp_path):
     p = tmp_path / "m.kzm"
     p.write_bytes(O.load_blob("ataxx7_2x16"))
