@@ -354,7 +354,7 @@ def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm):
         w.close()
 
 
-def seam_record(blob, seconds):
+def seam_record(blob, seconds, devices=(0,)):
     """BASELINE configs[2] as the reference runs it: generator threads -> job channel -> executor loop
     (`RunCondition::JobCount`, sizing of server_alphazero.rs:47-55) -> `HipNetwork::evaluate_batch` (host encode, the
     engine over PCIe, host decode_output) -> replies, counted like the collector's `real` evals/s.  The host side is the
@@ -374,8 +374,8 @@ def seam_record(blob, seconds):
         with open(path, "wb") as f:
             f.write(blob)
         try:
-            out = subprocess.run([exe, path, str(seconds), "1", "6", "256", "8", "f16", "3", "0"], capture_output=True,
-                                 text=True, timeout=120)
+            out = subprocess.run([exe, path, str(seconds), "1", "6", "256", "8", "f16", "3", "0",
+                                  ",".join(str(d) for d in devices)], capture_output=True, text=True, timeout=120)
         finally:
             os.unlink(path)
         rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -384,22 +384,50 @@ def seam_record(blob, seconds):
                 "executor_threads": rec["gpu_threads"], "pipeline_depth": rec["pipeline_depth"],
                 "generator_threads": rec["generator_threads"], "concurrent_games": rec["concurrent_games"],
                 "gpu_batch": rec["gpu_batch"], "search_batch": rec["search_batch"], "seconds": rec["seconds"],
+                "devices": rec.get("devices"), "per_device_evals_per_s": rec.get("per_device_evals_per_s"),
                 "host": "C++ mirror of the Rust seam (kzero_amd/csrc/host), tests/cpp/bench_executor.cpp"}
     except Exception as ex:  # noqa: BLE001 (diagnostic record only)
         return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
-def fake_main(args, benchlib, rank, world, dist):
-    """--fake-step: the launcher and aggregation without a GPU (tests/test_bench_launcher.py)."""
+def select_device(benchlib, dist, rank, local_rank, world, ndev, bus_id_of):
+    """The device this rank drives and every rank's PCI bus id, or (None, message): LOCAL_RANK among the visible GPUs, or
+    the single visible GPU of a rank whose launcher masked the others; the ranks must report `world` distinct bus ids."""
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    device, why = benchlib.pick_device(ndev, local_rank, local_world)
+    # every rank takes part in the gather, also one that has no device: nobody may be left waiting in a collective
+    seen = benchlib.gather_strings(dist, bus_id_of(device) if device is not None else f"none:{rank}")
+    if device is None:
+        return None, seen, f"bench.py: {why}"
+    bad = benchlib.check_distinct(seen, world)
+    if any(x.startswith("none:") for x in seen):
+        bad = bad or f"a rank has no GPU: {seen}"
+    return (None, seen, f"bench.py: {bad}") if bad else (device, seen, None)
+
+
+def fake_main(args, benchlib, rank, local_rank, world, dist):
+    """--fake-step: the launcher, the device selection and the aggregation without a GPU (tests/test_bench_launcher.py).
+    KZ_FAKE_NDEV = GPUs every rank "sees" (default: one per rank); a fake GPU's bus id is its index behind
+    HIP_VISIBLE_DEVICES, so a per-rank mask gives distinct ids and a shared one collides."""
+    ndev = int(os.environ.get("KZ_FAKE_NDEV", os.environ.get("LOCAL_WORLD_SIZE", world)))
+    device, seen, err = select_device(benchlib, dist, rank, local_rank, world, ndev,
+                                      lambda d: f"fake:{benchlib.visible_index(d)}")
+    if err:
+        print(err, file=sys.stderr)
+        return 3
+
     def step(i):
-        time.sleep(args.fake_step * 1e-3)
-    elapsed = benchlib.run_timed(step, lambda: None, args.steps, args.warmup, dist)
-    seen = benchlib.gather_strings(dist, f"fake:{rank}")
+        time.sleep(args.fake_step * 1e-3 * (1 + rank))  # (rank r is r+1 times slower: the per-rank lines must show it)
+    own = []
+    elapsed = benchlib.run_timed(step, lambda: None, args.steps, args.warmup, dist, own=own)
+    per_rank = benchlib.gather_objects(dist, {"rank": rank, "device": device, "bus_id": seen[rank],
+                                              "evals_s": round(args.steps / own[0], 3)})
     if rank == 0:
         print(json.dumps({"metric": "fake steps/sec (launcher test)", "value": round(args.steps * world / elapsed, 3),
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "fake", "devices_seen": sorted(set(seen)),
+                          "per_rank": per_rank,
                           "config": {"workload": "sleep", "parallelism": f"dp{world} (no collective)"}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -419,29 +447,36 @@ def main():
         import torch  # noqa: F401  (control plane only; imported before the HIP library on purpose)
     dist = benchlib.init_control_plane()
     if args.fake_step is not None:
-        return fake_main(args, benchlib, rank, world, dist)
+        return fake_main(args, benchlib, rank, local_rank, world, dist)
+
+    # NUMA: before the first HIP call, pin this rank to the CPUs next to its GPU (bus id from the KFD topology in sysfs):
+    # the executor threads and the zero-copy pinned staging (first touched by the allocating thread) then sit on the
+    # GPU's node.  A rank whose launcher masked the other GPUs drives ordinal 0 of its mask.
+    masked = len((os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or "").split(",")) == 1 \
+        and bool(os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
+    numa = benchlib.bind_to_gpu_numa(0 if masked else local_rank)
 
     from kzero_amd import capi, synth
     ndev = capi.device_count()
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    if ndev < local_world or local_rank >= ndev:
-        # never fold several ranks onto one GPU: a scaling curve measured that way would be wrong without any error
-        print(f"bench.py: rank {rank} needs device {local_rank} of {local_world} on this node, but only {ndev} GPU(s) "
-              f"are visible", file=sys.stderr)
+    # never fold several ranks onto one GPU: a scaling curve measured that way would be wrong without any error
+    device, devices_seen, err = select_device(benchlib, dist, rank, local_rank, world, ndev, capi.device_pci_bus_id)
+    if err:
+        print(f"{err} (rank {rank}, {ndev} GPU(s) visible)", file=sys.stderr)
         return 3
-    device = local_rank
-    devices_seen = benchlib.gather_strings(dist, capi.device_pci_bus_id(device))
-    if len(set(devices_seen)) != world:
-        print(f"bench.py: {world} ranks on {len(set(devices_seen))} distinct GPUs: {devices_seen}", file=sys.stderr)
-        return 3
+    if numa["bus_id"] is None or numa["bus_id"].lower() != devices_seen[rank].lower():
+        # the sysfs guess was not available (or wrong): bind now, from the bus id HIP reports — later than intended
+        numa = dict(benchlib.bind_to_gpu_numa(device, bus_id=devices_seen[rank]), bound_before_first_hip_call=False)
+    else:
+        numa["bound_before_first_hip_call"] = numa["bound"]
 
     w = Workload(capi, synth, args.workload, args.dtype, args.batch, args.engines, device, benchlib.board_seed(rank))
     B = args.batch
 
     # ---- timed region 1 (`value`): inputs resident in HBM, outputs left in HBM ----
     w.condition(w.step_resident, args.prewarm)
+    own, h_own = [], []
     elapsed = benchlib.run_timed(w.step_resident, w.sync, args.steps, args.warmup, dist,
-                                 on_timed_start=lambda: w.profiling(True))
+                                 on_timed_start=lambda: w.profiling(True), own=own)
     k_ms, k_n = w.kernel_time()
     w.profiling(False)
     w.check_finite()
@@ -452,7 +487,7 @@ def main():
     if not args.no_host_io:
         w.condition(w.step_host, min(args.prewarm, 0.1))
         h_elapsed = benchlib.run_timed(w.step_host, w.sync, args.steps, args.warmup, dist,
-                                       on_timed_start=lambda: w.profiling(True))
+                                       on_timed_start=lambda: w.profiling(True), own=h_own)
         h_ms, h_n = w.kernel_time()
         w.profiling(False)
         h_value = benchlib.whole_job_value(args.steps, B, world, h_elapsed)
@@ -467,9 +502,17 @@ def main():
                 "kernel_avg_launch_ms": round(h_ms / max(h_n, 1), 5),
                 "chip_frac": round(h_value / world * info.flops_per_eval / 1e12 / (157.3 if args.dtype == "f32" else 2500.0), 4)}
 
+    # every rank's own line (a slow rank — NUMA, thermals, a bad link — must be visible next to the aggregate)
+    per_rank = benchlib.gather_objects(dist, {
+        "rank": rank, "device": device, "bus_id": devices_seen[rank], "numa_node": numa["numa_node"],
+        "numa_bound": numa["bound"], "numa_bound_before_first_hip_call": numa.get("bound_before_first_hip_call", False),
+        "host_cpus": numa["cpus"], "evals_s": round(args.steps * B / own[0], 1),
+        "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
+        "pcie_inclusive_evals_s": round(args.steps * B / h_own[0], 1) if h_own else None})
     if rank != 0:
         w.close()
         if dist is not None:
+            dist.barrier()  # (rank 0's one-process seam run starts once every rank has released its GPU)
             dist.destroy_process_group()
         return 0
 
@@ -487,6 +530,7 @@ def main():
                    "device_resident_evals_s": round(value, 1),
                    "pcie_inclusive_evals_s": host["value"] if host else None},
         "devices_seen": sorted(set(devices_seen)),
+        "per_rank": per_rank,
         "roofline": w.roofline(k_ms, k_n, args.steps, value / world),
     }
     if host:
@@ -497,6 +541,12 @@ def main():
         out["others"] = [sub_record(capi, synth, n, d, device, args.other_seconds, args.prewarm) for n, d in OTHERS]
     if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
         out["seam"] = seam_record(blob, args.seam_seconds)
+    if world > 1:
+        dist.barrier()  # every rank has closed its engines
+        if args.is_default_line and not args.no_seam and not args.no_others:
+            # the topology the reference and the Rust drop-in use: ONE process, a thread set per device
+            # (rust/kz-selfplay/src/server/server.rs:323-331) over every GPU this rank can see
+            out["seam_one_process"] = seam_record(blob, args.seam_seconds, devices=list(range(ndev)))
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(blob, bits, scalars_in, args.cpu_seconds)
     print(json.dumps(out), flush=True)

@@ -53,10 +53,142 @@ def board_seed(rank: int) -> int:
     return 1000 + rank
 
 
+def gather_objects(dist, obj):
+    """Every rank's (picklable) record, in rank order, on every rank — the per-rank lines of an N > 1 run."""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# which GPU a rank drives, and where its host threads and pinned staging should live
+# ------------------------------------------------------------------------------------------------------------------
+def pick_device(ndev: int, local_rank: int, local_world: int):
+    """(device ordinal, None) or (None, message).  Every rank normally sees all GPUs of the node and takes ordinal
+    LOCAL_RANK.  A launcher that masks visibility per rank (HIP_VISIBLE_DEVICES=$LOCAL_RANK, common under torchrun
+    wrappers) leaves every rank with ONE visible GPU: take ordinal 0 and let the distinct-PCI-bus-id check across ranks
+    (check_distinct) decide whether the ranks really sit on different devices.  Anything else would fold several ranks
+    onto one GPU — a scaling curve measured that way is wrong without any error — and is refused."""
+    if ndev >= local_world and local_rank < ndev:
+        return local_rank, None
+    if ndev == 1:
+        return 0, None
+    return None, (f"rank with LOCAL_RANK {local_rank} of {local_world} on this node sees {ndev} GPU(s): neither one per "
+                  f"rank nor a single masked device")
+
+
+def check_distinct(bus_ids, world: int):
+    """None when the `world` ranks reported `world` distinct PCI bus ids, else the message to fail with."""
+    if len(set(bus_ids)) == world:
+        return None
+    return f"{world} ranks on {len(set(bus_ids))} distinct GPU(s): {list(bus_ids)}"
+
+
+def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes"):
+    """PCI bus ids ("0000:c1:00.0") of the GPU nodes in KFD topology order — the order HIP enumerates devices in before
+    HIP_VISIBLE_DEVICES is applied — read from sysfs, so that a rank can find its GPU's NUMA node BEFORE its first HIP
+    call.  [] when the topology is not readable."""
+    out = []
+    try:
+        nodes = sorted((int(n) for n in os.listdir(root) if n.isdigit()))
+    except OSError:
+        return out
+    for n in nodes:
+        props = {}
+        try:
+            for line in open(os.path.join(root, str(n), "properties")):
+                k, _, v = line.strip().partition(" ")
+                props[k] = v
+        except OSError:
+            continue
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue  # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        except (KeyError, ValueError):
+            continue
+        out.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
+    return out
+
+
+def visible_index(ordinal: int, env=None):
+    """KFD-order index of HIP ordinal `ordinal` under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (integer lists only;
+    None when a mask is present that this cannot interpret, e.g. UUIDs or both masks at once)."""
+    env = os.environ if env is None else env
+    hip, rocr = env.get("HIP_VISIBLE_DEVICES", env.get("CUDA_VISIBLE_DEVICES")), env.get("ROCR_VISIBLE_DEVICES")
+    if hip and rocr:
+        return None
+    mask = hip or rocr
+    if not mask:
+        return ordinal
+    try:
+        ids = [int(x) for x in mask.split(",") if x.strip() != ""]
+    except ValueError:
+        return None
+    return ids[ordinal] if 0 <= ordinal < len(ids) else None
+
+
+def numa_node_of(bus_id: str, root: str = "/sys/bus/pci/devices"):
+    try:
+        n = int(open(os.path.join(root, bus_id.lower(), "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None
+    return n if n >= 0 else None
+
+
+def node_cpus(node: int, root: str = "/sys/devices/system/node"):
+    """CPUs of a NUMA node from its cpulist ("0-63,128-191")."""
+    try:
+        txt = open(os.path.join(root, f"node{node}", "cpulist")).read().strip()
+    except OSError:
+        return set()
+    cpus = set()
+    for part in txt.split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa(ordinal: int, bus_id: str = None, kfd_root: str = "/sys/class/kfd/kfd/topology/nodes",
+                     pci_root: str = "/sys/bus/pci/devices", node_root: str = "/sys/devices/system/node", env=None,
+                     apply: bool = True):
+    """Pins this process to the CPUs of the NUMA node its GPU hangs off, so that the executor threads run and the
+    zero-copy pinned staging (hipHostMalloc, first touched by the allocating thread) lands next to the device.  Call it
+    before the first HIP call with `bus_id=None` (the bus id is then taken from the KFD topology); call it again with
+    the bus id HIP reports to verify/correct.  Returns a record for the bench line; never raises."""
+    rec = {"bus_id": bus_id, "numa_node": None, "cpus": None, "bound": False}
+    try:
+        if bus_id is None:
+            idx = visible_index(ordinal, env)
+            ids = kfd_gpu_bus_ids(kfd_root)
+            if idx is None or idx >= len(ids):
+                return rec
+            bus_id = rec["bus_id"] = ids[idx]
+        node = numa_node_of(bus_id, pci_root)
+        rec["numa_node"] = node
+        if node is None:
+            return rec
+        cpus = node_cpus(node, node_root)
+        allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set()
+        target = cpus & allowed
+        rec["cpus"] = len(target)
+        if target and apply and hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, target)
+            rec["bound"] = True
+    except (OSError, ValueError):
+        pass
+    return rec
+
+
 def run_timed(step: Callable[[int], None], sync: Callable[[], None], steps: int, warmup: int, dist=None,
-              on_timed_start: Optional[Callable[[], None]] = None) -> float:
+              on_timed_start: Optional[Callable[[], None]] = None, own: Optional[list] = None) -> float:
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + device sync on both sides.
-    Returns the MAX over ranks of the elapsed seconds."""
+    Returns the MAX over ranks of the elapsed seconds; `own`, when given, receives this rank's own time from the start
+    barrier to the end of its last step (before the closing barrier): what tells a slow rank from a fast one."""
     for i in range(warmup):
         step(i)
     sync()
@@ -69,6 +201,8 @@ def run_timed(step: Callable[[int], None], sync: Callable[[], None], steps: int,
     for i in range(steps):
         step(i)
     sync()
+    if own is not None:
+        own.append(time.perf_counter() - t0)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0

@@ -124,10 +124,15 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
 template <class B, class M, class Net = HipNetwork<B, M>, class GraphT = std::shared_ptr<const HipModel>>
 std::vector<std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>>> spawn_all_devices(const std::vector<int> &devices,
                                                                                      const StartupSettings &startup, M mapper,
-                                                                                     int dtype, EvalCounters *counters) {
+                                                                                     int dtype, EvalCounters *counters,
+                                                                                     EvalCounters *per_device = nullptr) {
+    // per_device: optional array of devices.size() counters, one per device, instead of the shared one (measurement only:
+    // the reference's collector sums all devices, collector.rs:172-191)
     if (devices.empty()) throw std::invalid_argument("No devices found");  // server.rs:53, :314
     std::vector<std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>>> all;
-    for (int device : devices) all.push_back(spawn_device_executors<B, M, Net, GraphT>(device, startup, mapper, dtype, counters));
+    for (size_t i = 0; i < devices.size(); i++)
+        all.push_back(spawn_device_executors<B, M, Net, GraphT>(devices[i], startup, mapper, dtype,
+                                                                per_device ? &per_device[i] : counters));
     return all;
 }
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
             const int r = i / pieces, p = i - r * pieces;
             f32x4 v = f32x4{0, 0, 0, 0};
             if (r < rows_valid) {
-                if (a.bits) {  // F0 (rust/kz-core/src/mapping/bit_buffer.rs + cuda_network.rs:110-123): scalar planes, then bit planes
+                if (a.bits) {  // F0 (rust/kz-core/src/mapping/mod.rs:40-63, bit order bit_buffer.rs:73-75): scalar planes, then bit planes
                     const int bb = (int)(((unsigned)r * a.inv_hw) >> 16), q = r - bb * a.hw;
                     const uint8_t *bits = a.bits + (size_t)(board0 + bb) * a.bits_stride;
 #pragma unroll
@@ -461,10 +461,12 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
             }
         }
         __syncthreads();
-        if (tid < a.nb * a.hs) {
-            float s = b1v;
-            for (int seg = 0; seg < nseg; seg++) s += sred[seg * a.nb * a.hs + tid];
-            shid[tid] = fmaxf(s, 0.0f);
+        // (nb * hs may exceed the 256 threads — e.g. three 6x6 boards with a hidden size of 96: every hidden unit of every
+        // board gets a turn; the first turn's bias was fetched before the small convolutions)
+        for (int o = tid; o < a.nb * a.hs; o += 256) {
+            float s = o == tid ? b1v : a.sh_b1[o % a.hs];
+            for (int seg = 0; seg < nseg; seg++) s += sred[seg * a.nb * a.hs + o];
+            shid[o] = fmaxf(s, 0.0f);
         }
         __syncthreads();
         if (tid < boards * 5) {

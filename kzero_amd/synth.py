@@ -20,6 +20,8 @@ GAMES = {
     # name: (board, scalar planes, bool planes, policy_len fn)
     "chess": dict(size=8, n_scalar=8, n_bool=13, policy_len=1880, p_bool=0.04),      # chess.rs:125-171
     "ataxx-7": dict(size=7, n_scalar=1, n_bool=3, policy_len=17 * 49 + 1, p_bool=0.3),  # ataxx.rs:93-116
+    "ataxx-5": dict(size=5, n_scalar=1, n_bool=3, policy_len=17 * 25 + 1, p_bool=0.3),  # (AtaxxBoard sizes 2..8)
+    "ataxx-6": dict(size=6, n_scalar=1, n_bool=3, policy_len=17 * 36 + 1, p_bool=0.3),
     "go-19": dict(size=19, n_scalar=6, n_bool=7, policy_len=1 + 361, p_bool=0.25),   # go.rs:46-113 (territory on)
     "go-9": dict(size=9, n_scalar=6, n_bool=7, policy_len=1 + 81, p_bool=0.25),
 }
@@ -57,7 +59,9 @@ def _bn(rng, t, prefix, c):
 
 
 def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0, query_channels: int = None,
-                 n_bool: int = None) -> bytes:
+                 n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0) -> bytes:
+    """`block_gain` > 1 scales every block's second BatchNorm weight: the residual stream then grows from block to block
+    the way a trained network's does (a random-init tower keeps it within a few tens)."""
     g = GAMES[game]
     size, n_scalar = g["size"], g["n_scalar"]
     n_bool = g["n_bool"] if n_bool is None else n_bool
@@ -68,7 +72,7 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
         "game": game, "board_h": size, "board_w": size,
         "input_scalar_channels": n_scalar, "input_bool_channels": n_bool,
         "tower_depth": depth, "tower_channels": C, "tower_final_affine": 1,
-        "scalar_hidden_channels": 4, "scalar_hidden_size": 32,
+        "scalar_hidden_channels": 4, "scalar_hidden_size": scalar_hidden_size,
         "policy_kind": head, "policy_len": g["policy_len"], "bn_eps": 1e-5,
     }
     _conv(rng, t, "common.tower.0", C, n_scalar + n_bool, 3)
@@ -82,10 +86,12 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
         _bn(rng, t, f"common.tower.{i}.seq.1", C)
         _conv(rng, t, f"common.tower.{i}.seq.3", C, C, 3)
         _bn(rng, t, f"common.tower.{i}.seq.4", C)
+        if block_gain != 1.0:
+            t[f"common.tower.{i}.seq.4.weight"] *= np.float32(block_gain)
     _bn(rng, t, f"common.tower.{depth + 1}", C)
     _conv(rng, t, "scalar_head.seq.0", 4, C, 1)
-    _linear(rng, t, "scalar_head.seq.3", 32, 4 * hw)
-    _linear(rng, t, "scalar_head.seq.5", 5, 32)
+    _linear(rng, t, "scalar_head.seq.3", scalar_hidden_size, 4 * hw)
+    _linear(rng, t, "scalar_head.seq.5", 5, scalar_hidden_size)
     if head == "ataxx_conv":
         meta["policy_conv_channels"] = 17
         _conv(rng, t, "policy_head.seq.0", C, C, 1)
