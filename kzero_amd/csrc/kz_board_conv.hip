@@ -17,7 +17,10 @@
 //               [32,64)) of rows x 80 B, a multiple of 256 B apart: the two lane groups that share a ds_read_b128
 //               bank group read the two planes at the same row offset and rows advance by 5 sixteen-byte slots ->
 //               conflict-free fragment reads, except one 2-way pair in tiles that cross a line end.  Go: 66 KB.
-//   registers = 96 accumulators + 24 fragment + 48 weight ring: < 256, two waves per SIMD.
+//   registers = 96 accumulators + 24 fragment + 48 weight ring: < 256, two waves per SIMD.  The ring's 48 registers are
+//               also the staging buffer: during the last PF k-steps of a chunk a ring stage that has fed its MFMAs is not
+//               refilled with weights but with this thread's 12 pieces of the NEXT chunk's image (or, in the last chunk,
+//               of the residual), so those loads fly under the MFMAs instead of behind a barrier.
 //   grid      = 1-D, XCD-aware: the cout/64 workgroups of one board group run on ONE XCD back to back, so the
 //               image is read from HBM once and from that XCD's L2 by the others.
 #include <cstdio>
@@ -70,6 +73,9 @@ __device__ __forceinline__ h16x8 lds_frag(int addr) {
 }
 
 constexpr int SG_MFMA = 0x8, SG_DS_READ = 0x100;
+#ifndef KZ_BC_STORE_AUX
+#define KZ_BC_STORE_AUX 0  // cache policy bits of the output stores (diagnostic builds: 2 = nt)
+#endif
 
 // Diagnostic build only (-DKZ_BC_STAMPS): s_memtime stamps at the phase boundaries of every wave, dumped by the
 // launcher to $KZ_BC_STAMP_FILE after the 20th launch.  No stamp executes in the real kernel.
@@ -92,12 +98,13 @@ struct BoardConvDev {
     const float *bias, *post_scale, *post_shift;  // [cout]
     const h16 *res;     // optional residual [boards*hw][ld]
     h16 *y;             // [boards*hw][ld]
-    int bytes;          // size of each of those tensors: boards * hw * ld * 2 (< 2^31)
+    int bytes;          // size of y (and of the residual): boards * hw * ld * 2 (< 2^31)
+    int bytes_x, ldx;   // the input's: ldx == ld unless the convolution has a single chunk (the stem: 64 input channels)
     int ld, boards, h, w_, hw, tpb, bpw, cin, relu, groups, nq;
-    const int *rowmap;             // [384] tile row -> board << 20 | pixel << 10 | image row, or -1 (padding row)
-    const unsigned short *halo;   // [n_halo] image rows that are halo (zeroed once per workgroup)
-    int n_halo;
+    unsigned inv_tpb, inv_w, inv_nhb;  // ceil(65536 / tpb), / w, / (halo rows per board): exact quotients for the small
+                                       // values they meet
     int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
+    int rm_off;             // LDS offset of the 384 image-row indices (u16), behind the image / the epilogue's output tile
     unsigned long long *stamps;  // diagnostic build only
 };
 
@@ -134,13 +141,42 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const int chunks = a.cin / CH;
     const int total_ksteps = chunks * KPC;
 
-    // host-built tile-row map (no divisions here), fetched first so that its latency hides behind the ring fill and
-    // the halo clear: the 12 (pixel row, piece) slots this thread copies and the 6 fragment rows of this lane
-    int emap[12], emapT[MTW];
+    // ---- set-up, ordered by latency: (1) this thread's 12 image pieces of chunk 0 are requested FIRST — everything about
+    // a tile row (board, pixel, image row) is arithmetic on the thread id, no table is read — (2) then the weight ring,
+    // (3) then, under those loads, the halo clear, the fragment rows and the accumulators.
+    // Slot i of a thread = tile row (tid >> 3) + 32 i, 16-byte piece tid & 7 of its 64 channels; the same 12 slots serve
+    // the staging of every chunk, the residual and the output stores.
+    const int piece = tid & 7;
+    const int ls_piece = (piece >> 2) * a.plane + (piece & 3) * 16;
+    // tile row r -> board b (of this workgroup), pixel q, image row; false for a padding row or a board beyond the batch
+    // (every factor is below 2^24: v_mul_u32_u24 / v_mad_u32_u24 run at full rate, a 32-bit v_mul_lo_u32 at a quarter)
+    auto locate = [&](int r, int &b, int &q, int &irow) __attribute__((always_inline)) {
+        const int mt = r >> 4;
+        b = (int)(__umul24((unsigned)mt, a.inv_tpb) >> 16);           // mt / tpb (exact: mt < 24)
+        q = (mt - (int)__umul24((unsigned)b, (unsigned)a.tpb)) * 16 + (r & 15);
+        const int yy = (int)(__umul24((unsigned)q, a.inv_w) >> 16);   // q / w (exact: q < 512, w <= 32)
+        irow = (int)(__umul24((unsigned)b, (unsigned)a.rpb) + __umul24((unsigned)(yy + 1), (unsigned)a.pitch)) +
+               (q - (int)__umul24((unsigned)yy, (unsigned)a.w_)) + 1;
+        return b < a.bpw && q < a.hw && board0 + b < a.boards;
+    };
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.x), 0, a.bytes_x, 0x00020000);
+    // po[i] = byte offset of slot i in the [pixels][ld] OUTPUT tensor (the residual and, for a convolution of more than
+    // one chunk, the input have the same ld), or -1 for a padding row: 32-bit offsets on a uniform base keep the twelve
+    // addresses in twelve registers.  The image rows (where a piece goes in LDS) are not kept across the k-loops — 12
+    // registers the loop needs: they sit in LDS behind the image, 768 bytes, and are read back at every chunk boundary.
+    int po[12];
+    u32x4 v0[12];  // chunk 0
+    int irow0[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) emap[i] = a.rowmap[(tid >> 3) + i * 32];
-#pragma unroll
-    for (int i = 0; i < MTW; i++) emapT[i] = a.rowmap[(wr * MTW + i) * 16 + fr];
+    for (int i = 0; i < 12; i++) {
+        int b, q, irow;
+        const bool ok = locate((tid >> 3) + i * 32, b, q, irow);
+        irow0[i] = irow;
+        const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
+        po[i] = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
+        v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
+        if (piece == 0) *reinterpret_cast<unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2) = (unsigned short)irow;
+    }
 
     // weight ring: k-step g of this (layer, quarter): 4 KB = [nt 4][lane] x 16 B, the same for the four waves
     const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + lane;
@@ -151,44 +187,32 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) wreg[s][nt] = wp[(size_t)g * 256 + (wo * NTW + nt) * 64];
     }
-    int g = 0;
+    int g = 0;  // k-step counter; at a chunk boundary the ring holds k-steps g .. g + PF - 1
 
     KZ_STAMP(21);
     // zero the halo rows once (10 sixteen-byte pieces per row: 5 per plane); they are never written again, and the
-    // pixel rows are overwritten by every chunk
-    for (int id = tid; id < a.n_halo * 10; id += 256) {
-        const int k = (int)(((unsigned)id * 6554u) >> 16), pc = id - k * 10;  // id / 10 for id < 16384
-        *reinterpret_cast<uint4 *>(lds + (pc >= 5 ? a.plane + (pc - 5) * 16 : pc * 16) + a.halo[k] * PRS) = make_uint4(0, 0, 0, 0);
+    // pixel rows are overwritten by every chunk.  Halo row k of a board: the line above the board (k < pitch), the left
+    // neighbour of every line (the right neighbour of the line before), the line below plus one.
+    {
+        const int nhb = 2 * a.pitch + a.h + 1;  // halo rows per board
+        for (int id = tid; id < a.bpw * nhb * 10; id += 256) {
+            const int k = (int)(((unsigned)id * 6554u) >> 16), pc = id - k * 10;  // id / 10 for id < 16384
+            const int b = (int)(((unsigned)k * a.inv_nhb) >> 16), kk = k - b * nhb;
+            const int row = b * a.rpb + (kk < a.pitch ? kk : kk < a.pitch + a.h ? (kk - a.pitch + 1) * a.pitch : (a.h + 1) * a.pitch + (kk - a.pitch - a.h));
+            *reinterpret_cast<uint4 *>(lds + (pc >= 5 ? a.plane + (pc - 5) * 16 : pc * 16) + row * PRS) = make_uint4(0, 0, 0, 0);
+        }
     }
 
     KZ_STAMP(22);
-    // The 12 (pixel row, 16-byte piece) slots this thread copies, for staging and for the epilogue alike: slot i is tile
-    // row (tid >> 3) + 32 i, piece tid & 7.  po[i] = byte offset of that slot in a [pixels][ld] activation tensor
-    // (x, y and the residual share ld), or -1 for a padding row (32-bit offsets on a uniform base keep the twelve
-    // addresses in twelve registers); ls[i] = where the piece goes in the halo image.
-    const int piece = tid & 7;
-    int po[12], ls[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        const int e = emap[i];
-        const int b = e >> 20, q = (e >> 10) & 1023;
-        const bool ok = e >= 0 && board0 + b < a.boards;
-        po[i] = ok ? (((board0 + b) * a.hw + q) * a.ld + piece * 8) * 2 : -1;
-        ls[i] = (e & 1023) * PRS + (piece >> 2) * a.plane + (piece & 3) * 16;
-    }
-    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.x), 0, a.bytes, 0x00020000);
-    KZ_STAMP(23);
-
-    // Centre-tap LDS address of this lane's fragment row for each of the wave's 12 tiles (plane kq & 1, 16-byte piece
+    // Centre-tap LDS address of this lane's fragment row for each of the wave's 6 tiles (plane kq & 1, 16-byte piece
     // kq >> 1 of the k-step); a lane without a pixel (padding row, missing board) reads pixel (0, 0) of board 0 — its
     // outputs are never stored.
     int T0[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
-        const int e = emapT[i];
-        const bool valid = e >= 0 && board0 + (e >> 20) < a.boards;
-        const int row = valid ? (e & 1023) : a.pitch + 1;
-        T0[i] = row * PRS + (kq & 1) * a.plane + (kq >> 1) * 16;
+        int b, q, irow;
+        const bool valid = locate((wr * MTW + i) * 16 + fr, b, q, irow);
+        T0[i] = (valid ? irow : a.pitch + 1) * PRS + (kq & 1) * a.plane + (kq >> 1) * 16;
     }
 
     KZ_STAMP(24);
@@ -216,27 +240,37 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     };
 
     KZ_STAMP(1);
+    // (wave-uniform) this wave's sixth tile lies beyond the workgroup's last pixel tile
+#ifdef KZ_BC_NO_SKIP  // (diagnostic builds: the A/B of the padding-tile skip)
+    const bool skip_last_tile = false;
+#else
+    const bool skip_last_tile = (wr * MTW + MTW - 1) >= a.bpw * a.tpb && (wr * MTW + MTW - 2) < a.bpw * a.tpb;
+#endif
+    const bool with_res = a.res != nullptr;
+    const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res ? a.bytes : 0, 0x00020000);
+    // ---- chunk 0 into the image: channels [0, 64) of this workgroup's boards, 8 pieces of 16 B per pixel row (never
+    // into the halo: the halo clear of other threads needs no barrier in front of these writes) ----
+    KZ_STAMP(2);
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+        if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + irow0[i] * PRS + ls_piece) = v0[i];
+    KZ_STAMP(3);
     for (int chunk = 0; chunk < chunks; chunk++) {
-        // ---- stage channels [64*chunk, +64) of this workgroup's boards: 8 pieces of 16 B per pixel row ----
-        __syncthreads();  // everyone is done reading the previous chunk
-        KZ_STAMP(2 + chunk * 4);
-        {
-            // 12 pieces per thread, all in flight at once (the fragment registers are dead here)
-            u32x4 v[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++)
-                v[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], chunk * CH * 2, 0);
-#pragma unroll
-            for (int i = 0; i < 12; i++)
-                if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + ls[i]) = v[i];  // never into the halo
-        }
-        KZ_STAMP(3 + chunk * 4);
-        __syncthreads();
+        __syncthreads();  // the chunk is staged
         KZ_STAMP(4 + chunk * 4);
+        // what the ring's dying stages fetch during the last PF k-steps of this chunk: the next chunk's image pieces, or
+        // (last chunk) the residual's, or nothing
+        // (no branch in the k-loop: one descriptor and one scalar offset, selected here; without a residual the last
+        // chunk's descriptor has no records, so its tail loads return zeros without touching memory)
+        const bool last_chunk = chunk + 1 == chunks;
+        const auto trsrc = last_chunk ? rrsrc : xrsrc;
+        const int tsoff = last_chunk ? nquarter * OCW * 2 : (chunk + 1) * CH * 2;
 
         // Two half-steps per k-step: the MFMAs of tiles 0..2 run while the fragments of tiles 3..5 are read, and
         // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (the CU's second
         // workgroup) fills whatever latency is left.
+        // A wave whose sixth tile is pure padding (Go's 361 pixels are 22.6 tiles, so tile 23 — wave 3's sixth — holds
+        // none) does not issue that tile's fragment read and 4 MFMAs: 4 % of the launch's MFMA work, and of its power.
         constexpr int HT = MTW / 2;
         int T[MTW];
         h16x8 bfA[HT], bfB[HT] = {};
@@ -245,28 +279,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         tap_rows(0, 0, MTW, pitch_prs, T);
 #pragma unroll
         for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i]);
-#ifdef KZ_BC_SIMPLE  // debugging aid: the same k-loop without the half-step software pipelining
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            tap_rows(tap, 0, MTW, pitch_prs, T);
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const int stage = (tap * 2 + ks) % PF;
-#pragma unroll
-                for (int i = 0; i < MTW; i++) {
-                    const h16x8 bf = lds_frag(T[i] + ks * 32);
-#pragma unroll
-                    for (int nt = 0; nt < NTW; nt++)
-                        acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h16x8 *>(&wreg[stage][nt]),
-                                                                            bf, acc[nt][i], 0, 0, 0);
-                }
-                const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)gn * 256 + (wo * NTW + nt) * 64];
-                g++;
-            }
-        }
-#else
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int next_tap = tap < 8 ? tap + 1 : 8;
@@ -274,10 +286,9 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
             for (int ks = 0; ks < 2; ks++) {
                 const int stage = (tap * 2 + ks) % PF;
                 // ---- half 1 ----
-#ifndef KZ_BC_NO_DSREAD  // (timing experiments: a build without the fragment reads)
 #pragma unroll
-                for (int i = 0; i < HT; i++) bfB[i] = lds_frag(T[HT + i] + ks * 32);
-#endif
+                for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i] + ks * 32);
+                if (!skip_last_tile) bfB[HT - 1] = lds_frag(T[MTW - 1] + ks * 32);
                 h16x8 af[NTW];  // aliases of the ring stage (no copy: the stage is reloaded after this k-step's MFMAs)
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
@@ -286,66 +297,79 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++)
                         acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfA[i], acc[nt][i], 0, 0, 0);
-                // all three reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
-                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT, 0);
+                // the reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
+                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT - 1, 0);
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- half 2 ----
                 // T is updated in place for the next tap: rows 0..2 are dead after the last half-2 read of this tap,
                 // rows 3..5 after the half-1 read above
                 if (ks == 1) tap_rows(next_tap, 0, HT, pitch_prs, T);
-#ifndef KZ_BC_NO_DSREAD
 #pragma unroll
                 for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i] + (ks < 1 ? (ks + 1) * 32 : 0));
-#endif
                 if (ks == 1) tap_rows(next_tap, HT, MTW, pitch_prs, T);
 #pragma unroll
-                for (int i = 0; i < HT; i++)
+                for (int i = 0; i < HT - 1; i++)
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++)
                         acc[nt][HT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[i], acc[nt][HT + i], 0, 0, 0);
-                // all three reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
                 __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, (HT - 1) * NTW, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef KZ_BC_NO_WLOAD  // (timing experiments: a build without the weight stream)
-                {   // this stage's fragments have been issued to the MFMAs: refill it for k-step g + PF
-                    const int gn = g + PF < total_ksteps ? g + PF : total_ksteps - 1;
+                if (!skip_last_tile) {
 #pragma unroll
-                    for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)gn * 256 + (wo * NTW + nt) * 64];
+                    for (int nt = 0; nt < NTW; nt++)
+                        acc[nt][MTW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[HT - 1], acc[nt][MTW - 1], 0, 0, 0);
                 }
-#endif
+                __builtin_amdgcn_sched_barrier(0);
+                // this stage's fragments have been issued to the MFMAs: refill it
+                if (tap * 2 + ks < KPC - PF) {  // (compile time) with the weights of k-step g + PF
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)(g + PF) * 256 + (wo * NTW + nt) * 64];
+                } else {  // last PF k-steps: pieces 4 jj .. 4 jj + 3 of the next image chunk / the residual
+                    const int jj = tap * 2 + ks - (KPC - PF);
+                    static_assert(NTW == 4 && PF == 3, "12 pieces = PF stages x NTW registers");
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++)
+                        wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po[jj * 4 + nt], tsoff, 0));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
         }
-#endif
         KZ_STAMP(5 + chunk * 4);
+        if (!last_chunk) {
+            // ---- the next chunk's 12 pieces sit in the ring registers (piece 4 j + nt in stage j): into the image once
+            // every wave is done with this chunk's fragments; then the ring takes the next chunk's first PF k-steps ----
+            int erow[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) erow[i] = *reinterpret_cast<const unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2);
+            __syncthreads();
+            KZ_STAMP(6 + chunk * 4);
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                if (po[i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * PRS + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
+#pragma unroll
+            for (int st = 0; st < PF; st++)
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) wreg[st][nt] = wp[(size_t)(g + st) * 256 + (wo * NTW + nt) * 64];
+            KZ_STAMP(7 + chunk * 4);
+        }
     }
 
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
-    // The residual comes straight into registers in the accumulators' layout (8 bytes = this lane's 4 channels of a
-    // pixel row; the loads fly while the waves meet at the barrier); the result is staged through LDS (the image is
-    // dead now) so that HBM sees whole 128-byte lines (this workgroup's 64 output channels of a pixel) instead of
-    // 8-byte pieces: O[row][64 oc] f16, row stride 144 B.
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    const bool with_res = a.res != nullptr;
-    u32x2 resv[NTW][MTW];
-    if (with_res) {
-        const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.res), 0, a.bytes, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < MTW; i++) {
-            const int e = emapT[i];
-            const bool valid = e >= 0 && board0 + (e >> 20) < a.boards;
-            const int off = valid ? (((board0 + (e >> 20)) * a.hw + ((e >> 10) & 1023)) * a.ld + kq * 4) * 2 : -1;
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++)
-                resv[nt][i] = __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, (nquarter * OCW + (wo * NTW + nt) * 16) * 2, 0);
-        }
-    }
+    // The result is staged through LDS (the image is dead now) so that HBM sees whole 128-byte lines (this workgroup's
+    // 64 output channels of a pixel) instead of 8-byte pieces: O[row][64 oc] f16, row stride 144 B.  The residual arrived
+    // in the ring registers as the same coalesced 16-byte pieces during the last three k-steps: it goes into O first, and
+    // each lane then replaces the 8 bytes it owns (its 4 channels of a pixel row) by relu(acc) + residual, added in f32.
     __syncthreads();  // every wave is done with the last chunk's fragments
     KZ_STAMP(18);
     const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
+    if (with_res) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
+        __syncthreads();
+    }
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
         const int ocl = (wo * NTW + nt) * 16 + kq * 4;  // within this workgroup's 64 channels
@@ -363,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                 for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
             }
             if (with_res) {
-                const h16x4 r = __builtin_bit_cast(h16x4, resv[nt][i]);
+                const h16x4 r = *reinterpret_cast<const h16x4 *>(slot);
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] += (float)r[j];  // added in f32, AFTER the ReLU (post_act.py:227-228)
             }
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 #pragma unroll
     for (int i = 0; i < 12; i++)  // a padding row's store is out of range and dropped
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
-                                               nquarter * OCW * 2, 0);
+                                               nquarter * OCW * 2, KZ_BC_STORE_AUX);
     KZ_STAMP(20);
 }
 
@@ -386,17 +410,19 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 namespace {
 // halo image geometry: boards per workgroup limited by the 24 tiles and by 40 KB per plane (two workgroups per CU)
 struct Geometry {
-    int tpb, bpw, pitch, rpb, plane, lds_bytes;
+    int tpb, bpw, pitch, rpb, plane, rm_off, lds_bytes;
 };
+constexpr int RM_BYTES = ROWS * 2;
 Geometry geometry(int h, int w) {
     Geometry g{};
     g.tpb = (h * w + 15) / 16;
     g.pitch = w + 1;
     g.rpb = (h + 2) * g.pitch + 1;
-    const int by_tiles = g.tpb <= MT ? MT / g.tpb : 0, by_lds = (LDS_MAX / 2 / PRS) / g.rpb;
+    const int by_tiles = g.tpb <= MT ? MT / g.tpb : 0, by_lds = ((LDS_MAX - RM_BYTES) / 2 / PRS) / g.rpb;
     g.bpw = by_tiles < by_lds ? by_tiles : by_lds;
     g.plane = (g.bpw * g.rpb * PRS + 255) / 256 * 256;
-    g.lds_bytes = 2 * g.plane > ROWS * ORS ? 2 * g.plane : ROWS * ORS;  // the epilogue reuses it for the output tile
+    g.rm_off = 2 * g.plane > ROWS * ORS ? 2 * g.plane : ROWS * ORS;  // the epilogue reuses the image for the output tile
+    g.lds_bytes = g.rm_off + RM_BYTES;
     return g;
 }
 }  // namespace
@@ -459,8 +485,10 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.post_shift = t.post_shift;
     d.res = static_cast<const h16 *>(t.res);
     d.y = static_cast<h16 *>(t.y);
-    d.bytes = (int)((size_t)t.boards * t.h * t.w * t.ldx * 2);
-    d.ld = t.ldx;  // == t.ldy (board_conv_supported callers pass tower activations of one width)
+    d.bytes = (int)((size_t)t.boards * t.h * t.w * t.ldy * 2);
+    d.bytes_x = (int)((size_t)t.boards * t.h * t.w * t.ldx * 2);
+    d.ld = t.ldy;
+    d.ldx = t.ldx;  // (ldx != ldy only for a single-chunk convolution: the stem)
     d.boards = t.boards;
     d.h = t.h;
     d.w_ = t.w;
@@ -471,6 +499,7 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.pitch = geo.pitch;
     d.rpb = geo.rpb;
     d.plane = geo.plane;
+    d.rm_off = geo.rm_off;
     d.cin = t.cin;
     d.relu = t.relu;
     d.groups = (t.boards + d.bpw - 1) / d.bpw;
@@ -478,9 +507,10 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    d.rowmap = t.rowmap;
-    d.halo = t.halo;
-    d.n_halo = t.n_halo;
+    d.inv_tpb = (65536u + (unsigned)geo.tpb - 1) / (unsigned)geo.tpb;
+    d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
+    const unsigned nhb = 2 * (unsigned)geo.pitch + (unsigned)t.h + 1;
+    d.inv_nhb = (65536u + nhb - 1) / nhb;
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done_mask |= 1ull << (dev & 63);

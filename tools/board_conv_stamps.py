@@ -4,17 +4,30 @@ ok = d[:, 0, 0] > 0
 d = d[ok]
 print("workgroups with stamps:", d.shape[0])
 t0 = d[:, :, 0].min()
-names = ["start", "prologue"]
-for c in range(4): names += [f"c{c}.bar1", f"c{c}.staged", f"c{c}.bar2", f"c{c}.kloop"]
-names += ["epi.bar", "epi.math", "epi.store"]
+# stamp slots (kz_board_conv.hip): 0 start, 1 set-up done, 2 first barrier, 3 chunk 0 staged; per chunk c: 4+4c staged data
+# visible (k-loop starts), 5+4c k-loop done, 6+4c (c < 3) barrier behind the k-loop, 7+4c next chunk's pieces written and
+# the ring re-issued; 18 barrier in front of the epilogue, 19 output tile complete, 20 stores issued
+names = {1: "prologue", 2: "first barrier", 3: "chunk0 staging"}
+for c in range(4):
+    names[4 + 4 * c] = f"c{c}.barrier"
+    names[5 + 4 * c] = f"c{c}.kloop"
+    if c < 3:
+        names[6 + 4 * c] = f"c{c}.end barrier"
+        names[7 + 4 * c] = f"c{c}.pieces->LDS"
+names[18] = "epi.barrier"
+names[19] = "epi.math"
+names[20] = "epi.store"
+order = sorted(names)
 prev = d[:, :, 0]
 print("kernel span (cycles):", (d[:, :, 20].max() - t0))
 life = d[:, :, 20] - d[:, :, 0]
 print("wave lifetime mean/min/max:", life.mean(), life.min(), life.max())
 tot = {}
-for i in range(1, 21):
-    seg = d[:, :, i] - d[:, :, i - 1]
-    print(f"{names[i]:12s} mean {seg.mean():9.0f}  p10 {np.percentile(seg,10):9.0f}  p90 {np.percentile(seg,90):9.0f}  share {seg.mean()/life.mean()*100:5.1f}%")
+prev_slot = 0
+for i in order:
+    seg = d[:, :, i] - d[:, :, prev_slot]
+    prev_slot = i
+    print(f"{names[i]:18s} mean {seg.mean():9.0f}  p10 {np.percentile(seg,10):9.0f}  p90 {np.percentile(seg,90):9.0f}  share {seg.mean()/life.mean()*100:5.1f}%")
 # start times: how WGs are spread
 st = np.sort(d[:, 0, 0] - t0)
 print("start-time quantiles:", [int(np.percentile(st, q)) for q in (0, 25, 50, 75, 100)])
