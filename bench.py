@@ -54,7 +54,7 @@ OTHERS = [("ataxx-8x128", "f32"), ("go19-40x256", "f16"), ("chess-20x256", "f32s
 KERNEL_OF_PATH = {
     "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
     "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_f32+heads": "kz_tower_resident_f32",
-    "tower_resident_split16": "kz_tower_resident_split",
+    "tower_resident_split16": "kz_tower_resident_split", "tower_resident_split16+heads": "kz_tower_resident_split",
     "tower_resident_f16g": "kz_tower_resident_f16g", "board_conv_f16": "kz_board_conv_f16",
     "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32",
 }

@@ -73,6 +73,7 @@ struct DeviceWeights {
 
     // resident tower
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
+    bool fused_split = false;  // the split launch carries the attention heads (set before build)
     float *h32_small = nullptr;  // the fused f32 heads' small 1x1 convolutions (tower32_pack_small_weights)
     void *res32_w = nullptr;  // f32 resident launch (exact f32, or split f16 pairs): one packed weight stream
     void *res_w_stem = nullptr, *res_w_tower = nullptr;
@@ -213,16 +214,26 @@ struct DeviceWeights {
 
         if (split16 || pairs16) {
             // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 stem k-steps, then 9*C/32 per convolution
-            std::vector<uint16_t> packed(kz::tower_split_weight_elems(C, m.depth, split16));
+            // (+ the attention heads' five passes and bias rows when the split launch carries the heads)
+            const bool heads = split16 && fused_split;
+            const size_t tower_elems = kz::tower_split_weight_elems(C, m.depth, split16);
+            std::vector<uint16_t> packed(tower_elems + (heads ? kz::tower_split_heads_weight_elems() : 0));
             const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = 9 * step_elems,
                          layer_elems = (size_t)9 * (C / 32) * step_elems;
             kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, hw, true, split16, packed.data());
             for (int l = 0; l < 2 * m.depth; l++)
                 kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, hw, false, split16,
                                              packed.data() + stem_elems + layer_elems * l);
-            std::vector<float> bias((size_t)(1 + 2 * m.depth) * C);
+            std::vector<float> bias((size_t)(1 + 2 * m.depth + (heads ? 5 : 0)) * C);
             for (int l = 0; l < 1 + 2 * m.depth; l++)
                 for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
+            if (heads) {
+                kz::tower_split_pack_heads(m.p_bulk.w.data(), m.p_bulk.b.data(), m.p_under.w.data(), m.p_under.b.data(),
+                                           packed.data() + tower_elems, bias.data() + (size_t)(1 + 2 * m.depth) * C);
+                std::vector<int32_t> idx(m.flat_to_att.size());
+                for (size_t i = 0; i < idx.size(); i++) idx[i] = (m.flat_to_att[i] / 88) * 96 + m.flat_to_att[i] % 88;
+                if (upload(idx.data(), idx.size() * 4, (void **)&att_idx)) return 1;
+            }
             if (upload(packed.data(), packed.size() * 2, &res32_w)) return 1;
             if (upload_f32(bias, &res_bias)) return 1;
         } else if (resident32) {
@@ -415,6 +426,7 @@ struct kz_engine {
     std::vector<void *> allocs, pinned;
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
     bool fused32 = false;  // the exact-f32 resident launch with the conv policy head and the scalar head inside
+    bool fused_split = false;  // the split-f16 launch with the scalar head and the attention policy head inside
     bool nb4 = false;        // resident chess tower with four boards per workgroup (KZ_TOWER_NB=4)
     void *xres = nullptr;    // its residual scratch
     std::string path;
@@ -677,6 +689,15 @@ struct kz_engine {
                 t.n_scalar = m.n_scalar;
                 t.n_bool = m.n_bool;
             }
+            if (fused_split) {
+                kz::Tower32Args::Heads &hd = t.heads;
+                hd.on = true;
+                hd.sh_w0 = wts->sh_w0; hd.sh_b0 = wts->sh_b0; hd.sh_w1 = wts->sh_w1; hd.sh_b1 = wts->sh_b1;
+                hd.sh_w2 = wts->sh_w2; hd.sh_b2 = wts->sh_b2; hd.att_idx = wts->att_idx;
+                hd.policy_len = m.policy_len;
+                hd.scalars = d_scalars; hd.policy = d_policy;
+                hd.nonfinite_flag = nf_flag; hd.epoch = nf_epoch;
+            }
             if (fused32) {
                 kz::Tower32Args::Heads &hd = t.heads;
                 hd.on = true;
@@ -722,7 +743,7 @@ struct kz_engine {
     }
 
     int run_heads(int batch, float *d_scalars, float *d_policy) {
-        if (fused_heads || fused32) return 0;  // written by the tower launch
+        if (fused_heads || fused32 || fused_split) return 0;  // written by the tower launch
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         const void *x = act[tower_out];
@@ -993,8 +1014,12 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->fused32 = e->resident32 && !e->split16 && !(nofuse && nofuse[0] == '1') &&
                  kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
                                              m.channels, m.sh_conv.cout, m.sh_fc0.out);
+    e->fused_split = e->split16 && !(nofuse && nofuse[0] == '1') &&
+                     kz::tower_split_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.h, m.w,
+                                                     m.channels, m.sh_conv.cout, m.sh_fc0.out);
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
+              : e->fused_split ? "tower_resident_split16+heads"
               : e->split16   ? "tower_resident_split16"
               : e->fused32   ? "tower_resident_f32+heads"
               : e->resident32 ? "tower_resident_f32"
@@ -1011,7 +1036,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 #endif
         auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + variant,
                                    e->resident || e->resident32,
-                                   e->fused_heads, board_conv);
+                                   e->fused_heads || e->fused_split, board_conv);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) e->wts = it->second.lock();
         if (!e->wts) {
@@ -1019,6 +1044,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->device = device;
             w->dtype = dtype;
             w->use_board_conv = board_conv;
+            w->fused_split = e->fused_split;
             if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16, e->pairs16)) return 1;
             g_cache[key] = w;
             e->wts = w;
@@ -1028,12 +1054,12 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 #ifdef KZ_EXPERIMENTS
     {
         const char *hg = getenv("KZ_HIP_GRAPH");
-        e->use_graph = hg && hg[0] == '1' && !e->fused_heads && !e->fused32;
+        e->use_graph = hg && hg[0] == '1' && !e->fused_heads && !e->fused32 && !e->fused_split;
     }
 #endif
     HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[0], hipStreamNonBlocking));
     e->stream = e->slot_stream[0];
-    if (e->fused_heads || e->fused32) {  // one launch per batch that touches nothing but its slot's buffers
+    if (e->fused_heads || e->fused32 || e->fused_split) {  // one launch per batch that touches nothing but its slot's buffers
         HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[1], hipStreamNonBlocking));
         for (int i = 2; i < KZ_ENGINE_SLOTS; i++) e->slot_stream[i] = e->slot_stream[i & 1];
         e->zero_copy = true;
@@ -1480,7 +1506,7 @@ KZ_API int kz_engine_read_activation(kz_engine *e, const char *name, int batch, 
     if (!e || !name || !out_nchw) return fail("kz_engine_read_activation: null argument");
     // "tower.out": the tower output of the last evaluation, on every path that materialises it (all but the fused-heads
     // launch)
-    const bool tower_out = std::string(name) == "tower.out" && !e->fused_heads && !e->fused32;
+    const bool tower_out = std::string(name) == "tower.out" && !e->fused_heads && !e->fused32 && !e->fused_split;
     if (!e->keep && !tower_out)
         return fail("kz_engine_read_activation: engine keeps no activations (create it with KZ_FORCE_GENERIC=1 and "
                     "KZ_KEEP_ACTIVATIONS=1; \"tower.out\" is available on every path without fused heads)");

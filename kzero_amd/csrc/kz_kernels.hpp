@@ -157,6 +157,9 @@ struct Tower32Args {
     // output never leaves LDS and `y` is not written.  tower32_heads_supported says for which models.
     struct Heads {
         bool on = false;
+        // (the split launch's attention heads, kz_tower_split.hip: the scalar head's matrices as they are, the gather table)
+        const float *sh_w0 = nullptr, *sh_w1 = nullptr;
+        const int32_t *att_idx = nullptr;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
         int hc = 0, hs = 0;  // scalar head: 1x1 conv channels, hidden size
         const float *small_w = nullptr;  // tower32_pack_small_weights: scalar-head conv (+ extra-move conv), policy conv
         const float *sh_b0 = nullptr, *sh_w1t = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
@@ -192,6 +195,12 @@ int tower_split_boards_per_workgroup(int h, int w, int channels, bool split);
 size_t tower_split_weight_elems(int channels, int depth, bool split = true);  // f16 elements
 void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool stem, bool split, uint16_t *dst);
 void launch_tower_split(const Tower32Args &a, hipStream_t stream);
+// the chess attention network's heads inside that launch (a.heads.on; scalars and policy are then its only output)
+bool tower_split_heads_supported(int policy_kind, int query_channels, int policy_len, int h, int w, int channels, int sh_channels,
+                                 int sh_size);
+size_t tower_split_heads_weight_elems();  // f16 elements behind the tower's k-steps
+void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const float *w_under, const float *b_under, uint16_t *dst,
+                            float *bias5 /* [5][256] behind the tower's bias rows */);
 // the same launch without the lo halves (split = false): plain f16 arithmetic, x0 and y are f16 tensors behind the
 // float pointers of Tower32Args — the board-resident f16 tower for the shapes kz_tower.hip does not take
 void launch_tower_pairs(const Tower32Args &a, bool split, hipStream_t stream);

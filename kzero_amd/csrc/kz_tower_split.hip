@@ -71,7 +71,16 @@ struct SplitDev {
     size_t bits_stride;
     const float *scalars_in;
     int n_scalar, n_bool;
+    // fused heads (HEADS: chess attention network, 256 channels = query channels): ScalarHead + AttentionPolicyHead on the
+    // LDS-resident tower output.  The weight stream carries 5 more passes of 8 k-steps (conv_bulk[0:Q), conv_under as
+    // three s-major passes, conv_bulk[Q:2Q)), the bias table 5 more rows in the same order.
+    const float *sh_w0, *sh_b0, *sh_w1, *sh_b1, *sh_w2, *sh_b2;
+    const int32_t *att_idx;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
+    float *scalars, *policy;
+    int *nonfinite_flag;
+    int epoch;
 };
+constexpr int HEAD_PASSES = 5, POLICY = 1880, LOGIT_LD = 96;
 
 __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
 #pragma unroll
@@ -81,8 +90,9 @@ __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
     }
 }
 
-template <int C, int NT, bool SPLIT>
+template <int C, int NT, bool SPLIT, bool HEADS = false>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
+    static_assert(!HEADS || (C == 256 && NT == 4 && SPLIT), "fused heads: the chess attention network in split arithmetic");
     using L = Geo<C, NT, SPLIT>;
     constexpr int PARTS = L::PARTS, PF = L::PF;
     constexpr int RS = L::RS, OT = L::OT, G = L::G, DELTA = L::DELTA, XH = L::XH, YH = L::YH, ZH = L::ZH;
@@ -95,7 +105,9 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     const int boards = min(a.nb, a.batch - board0);
     const int rows_valid = boards * a.hw;
     const int layers = 2 * a.depth;
-    const int total_ksteps = layers * 9 * G;  // of the ring: the 9 stem k-steps in front of them are read directly
+    // of the ring: the 9 stem k-steps in front of them are read directly; the heads' passes follow the tower's
+    const int total_ksteps = layers * 9 * G + (HEADS ? HEAD_PASSES * G : 0);
+    const int bias_rows = layers + (HEADS ? HEAD_PASSES : 0);
 
     // ---- weight stream: prime PF stages (stage s = k-step g % PF) ----
     const uint4 *wp_stem = a.w + wave * OT * 64 + lane;
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     f32x4 acc[OT][NT];
     f32x4 bias_next[OT];
     auto fetch_bias = [&](int row) __attribute__((always_inline)) {
-        const int l = row <= layers ? row : layers;
+        const int l = row <= bias_rows ? row : bias_rows;
 #pragma unroll
         for (int ot = 0; ot < OT; ot++)
             bias_next[ot] = *reinterpret_cast<const f32x4 *>(a.bias + l * C + (wave * OT + ot) * 16 + kq * 4);
@@ -376,6 +388,13 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                         for (int j = 0; j < 4; j++) v[j] += (float)rl[j];
                     }
                     v = v * ps + pt;
+                    if constexpr (HEADS) {  // the heads read the tower output from X (in place: this lane owns the slot)
+                        h16x4 hi, lo;
+                        split4(v, hi, lo);
+                        *reinterpret_cast<h16x4 *>(lds + XH + off) = hi;
+                        *reinterpret_cast<h16x4 *>(lds + XH + DELTA + off) = lo;
+                        continue;
+                    }
                     const int r = nt * 16 + fr;
                     const size_t o = ((size_t)board0 * a.hw + r) * a.ldy + oc;
                     if (r < rows_valid) {
@@ -386,6 +405,185 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             }
         }
         __syncthreads();
+    }
+
+    if constexpr (HEADS) {
+        // =====================================================================================================
+        // Heads on the LDS-resident tower output X (hi, lo; already through the final BN), in the same split arithmetic:
+        // every 1x1 convolution is one more pass of the weight stream (three MFMAs per product, f32 accumulators), every
+        // intermediate is stored as a (hi, lo) pair, the attention product runs on the same three MFMAs, the scalar
+        // head's small Linears in f32.  The zero rows and the stem input are dead: the under image of one pass lives in
+        // the hi zero rows (UA), the scalar head's activations behind the lo zero rows (ACT).
+        // =====================================================================================================
+        constexpr int UA = ZH, UDELTA = 8 * RS;            // under block s: 8 rows (x) x 256 q, hi then lo
+        static_assert(2 * UDELTA <= 16 * RS, "one under pass fits the hi zero rows");
+        constexpr int ACT = ZH + DELTA, HID = ACT + 256 * 4;  // act [4*64] f32 (channel-major flatten), hid [32] f32
+        static_assert(HID + 32 * 4 <= L::LDS_BYTES, "scalar head scratch");
+        constexpr int LOG = YH;                            // logits [64][96] f32 once q_from is consumed
+        static_assert(64 * LOGIT_LD * 4 <= 2 * L::IMG, "logits fit the hi block's X and Y");
+        auto conv_1x1 = [&](int src_h, int tiles) __attribute__((always_inline)) {
+            // centre tap only; `tiles` = 4: all 64 rows, 1: the tile of rows 48..63 (the far rank is rows 56..63)
+#pragma unroll
+            for (int ch = 0; ch < G; ch++) {
+                h16x8 ah[OT], al[OT], bh[NT], bl[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const int t = src_h + frag_base + (tiles == 1 ? 3 : nt) * 16 * RS + ch * 16;
+                    bh[nt] = *reinterpret_cast<const h16x8 *>(lds + t);
+                    bl[nt] = *reinterpret_cast<const h16x8 *>(lds + t + DELTA);
+                }
+                ring_take(ch & (PF - 1), ah, al);
+                if (tiles == 1) {
+#pragma unroll
+                    for (int ot = 0; ot < OT; ot++) {
+                        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ot], bh[0], acc[ot][0], 0, 0, 0);
+                        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ot], bl[0], acc[ot][0], 0, 0, 0);
+                        acc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ot], bh[0], acc[ot][0], 0, 0, 0);
+                    }
+                } else {
+                    mfma3(ah, al, bh, bl);
+                }
+                g++;
+            }
+        };
+
+        // ---- H1: ScalarHead conv1x1 C->4 + ReLU (post_act.py:14-15), channel-major flatten (:16) -> act[c*64 + p];
+        // the range check: a non-finite value anywhere in the residual stream persists to the tower output
+        {
+            float *act = reinterpret_cast<float *>(lds + ACT);
+            const int c4 = tid >> 6, p = tid & 63;
+            const unsigned char *row = lds + XH + p * RS;
+            const float *w = a.sh_w0 + c4 * C;
+            float sum = a.sh_b0[c4];
+#pragma unroll 4
+            for (int i = 0; i < C; i += 8) {
+                const h16x8 xh = *reinterpret_cast<const h16x8 *>(row + i * 2), xl = *reinterpret_cast<const h16x8 *>(row + DELTA + i * 2);
+                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + i), w1 = *reinterpret_cast<const f32x4 *>(w + i + 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    sum += ((float)xh[j] + (float)xl[j]) * w0[j] + ((float)xh[4 + j] + (float)xl[4 + j]) * w1[j];
+            }
+            if (!(fabsf(sum) <= 3.0e38f) && a.nonfinite_flag)
+                *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may be in pinned host memory)
+            act[tid] = fmaxf(sum, 0.0f);
+        }
+
+        // ---- H2: conv_bulk channels [0, Q) = q_from (post_act.py:127,131): X -> Y
+        init_acc();
+        fetch_bias(layers + 2);
+        conv_1x1(XH, 4);
+        epilogue(YH, false, false);
+        __syncthreads();  // q_from and act are complete
+
+        // ---- H3: conv_under on the 8 squares of rank index 7 (post_act.py:129) as 3 passes of 256 output channels: the
+        // host permutes its output channels to s-major (oc' = 256 s + q for the original channel 3 q + s), so that
+        // under.reshape(Q, 24)[q][8 s + x] (post_act.py:134) is row x of pass s.  Each pass goes straight into its 8
+        // columns of the logits: L[i][64 + 8 s + x] = sum_q q_from[q][i] * under_s[x][q] — q_to rows as the A operand,
+        // q_from rows as the B operand, this wave's 16 squares i
+        f32x4 lu[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; sp++) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) acc[ot][0] = bias_next[ot];
+            fetch_bias(layers + 3 + sp);
+            conv_1x1(XH, 1);
+            if (sp > 0) __syncthreads();  // the previous pass's under image has been multiplied
+            if (fr >= 8) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ot++) {
+                    h16x4 hi, lo;
+                    split4(acc[ot][0], hi, lo);
+                    const int off = UA + (fr - 8) * RS + ((wave * OT + ot) * 16 + kq * 4) * 2;
+                    *reinterpret_cast<h16x4 *>(lds + off) = hi;
+                    *reinterpret_cast<h16x4 *>(lds + off + UDELTA) = lo;
+                }
+            }
+            __syncthreads();
+            f32x4 l = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ua = UA + (fr & 7) * RS + kq_off, qf = YH + (wave * 16 + fr) * RS + kq_off;
+#pragma unroll
+            for (int ch = 0; ch < G; ch++) {
+                const h16x8 uh = *reinterpret_cast<const h16x8 *>(lds + ua + ch * 16), ul = *reinterpret_cast<const h16x8 *>(lds + ua + UDELTA + ch * 16);
+                const h16x8 qh = *reinterpret_cast<const h16x8 *>(lds + qf + ch * 16), ql = *reinterpret_cast<const h16x8 *>(lds + qf + DELTA + ch * 16);
+                l = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul, qh, l, 0, 0, 0);
+                l = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, ql, l, 0, 0, 0);
+                l = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, qh, l, 0, 0, 0);
+            }
+            lu[sp] = l;  // lane (fr = i, kq < 2): columns 64 + 8 sp + 4 kq + 0..3
+        }
+
+        // ---- H4: conv_bulk channels [Q, 2Q) = the 64 board squares of q_to: X -> X in place (every wave reads all of X
+        // in its k-loop, so the writes wait for a barrier)
+        init_acc();
+        conv_1x1(XH, 4);
+        __syncthreads();
+        epilogue(XH, false, false);
+
+        // ---- H5: ScalarHead Linear(256 -> 32) + ReLU (post_act.py:17-18): 4 lanes per output, 64 inputs each
+        {
+            const float *act = reinterpret_cast<const float *>(lds + ACT);
+            float *hid = reinterpret_cast<float *>(lds + HID);
+            if (tid < 128) {
+                const int j = tid >> 2, part = tid & 3;
+                const float *w = a.sh_w1 + j * 256 + part * 64;
+                const float *x = act + part * 64;
+                float sum = 0.0f;
+#pragma unroll 4
+                for (int i = 0; i < 64; i += 4) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + i), xv = *reinterpret_cast<const f32x4 *>(x + i);
+                    sum += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+                }
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                if (part == 0) hid[j] = fmaxf(sum + a.sh_b1[j], 0.0f);
+            }
+        }
+        __syncthreads();  // q_to (X) and hid are complete
+
+        // ---- H6: the 64 x 64 board block of the logits (post_act.py:138): L[i][j] = sum_q q_from[q][i] * q_to[q][j]
+        f32x4 la[4];
+        {
+            const int qf = YH + (wave * 16 + fr) * RS + kq_off;
+#pragma unroll
+            for (int jt = 0; jt < 4; jt++) la[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < G; ch++) {
+                const h16x8 qh = *reinterpret_cast<const h16x8 *>(lds + qf + ch * 16), ql = *reinterpret_cast<const h16x8 *>(lds + qf + DELTA + ch * 16);
+#pragma unroll
+                for (int jt = 0; jt < 4; jt++) {
+                    const int tj = XH + (jt * 16 + fr) * RS + kq_off + ch * 16;
+                    const h16x8 th = *reinterpret_cast<const h16x8 *>(lds + tj), tl = *reinterpret_cast<const h16x8 *>(lds + tj + DELTA);
+                    la[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, qh, la[jt], 0, 0, 0);
+                    la[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, ql, la[jt], 0, 0, 0);
+                    la[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, qh, la[jt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading q_from (Y) and q_to (X)
+        {
+            const float inv = 1.0f / sqrtf((float)C);  // / sqrt(query_channels) (post_act.py:138)
+            float *lg = reinterpret_cast<float *>(lds + LOG) + (wave * 16 + fr) * LOGIT_LD;
+#pragma unroll
+            for (int jt = 0; jt < 4; jt++) *reinterpret_cast<f32x4 *>(lg + jt * 16 + kq * 4) = la[jt] * inv;
+            if (kq < 2) {
+#pragma unroll
+                for (int sp = 0; sp < 3; sp++) *reinterpret_cast<f32x4 *>(lg + 64 + 8 * sp + kq * 4) = lu[sp] * inv;
+            }
+        }
+        // ---- H7: ScalarHead Linear(32 -> 5) (post_act.py:19)
+        if (tid < 5) {
+            const float *hid = reinterpret_cast<const float *>(lds + HID);
+            float sum = a.sh_b2[tid];
+            for (int i = 0; i < 32; i++) sum += a.sh_w2[tid * 32 + i] * hid[i];
+            a.scalars[(size_t)board0 * 5 + tid] = sum;
+        }
+        __syncthreads();
+        // ---- H8: policy.flatten(1)[:, FLAT_TO_ATT] (post_act.py:140): coalesced 1880-float rows
+        {
+            const float *lg = reinterpret_cast<const float *>(lds + LOG);
+            float *pol = a.policy + (size_t)board0 * POLICY;
+            for (int k = tid; k < POLICY; k += 256) pol[k] = lg[a.att_idx[k]];
+        }
     }
 }
 
@@ -764,17 +962,17 @@ int split_tiles_for(int hw, int channels, bool split) {
     return 0;
 }
 
-template <int C, int NT, bool SPLIT>
+template <int C, int NT, bool SPLIT, bool HEADS = false>
 void launch(const SplitDev &d, int grid, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done_mask >> (dev & 63)) & 1)) {
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Geo<C, NT, SPLIT>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT, SPLIT, HEADS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Geo<C, NT, SPLIT>::LDS_BYTES);
         done_mask |= 1ull << (dev & 63);
     }
-    kz_tower_resident_split<C, NT, SPLIT><<<grid, 256, Geo<C, NT, SPLIT>::LDS_BYTES, stream>>>(d);
+    kz_tower_resident_split<C, NT, SPLIT, HEADS><<<grid, 256, Geo<C, NT, SPLIT>::LDS_BYTES, stream>>>(d);
 }
 
 
@@ -972,6 +1170,60 @@ void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool
         }
 }
 
+// The chess attention network's heads inside the split launch: 256 tower channels = query channels on 8x8, the
+// reference's ScalarHead(8, C, 4, 32) (post_act.py:10-23, :115-141).
+bool tower_split_heads_supported(int policy_kind, int query_channels, int policy_len, int h, int w, int channels, int sh_channels,
+                                 int sh_size) {
+    return policy_kind == 2 && channels == 256 && query_channels == 256 && policy_len == POLICY && h == 8 && w == 8 &&
+           sh_channels == 4 && sh_size == 32;
+}
+
+size_t tower_split_heads_weight_elems() { return (size_t)HEAD_PASSES * 8 * 2 * 256 * 32; }  // f16 elements: 5 passes of 8 k-steps
+
+// One 1x1 convolution [256 out][256 in] as a pass of 8 k-steps in the tower layers' (hi, lo) fragment order
+static void pack_1x1_split(const float *w, uint16_t *dst) {
+    const int kq_base[4] = {0, 128, 64, 192};
+    const size_t part = (size_t)256 * 32;
+    for (int chunk = 0; chunk < 8; chunk++) {
+        uint16_t *step = dst + (size_t)chunk * 2 * part;
+        for (int wave = 0; wave < 4; wave++)
+            for (int ot = 0; ot < 4; ot++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int oc = 16 * (wave * 4 + ot) + (lane & 15);
+                        const int ch = 8 * chunk + kq_base[lane >> 4] + j;
+                        const float v = w[(size_t)oc * 256 + ch];
+                        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                        uint16_t hb, lb;
+                        __builtin_memcpy(&hb, &hi, 2);
+                        __builtin_memcpy(&lb, &lo, 2);
+                        const size_t e = (((size_t)wave * 4 + ot) * 64 + lane) * 8 + j;
+                        step[e] = hb;
+                        step[part + e] = lb;
+                    }
+    }
+}
+
+// conv_bulk [512][256] and conv_under [768][256] (post_act.py:122-123) -> the five passes behind the tower's k-steps, in
+// the order the launch runs them: conv_bulk[0:Q) (q_from), conv_under's channels 3 q + s as three s-major passes
+// (under.reshape(Q, 24)[q][8 s + x], post_act.py:134), conv_bulk[Q:2Q) (the board squares of q_to); bias5 [5][256] alike
+void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const float *w_under, const float *b_under, uint16_t *dst,
+                            float *bias5) {
+    const size_t pass = (size_t)8 * 2 * 256 * 32;
+    std::vector<float> tmp((size_t)256 * 256);
+    pack_1x1_split(w_bulk, dst);
+    for (int q = 0; q < 256; q++) bias5[q] = b_bulk[q];
+    for (int sp = 0; sp < 3; sp++) {
+        for (int q = 0; q < 256; q++) {
+            for (int c = 0; c < 256; c++) tmp[(size_t)q * 256 + c] = w_under[(size_t)(3 * q + sp) * 256 + c];
+            bias5[(1 + sp) * 256 + q] = b_under[3 * q + sp];
+        }
+        pack_1x1_split(tmp.data(), dst + pass * (1 + sp));
+    }
+    pack_1x1_split(w_bulk + (size_t)256 * 256, dst + pass * 4);
+    for (int q = 0; q < 256; q++) bias5[4 * 256 + q] = b_bulk[256 + q];
+}
+
 void launch_tower_split(const Tower32Args &t, hipStream_t stream) { launch_tower_pairs(t, true, stream); }
 
 void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
@@ -999,6 +1251,15 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
     const int grid = (t.batch + d.nb - 1) / d.nb;
+    if (split && t.heads.on) {  // (the engine asked tower_split_heads_supported)
+        const Tower32Args::Heads &hd = t.heads;
+        d.sh_w0 = hd.sh_w0; d.sh_b0 = hd.sh_b0; d.sh_w1 = hd.sh_w1; d.sh_b1 = hd.sh_b1; d.sh_w2 = hd.sh_w2; d.sh_b2 = hd.sh_b2;
+        d.att_idx = hd.att_idx;
+        d.scalars = hd.scalars; d.policy = hd.policy;
+        d.nonfinite_flag = hd.nonfinite_flag; d.epoch = hd.epoch;
+        launch<256, 4, true, true>(d, grid, stream);
+        return;
+    }
     if (split) {
 #ifdef KZ_EXPERIMENTS
         if (split_uses_32x32(t.channels, nt, true)) launch32<true>(d, grid, stream);

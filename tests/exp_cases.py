@@ -113,7 +113,8 @@ bits, sc = synth.random_boards({game!r}, 11, seed=45)
 s, p = eng.eval_packed(bits, sc)
 np.savez({out!r}, s=s, p=p, path=eng.tower_path)
 """
-    child_env = dict(os.environ, **{env: "1"})
+    # (the 32x32x16 launch has no fused heads: both sides run the tower launch + the separate head kernels)
+    child_env = dict(os.environ, **{env: "1", "KZ_NO_FUSED_HEADS": "1"})
     r = subprocess.run([sys.executable, "-c", code], env=child_env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr
@@ -121,7 +122,11 @@ np.savez({out!r}, s=s, p=p, path=eng.tower_path)
     blob = synth.random_model(game, depth, 256, head, seed=44)
     bits, sc = synth.random_boards(game, 11, seed=45)
     code_dtype = capi.KZ_DTYPE_F32_SPLIT16 if dtype_name == "split16" else capi.KZ_DTYPE_F16
-    eng = capi.Engine(capi.Model(blob=blob), dev, 16, code_dtype)
+    os.environ["KZ_NO_FUSED_HEADS"] = "1"
+    try:
+        eng = capi.Engine(capi.Model(blob=blob), dev, 16, code_dtype)
+    finally:
+        del os.environ["KZ_NO_FUSED_HEADS"]
     assert str(got["path"]) == eng.tower_path == ("tower_resident_split16" if dtype_name == "split16" else "tower_resident_f16g")
     s, p = eng.eval_packed(bits, sc)
     if dtype_name == "split16":
@@ -141,7 +146,7 @@ np.savez({out!r}, s=s, p=p, path=eng.tower_path)
     ("go-9", 2, 128, "conv", "f16", "board_conv_f16", {"KZ_NO_RESIDENT_F16G": "1"}),
     ("go-9", 2, 128, "conv", "f16", "conv_igemm_f16", {"KZ_NO_RESIDENT_F16G": "1", "KZ_NO_BOARD_CONV": "1"}),
     ("ataxx-7", 2, 128, "ataxx_conv", "f16", "tower_resident_f16g", {}),
-    ("chess", 2, 256, "attention", "split16", "tower_resident_split16", {}),
+    ("chess", 2, 256, "attention", "split16", "tower_resident_split16", {"KZ_NO_FUSED_HEADS": "1"}),
     ("chess", 2, 64, "attention", "f32", "conv_igemm_f32", {}),
 ])
 def test_hip_graph_replay_is_the_same_forward_pass(dev, game, depth, channels, head, dtype, path, env):

@@ -476,7 +476,8 @@ def _scaled_stem(blob, factor):
 @pytest.mark.parametrize("game,depth,channels,head,dtype,path,env", [
     ("chess", 2, 256, "attention", "f16", "tower_resident_f16+heads", {}),
     ("chess", 2, 256, "attention", "f16", "tower_resident_f16", {"KZ_NO_FUSED_HEADS": "1"}),
-    ("chess", 2, 256, "attention", "split16", "tower_resident_split16", {}),
+    ("chess", 2, 256, "attention", "split16", "tower_resident_split16+heads", {}),
+    ("chess", 2, 256, "attention", "split16", "tower_resident_split16", {"KZ_NO_FUSED_HEADS": "1"}),
     ("ataxx-7", 2, 128, "ataxx_conv", "f16", "tower_resident_f16g", {}),
     ("go-9", 2, 128, "conv", "f16", "board_conv_f16", {"KZ_NO_RESIDENT_F16G": "1"}),
     ("go-9", 2, 128, "conv", "f16", "conv_igemm_f16", {"KZ_NO_RESIDENT_F16G": "1", "KZ_NO_BOARD_CONV": "1"}),
@@ -769,7 +770,17 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     net = O.OracleNet(blob)
     model = capi.Model(blob=blob)
     eng = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32_SPLIT16)
-    assert eng.tower_path == "tower_resident_split16"
+    # the chess attention network at 256 channels is ONE launch (tower + scalar head + attention head in split arithmetic)
+    fused = game == "chess" and channels == 256 and head == "attention"
+    assert eng.tower_path == ("tower_resident_split16+heads" if fused else "tower_resident_split16")
+    unfused = None
+    if fused:  # the same tower launch followed by the separate f32 head kernels
+        os.environ["KZ_NO_FUSED_HEADS"] = "1"
+        try:
+            unfused = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32_SPLIT16)
+        finally:
+            del os.environ["KZ_NO_FUSED_HEADS"]
+        assert unfused.tower_path == "tower_resident_split16"
     exact = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32)
     assert exact.tower_path == ("conv_igemm_f32" if channels < 128 else
                                 "tower_resident_f32+heads" if head in ("ataxx_conv", "conv") else "tower_resident_f32")
@@ -785,6 +796,14 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
         se, pe = exact.eval_packed(bits, scalars_in)
         assert_f32(se, s, f"exact f32 vs split16 scalars b={batch}")
         assert_f32(pe, p, f"exact f32 vs split16 policy b={batch}")
+        if unfused is not None:
+            su, pu = unfused.eval_packed(bits, scalars_in)
+            assert_f32(su, s_ref, f"split16 with separate heads, scalars b={batch}")
+            assert_f32(pu, p_ref, f"split16 with separate heads, policy b={batch}")
+            dense_in = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+            sd, pd = eng.eval_dense(dense_in)  # the dense entry point goes through the same fused launch
+            assert_f32(sd, s_ref, f"split16 fused, dense input, scalars b={batch}")
+            assert_f32(pd, p_ref, f"split16 fused, dense input, policy b={batch}")
 
 
 @pytest.mark.parametrize("game,depth,channels,head,batches", [
@@ -910,7 +929,13 @@ def test_abi_helpers_on_the_device(dev):
     assert fused.launch_geometry(256) == (128, 2) and fused.launch_geometry(5) == (3, 2)
     with pytest.raises(capi.KzError, match="tower.out"):
         fused.read_activation("tower.out", 1)                              # the fused launch never writes the tower output
-    split = capi.Engine(big, dev, 256, capi.KZ_DTYPE_F32_SPLIT16)
+    with pytest.raises(capi.KzError, match="tower.out"):
+        capi.Engine(big, dev, 256, capi.KZ_DTYPE_F32_SPLIT16).read_activation("tower.out", 1)  # fused heads as well
+    os.environ["KZ_NO_FUSED_HEADS"] = "1"
+    try:
+        split = capi.Engine(big, dev, 256, capi.KZ_DTYPE_F32_SPLIT16)
+    finally:
+        del os.environ["KZ_NO_FUSED_HEADS"]
     assert split.launch_geometry(256) == (256, 1)
     bits, scalars_in = synth.random_boards("chess", 3, seed=2)
     split.eval_packed(bits, scalars_in)
