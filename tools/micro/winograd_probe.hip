@@ -48,7 +48,7 @@ __device__ constexpr float BT_S[4] = {-1.f, 1.f, -1.f, -1.f};
 // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]: coefficient of position i in output pixel u
 __device__ constexpr float AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
 
-template <bool MFMA_ON, bool TRANSFORM_ON, bool WLOAD_ON>
+template <bool MFMA_ON, bool TRANSFORM_ON, bool WLOAD_ON, bool IDEAL_LAYOUT>
 __global__ __launch_bounds__(256, 1) void winograd_layer(const uint4 *__restrict__ weights, const h16 *__restrict__ image, int layers,
                                                          int distinct_layers, float *sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256, 1) void winograd_layer(const uint4 *__restrict
     for (int n = 0; n < 4; n++) {
         const int ty = fr >> 2, tx = fr & 3;
         const int oy = ty == 0 ? 0 : 2 * ty - 1, ox = tx == 0 ? 0 : 2 * tx - 1;
-        // k-step channel assignment as in kz_tower.hip: lane group kq reads the 16-byte piece at 256 (kq & 1) + 128 (kq >> 1)
-        base[n] = (n * 64 + oy * 8 + ox) * RS + 256 * (kq & 1) + 128 * (kq >> 1);
+        // k-step channel assignment as in kz_tower.hip: lane group kq reads the 16-byte piece at 256 (kq & 1) + 128 (kq >> 1).
+        // IDEAL_LAYOUT: the 16 lanes of a fragment read 16 CONSECUTIVE rows, as the direct convolution's fragment reads do
+        // (conflict-free with this row stride) — the best case for a layout a real kernel would have to find; the natural
+        // patch origins (rows 2 ty x 8 + 2 tx apart) collide four ways on the bank slots with this row stride.
+        base[n] = (IDEAL_LAYOUT ? (n * 48 + fr) : (n * 64 + oy * 8 + ox)) * RS + 256 * (kq & 1) + 128 * (kq >> 1);
     }
     f32x4 spatial[4][4][4];  // [output pixel 2u+v][oc tile][N tile]: 256 registers
 #pragma unroll
@@ -103,42 +106,55 @@ __global__ __launch_bounds__(256, 1) void winograd_layer(const uint4 *__restrict
                 wreg[0][o] = WLOAD_ON ? wp[o * 64] : make_uint4(0x2c002c00u + lane, 0x2c00ac00u, 0x2800a800u, 0x30003000u + o);
                 wreg[1][o] = WLOAD_ON ? wp[1024 + o * 64] : wreg[0][o];
             }
+            // 32 units per position: unit u = (k-step u / 4, N tile u % 4) = one B fragment (4 reads + 12 packed FMAs) and its
+            // 4 MFMAs.  The reads run DEPTH units ahead of their use (a ring of DEPTH + 1 source sets, 16 registers each),
+            // so that with one wave per SIMD their latency hides behind the MFMAs and FMAs of the units in between.
+            constexpr int UNITS = KSTEPS * 4, DEPTH = 2;
+            h16x8 src[DEPTH + 1][4];
+            auto issue = [&](int u) __attribute__((always_inline)) {
+                const int b = base[u & 3] + (u >> 2) * 16;
+                src[u % (DEPTH + 1)][0] = *reinterpret_cast<const h16x8 *>(lds + b + o11);
+                if (TRANSFORM_ON) {
+                    src[u % (DEPTH + 1)][1] = *reinterpret_cast<const h16x8 *>(lds + b + o12);
+                    src[u % (DEPTH + 1)][2] = *reinterpret_cast<const h16x8 *>(lds + b + o21);
+                    src[u % (DEPTH + 1)][3] = *reinterpret_cast<const h16x8 *>(lds + b + o22);
+                }
+            };
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
+            for (int u = 0; u < DEPTH; u++) issue(u);
+#pragma unroll
+            for (int u = 0; u < UNITS; u++) {
+                const int ks = u >> 2, n = u & 3;
+                if (u + DEPTH < UNITS) issue(u + DEPTH);
                 h16x8 af[4];
 #pragma unroll
                 for (int o = 0; o < 4; o++) af[o] = __builtin_bit_cast(h16x8, wreg[ks & 1][o]);
+                h16x8 bf;
+                const h16x8 *d = src[u % (DEPTH + 1)];
+                if (TRANSFORM_ON) {
 #pragma unroll
-                for (int n = 0; n < 4; n++) {
-                    h16x8 bf;
-                    if (TRANSFORM_ON) {
-                        const int b = base[n] + ks * 16;
-                        const h16x8 d11 = *reinterpret_cast<const h16x8 *>(lds + b + o11), d12 = *reinterpret_cast<const h16x8 *>(lds + b + o12);
-                        const h16x8 d21 = *reinterpret_cast<const h16x8 *>(lds + b + o21), d22 = *reinterpret_cast<const h16x8 *>(lds + b + o22);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {  // V = (d11 + sb d12) + sa (d21 + sb d22): three v_pk_fma_f16 per register
-                            const h16x2 a = h16x2{d11[2 * r], d11[2 * r + 1]}, bq = h16x2{d12[2 * r], d12[2 * r + 1]};
-                            const h16x2 c = h16x2{d21[2 * r], d21[2 * r + 1]}, d = h16x2{d22[2 * r], d22[2 * r + 1]};
-                            const h16x2 t1 = bq * sb + a, t2 = d * sb + c, v = t2 * sa + t1;
-                            bf[2 * r] = v[0];
-                            bf[2 * r + 1] = v[1];
-                        }
-                    } else {
-                        bf = *reinterpret_cast<const h16x8 *>(lds + base[n] + ks * 16 + o11);
+                    for (int r = 0; r < 4; r++) {  // V = (d11 + sb d12) + sa (d21 + sb d22): three v_pk_fma_f16 per register
+                        const h16x2 a = h16x2{d[0][2 * r], d[0][2 * r + 1]}, bq = h16x2{d[1][2 * r], d[1][2 * r + 1]};
+                        const h16x2 c = h16x2{d[2][2 * r], d[2][2 * r + 1]}, e = h16x2{d[3][2 * r], d[3][2 * r + 1]};
+                        const h16x2 t1 = bq * sb + a, t2 = e * sb + c, v = t2 * sa + t1;
+                        bf[2 * r] = v[0];
+                        bf[2 * r + 1] = v[1];
                     }
-                    if (MFMA_ON) {
-#pragma unroll
-                        for (int o = 0; o < 4; o++) acc[o][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o], bf, acc[o][n], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int o = 0; o < 4; o++) acc[o][n][0] += (float)bf[o] + (float)af[o][0];
-                    }
+                } else {
+                    bf = d[0];
                 }
-                if (WLOAD_ON && ks + 2 < KSTEPS) {
+                if (MFMA_ON) {
+#pragma unroll
+                    for (int o = 0; o < 4; o++) acc[o][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o], bf, acc[o][n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 4; o++) acc[o][n][0] += (float)bf[o] + (float)af[o][0];
+                }
+                if (n == 3 && WLOAD_ON && ks + 2 < KSTEPS) {
 #pragma unroll
                     for (int o = 0; o < 4; o++) wreg[ks & 1][o] = wp[(size_t)(ks + 2) * 1024 + o * 64];
                 }
-                __builtin_amdgcn_sched_barrier(0);  // (keeps the compiler from hoisting every fragment read of a position)
+                __builtin_amdgcn_sched_barrier(0);  // (one unit = one scheduling region: the reads stay DEPTH units ahead)
             }
             // output transform: pixel (u, v) of the 2 x 2 output tile += AT[u][i] * AT[v][j] * m
 #pragma unroll
@@ -173,17 +189,17 @@ static float gauss() {
     return sqrtf(-2 * logf(u)) * cosf(6.2831853f * v);
 }
 
-template <bool MFMA_ON, bool TRANSFORM_ON, bool WLOAD_ON>
+template <bool MFMA_ON, bool TRANSFORM_ON, bool WLOAD_ON, bool IDEAL_LAYOUT = false>
 static void run(const char *name, const uint4 *w, const h16 *img, int distinct, float *sink) {
     const int layers = 400;  // ~15 ms per launch: long enough for the clock to settle over the repetitions
-    (void)hipFuncSetAttribute((const void *)winograd_layer<MFMA_ON, TRANSFORM_ON, WLOAD_ON>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)winograd_layer<MFMA_ON, TRANSFORM_ON, WLOAD_ON, IDEAL_LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     float ms = 0, best = 1e30f;
     for (int rep = 0; rep < 10; rep++) {
         (void)hipEventRecord(e0, 0);
-        winograd_layer<MFMA_ON, TRANSFORM_ON, WLOAD_ON><<<256, 256, LDS_BYTES>>>(w, img, layers, distinct, sink);
+        winograd_layer<MFMA_ON, TRANSFORM_ON, WLOAD_ON, IDEAL_LAYOUT><<<256, 256, LDS_BYTES>>>(w, img, layers, distinct, sink);
         (void)hipEventRecord(e1, 0);
         (void)hipDeviceSynchronize();
         (void)hipEventElapsedTime(&ms, e0, e1);
@@ -217,5 +233,7 @@ int main() {
     run<true, true, false>("  the same without the weight stream (A operands constant)", w, img, distinct, sink);
     run<true, false, true>("  the same with ONE fragment read and no transform per B fragment (LDS / VALU share)", w, img, distinct, sink);
     run<false, true, true>("  the same without the MFMAs (what the feeding alone costs)", w, img, distinct, sink);
+    run<true, true, true, true>("BEST CASE: every fragment read conflict-free (16 consecutive rows per read)", w, img, distinct, sink);
+    run<false, true, true, true>("  best case without the MFMAs (feeding alone)", w, img, distinct, sink);
     return 0;
 }
