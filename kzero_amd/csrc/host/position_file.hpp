@@ -11,6 +11,7 @@
 // so recorded self-play positions replay through the engine unchanged.  kzero_amd/position_file.py is the same format
 // in Python; tests/test_position_file.py checks that each reads what the other writes.
 #pragma once
+#include <charconv>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -152,11 +153,15 @@ class PositionFileWriter {
             return s + "]";
         };
         const bool known = outcomes_known_ && meta_.game_count > 0;
-        auto outcome_number = [&](double sum) {  // averages over the games (:276-277), NaN when a game came without them
-            std::ostringstream o;
-            if (known) o << sum / (double)meta_.game_count;
-            else o << "NaN";
-            return o.str();
+        // averages over the games (:276-277) as serde_json writes an f32: the shortest decimal that reads back as the same
+        // f32, and `null` for NaN (a game that came without them; 0 games) — strict JSON, byte-identical to the Python writer
+        auto outcome_number = [&](double sum) -> std::string {
+            if (!known) return "null";
+            char buf[32];
+            const auto r = std::to_chars(buf, buf + sizeof buf, (float)(sum / (double)meta_.game_count));
+            std::string out(buf, r.ptr);
+            if (out.find_first_of(".en") == std::string::npos) out += ".0";  // serde_json prints 1.0, not 1
+            return out;
         };
         auto outcome_list = [&] {
             return "[" + outcome_number(root_wdl_sum_[0]) + ", " + outcome_number(root_wdl_sum_[1]) + ", " +

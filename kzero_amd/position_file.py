@@ -27,6 +27,13 @@ SCALAR_NAMES = [  # binary_output.rs:321-349
 ]
 
 
+def _f32_json(v):
+    """An f32 the way serde_json writes it (binary_output.rs:276-277 are f32): the shortest decimal that reads back as the
+    same f32, and null for NaN — strict JSON, byte-identical to the C++ writer (host/position_file.hpp)."""
+    v = np.float32(v)
+    return None if np.isnan(v) else float(str(v))
+
+
 @dataclass
 class PositionRecord:
     scalars: dict                      # name -> float, all 26
@@ -124,7 +131,7 @@ class PositionFileWriter:
             "game_count": self.meta.game_count, "position_count": self.meta.position_count,
             "includes_terminal_positions": True, "includes_game_start_indices": True,
             "max_game_length": self.meta.max_game_length, "min_game_length": self.meta.min_game_length,
-            "root_wdl": list(self.meta.root_wdl), "hit_move_limit": self.meta.hit_move_limit,
+            "root_wdl": [_f32_json(v) for v in self.meta.root_wdl], "hit_move_limit": _f32_json(self.meta.hit_move_limit),
             "scalar_names": list(SCALAR_NAMES),
         }
         self._off.write(np.asarray(self._game_starts, dtype="<u8").tobytes())
@@ -145,7 +152,9 @@ class PositionFile:
             game=meta["game"], input_bool_shape=meta["input_bool_shape"], input_scalar_count=meta["input_scalar_count"],
             policy_shape=meta["policy_shape"], game_count=meta["game_count"], position_count=meta["position_count"],
             max_game_length=meta["max_game_length"], min_game_length=meta["min_game_length"],
-            root_wdl=meta.get("root_wdl"), hit_move_limit=meta.get("hit_move_limit"), scalar_names=meta["scalar_names"])
+            root_wdl=[float("nan") if v is None else v for v in (meta.get("root_wdl") or [None] * 3)],  # null = f32 NaN (serde_json)
+            hit_move_limit=float("nan") if meta.get("hit_move_limit") is None else meta["hit_move_limit"],
+            scalar_names=meta["scalar_names"])
         self._bin = np.fromfile(path + ".bin", dtype=np.uint8)
         off = np.fromfile(path + ".off", dtype="<u8")
         n = self.meta.position_count

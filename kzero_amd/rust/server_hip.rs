@@ -21,12 +21,30 @@
 //! `selfplay_server_main` and the three dispatch functions pass `args.device: Vec<i32>` down instead of
 //! `Vec<CudaDevice>`, and `selfplay_start` begins with `let devices = Z::devices(&devices);`.
 //!
-//! Generator half: `server_alphazero.rs:39-87` (sizing, `job_pair`, `ThreadPoolBuilder`, the
-//! `generator_alphazero_main` tasks) moves unchanged into
-//! `pub(super) fn spawn_alphazero_generators(s, device_id, startup, mapper, start_pos, update_sender)
-//!     -> (Vec<Sender<Settings>>, JobServer<B, ZeroEvaluation<'static>>)`,
-//! which `AlphaZeroSpecialization::spawn_device_threads` keeps calling first.  This file supplies the other half for
-//! the HIP backend: the executor threads and the model loader.
+//! No line of the reference is duplicated here.  The body of `AlphaZeroSpecialization::spawn_device_threads`
+//! (`server_alphazero.rs:39-123`: sizing, `job_pair`, `ThreadPoolBuilder`, the `generator_alphazero_main` tasks, the
+//! executor threads around `batched_executor_loop`) moves as it stands into a helper that is generic over the one thing
+//! the two backends differ in — how an executor thread turns the graph it was sent into a `Network`:
+//!
+//! ```ignore
+//! pub(super) fn spawn_alphazero_device_threads<'s, B, M, G, N>(
+//!     s: &Scope<'s>, device_id: usize, startup: &StartupSettings, mapper: M,
+//!     start_pos: impl Fn(&mut StdRng) -> B + Send + Sync + Clone + 'static,
+//!     update_sender: Sender<GeneratorUpdate<B>>,
+//!     load_network: impl Fn(Arc<G>) -> N + Send + Clone + 'static,      // the only new parameter
+//! ) -> (Vec<Sender<Settings>>, Vec<GraphSender<G>>)
+//! where B: Board + Hash, M: BoardMapper<B> + 'static, G: Send + Sync + 'static, N: Network<B>
+//! {
+//!     /* server_alphazero.rs:39-123 unchanged, except :106 */
+//!     //     let inner = CudaNetwork::new(mapper, &graph, gpu_batch_size, device);     becomes
+//!     //     let inner = load_network(graph);
+//! }
+//! ```
+//!
+//! `AlphaZeroSpecialization::spawn_device_threads` becomes the call
+//! `spawn_alphazero_device_threads(s, device_id, startup, mapper, start_pos, update_sender,
+//!     move |graph: Arc<Graph>| CudaNetwork::new(mapper, &graph, gpu_batch_size, device))`,
+//! and this file supplies the same call with the HIP constructor, plus the model loader and the device list.
 //!
 //! Generators, MCTS, job channel, `batched_executor_loop`, collector, commander and the wire protocol are untouched.
 //! NOT compiled in this repository's CI (no cargo in the build image); written against the cited signatures and kept
@@ -39,17 +57,13 @@ use board_game::board::Board;
 use crossbeam::thread::Scope;
 use flume::Sender;
 use rand::rngs::StdRng;
-use rand::thread_rng;
 
 use kz_core::mapping::BoardMapper;
 use kz_core::network::hip::{HipDevice, HipDtype, HipModel, HipNetwork};
-use kz_core::network::symmetry::RandomSymmetryNetwork;
-use kz_core::network::Network;
 
-use crate::server::executor::{batched_executor_loop, RunCondition};
-use crate::server::protocol::{Evals, GeneratorUpdate, Settings, StartupSettings};
+use crate::server::protocol::{GeneratorUpdate, Settings, StartupSettings};
 use crate::server::server::{GraphSender, ZeroSpecialization};
-use crate::server::server_alphazero::spawn_alphazero_generators;
+use crate::server::server_alphazero::spawn_alphazero_device_threads;
 
 #[derive(Debug)]
 pub struct HipSpecialization {
@@ -89,53 +103,12 @@ impl<B: Board + Hash, M: BoardMapper<B> + 'static> ZeroSpecialization<B, M> for 
         start_pos: impl Fn(&mut StdRng) -> B + Send + Sync + Clone + 'static,
         update_sender: Sender<GeneratorUpdate<B>>,
     ) -> (Vec<Sender<Settings>>, Vec<GraphSender<HipModel>>) {
-        let (settings_senders, eval_server) =
-            spawn_alphazero_generators(s, device_id, startup, mapper, start_pos, update_sender.clone());
-
-        let gpu_batch_size = startup.gpu_batch_size;
-        let eval_job_count = gpu_batch_size / startup.search_batch_size; // server_alphazero.rs:48
-        let eval_random_symmetries = startup.eval_random_symmetries;
-        let dtype = self.dtype;
-
-        let mut graph_senders: Vec<GraphSender<HipModel>> = vec![];
-        // spawn gpu eval threads (server_alphazero.rs:89-121 with the network constructor exchanged)
-        for local_id in 0..startup.gpu_threads_per_device {
-            let (graph_sender, graph_receiver) = flume::bounded(1);
-            graph_senders.push(graph_sender);
-
-            let eval_server = eval_server.clone();
-            let update_sender = update_sender.clone();
-
-            s.builder()
-                .name(format!("gpu-expand-{}-{}", device_id, local_id))
-                .spawn(move |_| {
-                    batched_executor_loop(
-                        gpu_batch_size,
-                        RunCondition::JobCount(eval_job_count),
-                        graph_receiver,
-                        eval_server,
-                        // one engine per executor thread, created on that thread (executor.rs:320-342); engines of
-                        // one device share the uploaded weights inside libkzhip
-                        |graph| {
-                            graph.map_left(|model: Arc<HipModel>| {
-                                let inner = HipNetwork::new(mapper, model, gpu_batch_size, device, dtype);
-                                RandomSymmetryNetwork::new(inner, thread_rng(), eval_random_symmetries)
-                            })
-                        },
-                        |network, x| {
-                            let y = network.evaluate_batch(&x);
-                            // the collector's `real` evals/s (server_alphazero.rs:111-117)
-                            let msg =
-                                GeneratorUpdate::ExpandEvals(Evals::new(x.len() as u64, gpu_batch_size as u64, 0));
-                            update_sender.send(msg).unwrap();
-                            y
-                        },
-                    );
-                })
-                .unwrap();
-        }
-
-        (settings_senders, graph_senders)
+        let (gpu_batch_size, dtype) = (startup.gpu_batch_size, self.dtype);
+        // one engine per executor thread, created on that thread by `handle_new_graph` (executor.rs:320-342); engines of
+        // one device share the uploaded weights inside libkzhip
+        spawn_alphazero_device_threads(s, device_id, startup, mapper, start_pos, update_sender, move |model: Arc<HipModel>| {
+            HipNetwork::new(mapper, model, gpu_batch_size, device, dtype)
+        })
     }
 
     /// The ONNX path of `Command::NewNetwork` (protocol.rs:36) goes straight to the C ABI; the mapper supplies the one

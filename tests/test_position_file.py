@@ -59,10 +59,15 @@ def test_outcome_metadata_is_real_or_nan(tmp_path):
     w.finish()
     meta = json.load(open(path + ".json"))
     assert meta["root_wdl"] == pytest.approx([1 / 3, 1 / 3, 1 / 3]) and meta["hit_move_limit"] == pytest.approx(1 / 3)
+    # f32 averages the way serde_json prints them (shortest decimal of the f32), not 6 or 17 significant digits
+    assert '"hit_move_limit": 0.33333334' in open(path + ".json").read()
     path2 = str(tmp_path / "games_8")
     _write(path2, games, shape, ns, pshape)
-    meta2 = json.load(open(path2 + ".json"))
-    assert all(math.isnan(v) for v in meta2["root_wdl"]) and math.isnan(meta2["hit_move_limit"])
+    # strict JSON: serde_json writes an f32 NaN as null, and a bare NaN token would be rejected by it (and by this parser)
+    meta2 = json.loads(open(path2 + ".json").read(), parse_constant=lambda c: pytest.fail(f"non-JSON constant {c}"))
+    assert meta2["root_wdl"] == [None, None, None] and meta2["hit_move_limit"] is None
+    back = PositionFile(path2).meta
+    assert all(math.isnan(v) for v in back.root_wdl) and math.isnan(back.hit_move_limit)
     assert len(PositionFile(path2)) == sum(len(g) for g in games)
 
 

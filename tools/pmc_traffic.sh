@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-side bytes per launch of a workload's dominant kernel: two separate rocprofv3 --pmc passes (FETCH_SIZE, then
-# WRITE_SIZE; never combined with traces), summarised into profiles/hbm_traffic.json by tools/pmc_traffic.py.
+# WRITE_SIZE; --pmc with --kernel-trace only, never with the sys / hip / hsa trace domains), summarised into profiles/hbm_traffic.json by tools/pmc_traffic.py.
 #   [STEPS=60 WARMUP=10] tools/pmc_traffic.sh chess-20x256 f16 [batch]      (per-layer paths: STEPS=4 WARMUP=1 — a Go
 #   batch is 85 launches and counter collection serialises every one of them)
 # One engine (counter collection serialises launches); run on the GPU box from the repo root.

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/r2b
 python3 bench.py > gpurun_out/r2b/bench.json 2> gpurun_out/r2b/bench.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2b/bench_driver_cmd.json 2> gpurun_out/r2b/bench_driver_cmd.err
 rm -rf gpurun_out/r2b/stats gpurun_out/r2b/stats_a1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2b/stats -o run -- python3 bench.py --steps 2000 --no-cpu-baseline > gpurun_out/r2b/stats_bench.json 2> gpurun_out/r2b/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2b/stats -o run -- python3 bench.py --steps 2000 --no-cpu-baseline --no-seam > gpurun_out/r2b/stats_bench.json 2> gpurun_out/r2b/stats.log
 cp $(find gpurun_out/r2b/stats -name "*kernel_stats.csv" | head -1) gpurun_out/r2b/kernel_stats_default_bench.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2b/stats_a1 -o run -- python3 bench.py --workload ataxx-8x128 --dtype f32 --steps 3000 --no-cpu-baseline --no-others --no-seam > gpurun_out/r2b/a1_bench.json 2> gpurun_out/r2b/stats_a1.log
 cp $(find gpurun_out/r2b/stats_a1 -name "*kernel_stats.csv" | head -1) gpurun_out/r2b/kernel_stats_a1_f32.csv

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-3 evidence, run on the GPU box from the repo root: the default bench line, the driver's command, rocprofv3 kernel
+# stats of the default command (sub-records included, the seam left out: a profiled process must not start GPU-using
+# children), FETCH_SIZE / WRITE_SIZE passes of the kernels that changed this round (Go board convolution, split-f16
+# launch), clock / MFMA-busy pass of the Go kernel.  Copies what is judged into profiles/r3/ (tracked).
+export TMPDIR=/tmp
+O=gpurun_out/r3
+mkdir -p $O profiles/r3
+python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+rm -rf $O/stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --steps 2000 --no-cpu-baseline --no-seam > $O/stats_bench.json 2> $O/stats.log
+# the stats file of the bench process itself (a run directory may hold more than one process's files)
+f=$(ls -S $(find $O/stats -name "*kernel_stats.csv") | head -1)
+cp "$f" $O/kernel_stats_default_bench.csv
+rm -rf $O/stats
+python3 tools/show_bench.py $O/bench.json
+python3 tools/show_bench.py $O/bench_driver_cmd.json
+head -12 $O/kernel_stats_default_bench.csv | cut -c1-170
+STEPS=4 WARMUP=1 bash tools/pmc_traffic.sh go19-40x256 f16
+STEPS=30 WARMUP=5 bash tools/pmc_traffic.sh chess-20x256 f32split16
+bash tools/pmc_go.sh | tee $O/clock_and_mfma_go19.txt
+cp $O/bench.json profiles/r3/bench.json
+cp $O/bench_driver_cmd.json profiles/r3/bench_driver_cmd.json
+cp $O/kernel_stats_default_bench.csv profiles/r3/kernel_stats_default_bench.csv
+cp $O/clock_and_mfma_go19.txt profiles/r3/clock_and_mfma_go19.txt
