@@ -119,17 +119,28 @@ struct DeviceWeights {
     }
 
     // 3x3 tower conv for the board-tile kernel (kz_board_conv.hip)
-    int upload_board_conv(const Conv &cv, DevConv &d) {
+    // (the stem's few input planes are padded with zero weights to the kernel's 64-channel chunk: cin_pad)
+    int upload_board_conv(const Conv &cv, DevConv &d, int cin_pad = 0) {
         d.k = 3;
         d.cout = d.cout_p = cv.cout;
-        d.cin_p = cv.cin;
-        std::vector<uint16_t> packed(kz::board_conv_weight_elems(cv.cin, cv.cout));
+        const int cin = cin_pad ? cin_pad : cv.cin;
+        d.cin_p = cin;
+        std::vector<float> padded;
+        const float *w = cv.w.data();
+        if (cin != cv.cin) {
+            padded.assign((size_t)cv.cout * cin * 9, 0.0f);
+            for (int o = 0; o < cv.cout; o++)
+                for (int i = 0; i < cv.cin; i++)
+                    for (int t = 0; t < 9; t++) padded[((size_t)o * cin + i) * 9 + t] = cv.w[((size_t)o * cv.cin + i) * 9 + t];
+            w = padded.data();
+        }
+        std::vector<uint16_t> packed(kz::board_conv_weight_elems(cin, cv.cout));
 #ifdef KZ_EXPERIMENTS
         d.bw2 = conv2;
-        if (conv2) kz::board_conv2_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        if (conv2) kz::board_conv2_pack_weights(w, cv.cout, cin, packed.data());
         else
 #endif
-        kz::board_conv_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        kz::board_conv_pack_weights(w, cv.cout, cin, packed.data());
         if (upload(packed.data(), packed.size() * 2, &d.bw)) return 1;
         return upload_f32(cv.b, &d.b);
     }
@@ -191,6 +202,7 @@ struct DeviceWeights {
     }
 
     bool use_board_conv = false;
+    int stem_cin_p = 0;  // != 0: the stem goes through the board-tile kernel and wants encoded rows of this many channels
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
     int *bc_rowmap = nullptr;  // kz_board_conv_f16's tile-row map and halo-row list for this board size
     unsigned short *bc_halo = nullptr;
@@ -302,9 +314,18 @@ struct DeviceWeights {
                 if (upload(halo.data(), halo.size() * sizeof(unsigned short), (void **)&bc_halo)) return 1;
             }
             for (size_t i = 0; i < m.tower.size(); i++) {
-                const bool board = use_board_conv && !(noboard && noboard[0] == '1') &&
-                                   kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
-                if (board ? upload_board_conv(m.tower[i], tower[i]) : upload_conv(m.tower[i], tower[i])) return 1;
+                const bool on = use_board_conv && !(noboard && noboard[0] == '1');
+                // the stem joins the board-tile family with its input planes padded to one 64-channel chunk (the encode
+                // kernel then writes 64-channel rows): a quarter of a tower layer's work instead of an implicit GEMM
+                const bool stem64 = on && i == 0 && !conv2 && m.tower[0].cin <= 64 && m.tower[0].k == 3 &&
+                                    kz::board_conv_supported(dtype, m.h, m.w, 64, m.tower[0].cout);
+                const bool board = on && kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
+                if (stem64) {
+                    stem_cin_p = 64;
+                    if (upload_board_conv(m.tower[0], tower[0], 64)) return 1;
+                } else if (board ? upload_board_conv(m.tower[i], tower[i]) : upload_conv(m.tower[i], tower[i])) {
+                    return 1;
+                }
             }
         }
 
@@ -1068,6 +1089,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         if (nzc && nzc[0] == '1') e->zero_copy = false;
 #endif
     }
+    if (e->wts->stem_cin_p) e->cin_p = e->wts->stem_cin_p;
     const size_t hw = (size_t)m.h * m.w, rows = (size_t)max_batch * hw;
     if (e->dmalloc(&e->x_in, rows * e->cin_p * e->esz)) return 1;
 #ifdef KZ_EXPERIMENTS

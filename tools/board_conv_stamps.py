@@ -57,12 +57,11 @@ if gaps:
     print("gap between consecutive workgroups on a CU slot: mean %.0f p10 %.0f p50 %.0f p90 %.0f" %
           (gaps.mean(), np.percentile(gaps, 10), np.percentile(gaps, 50), np.percentile(gaps, 90)))
 
-# ---- finer set-up stamps (21..24), when present ----
+# ---- finer set-up stamps, when present ----
 if (d[:, :, 21] > 0).all():
-    pn = ["start->ring issued", "zero fill", "slot table", "T0"]
-    seq = [0, 21, 22, 23, 24]
-    for k in range(4):
-        seg = d[:, :, seq[k + 1]] - d[:, :, seq[k]]
-        print(f"  set-up: {pn[k]:20s} mean {seg.mean():7.0f}")
-    seg = d[:, :, 1] - d[:, :, 24]
-    print(f"  set-up: {'acc init':20s} mean {seg.mean():7.0f}")
+    seq = [(0, "start"), (25, "kernel arguments, priority, ids"), (26, "12 slots located, chunk-0 loads issued"), (21, "weight ring issued"),
+           (22, "halo cleared"), (24, "fragment rows"), (1, "accumulators initialised")]
+    seq = [(k, n) for k, n in seq if (d[:, :, k] > 0).all()]
+    for (k0, _), (k1, n1) in zip(seq, seq[1:]):
+        seg = d[:, :, k1] - d[:, :, k0]
+        print(f"  set-up: {n1:42s} mean {seg.mean():7.0f}  p10 {np.percentile(seg, 10):7.0f}  p90 {np.percentile(seg, 90):7.0f}")
