@@ -59,17 +59,6 @@ constexpr int KPC = 18;                // k-steps (32 channels of one tap) per c
 #endif
 constexpr int PF = KZ_BC_PF;           // weight ring depth in k-steps (a k-step is 24 MFMAs = 384 cycles per wave)
 static_assert(KPC % PF == 0, "ring stage of a k-step must not depend on the chunk");
-#ifdef KZ_BC_WLDS
-// Weights ONCE per workgroup: the four waves of a workgroup multiply the same 4 KB of weights per k-step, and loading them
-// four times kept the CU's L1 / texture path at 53 of its 64 B/clk — every other load and store of the CU (image staging,
-// residual, output, the partner workgroup's set-up) queued behind that stream.  Here each wave loads ONE quarter of a
-// k-step (fragment nt = wave, WD k-steps ahead, 4 registers each), writes it into a three-slot ring in LDS two k-steps
-// before its use, and all four waves read their A fragments from there one k-step ahead of their MFMAs; one s_barrier
-// per k-step orders the ring (a slot written during k-step g is read during g + 1 for g + 2, and written again during g + 3).
-constexpr int WSLOT = 4 * 64 * 16, WSLOTS = 3, WD = 3;
-static_assert(KPC % WSLOTS == 0 && KPC % WD == 0 && KPC % 2 == 0, "slot, register and buffer of a k-step must not depend on the chunk");
-constexpr int PFK = 6;                 // k-step of a chunk at which the next chunk's image pieces (or the residual's) are requested
-#endif
 
 // fragment read from an integer LDS byte address (the dynamic LDS block starts at 0; going through the `lds` symbol
 // costs a v_add per read)
@@ -116,7 +105,6 @@ struct BoardConvDev {
                                        // values they meet
     int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
     int rm_off;             // LDS offset of the 384 image-row indices (u16), behind the image / the epilogue's output tile
-    int w_off;              // KZ_BC_WLDS: LDS offset of the weight ring, behind the row indices
     unsigned long long *stamps;  // diagnostic build only
 };
 
@@ -192,23 +180,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     }
 
     KZ_STAMP(26);
-#ifdef KZ_BC_WLDS
-    // this wave's quarter (fragment nt = wave) of k-step ks of this (layer, quarter): [k-step][nt 4][lane] x 16 B
-    const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + wave * 64 + lane;
-    auto wq_load = [&](int ks) __attribute__((always_inline)) { return wp[(size_t)(ks < total_ksteps ? ks : total_ksteps - 1) * 256]; };
-    const int wq_lds = a.w_off + wave * 1024 + lane * 16;  // where that quarter goes in a slot
-    const int wa_lds = a.w_off + lane * 16;                // where fragment nt of a slot is read from: + nt * 1024
-    uint4 wq[WD];  // wq[ks % WD] = the quarter of k-step ks, for the WD k-steps behind the two that are already in LDS
-    {
-        const uint4 q0 = wq_load(0), q1 = wq_load(1);
-#pragma unroll
-        for (int j = 0; j < WD; j++) wq[(2 + j) % WD] = wq_load(2 + j);
-        *reinterpret_cast<uint4 *>(lds + wq_lds) = q0;
-        *reinterpret_cast<uint4 *>(lds + wq_lds + WSLOT) = q1;
-    }
-    u32x4 pf[12];  // the next chunk's image pieces / the residual's, requested at k-step PFK of a chunk
-    h16x8 wa[2][NTW];  // A fragments: wa[ks & 1] feeds k-step ks, wa[(ks + 1) & 1] is being read for the next one
-#else
     // weight ring: k-step g of this (layer, quarter): 4 KB = [nt 4][lane] x 16 B, the same for the four waves
     const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + lane;
     uint4 wreg[PF][NTW];
@@ -218,7 +189,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) wreg[s][nt] = wp[(size_t)g * 256 + (wo * NTW + nt) * 64];
     }
-#endif
     int g = 0;  // k-step counter; at a chunk boundary the ring holds k-steps g .. g + PF - 1
 
     KZ_STAMP(21);
@@ -290,12 +260,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     for (int chunk = 0; chunk < chunks; chunk++) {
         __syncthreads();  // the chunk is staged
         KZ_STAMP(4 + chunk * 4);
-#ifdef KZ_BC_WLDS
-        if (chunk == 0) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++) wa[0][nt] = lds_frag(wa_lds + nt * 1024);  // k-step 0 (slot 0)
-        }
-#endif
         // what the ring's dying stages fetch during the last PF k-steps of this chunk: the next chunk's image pieces, or
         // (last chunk) the residual's, or nothing
         // (no branch in the k-loop: one descriptor and one scalar offset, selected here; without a residual the last
@@ -323,45 +287,21 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const int stage = (tap * 2 + ks) % PF;
-                (void)stage;
-#ifdef KZ_BC_WLDS
-                constexpr int dummy_ = 0;
-                (void)dummy_;
-                const int kidx = tap * 2 + ks;
-                // every wave has issued the previous k-step's MFMAs (its reads of slot g % 3 — made one k-step earlier —
-                // and of the slot this k-step overwrites are long done) and has written its quarter of k-step g + 1
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++) wa[(kidx + 1) & 1][nt] = lds_frag(wa_lds + ((kidx + 1) % WSLOTS) * WSLOT + nt * 1024);
-                *reinterpret_cast<uint4 *>(lds + wq_lds + ((kidx + 2) % WSLOTS) * WSLOT) = wq[(kidx + 2) % WD];
-                wq[(kidx + 2) % WD] = wq_load(g + 2 + WD);
-                if (kidx == PFK) {  // (compile time) pieces of the next image chunk / the residual: 12 k-steps of flight
-#pragma unroll
-                    for (int i = 0; i < 12; i++) pf[i] = __builtin_amdgcn_raw_buffer_load_b128(trsrc, po[i], tsoff, 0);
-                }
-#endif
                 // ---- half 1 ----
 #pragma unroll
                 for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i] + ks * 32);
                 if (!skip_last_tile) bfB[HT - 1] = lds_frag(T[MTW - 1] + ks * 32);
                 h16x8 af[NTW];  // aliases of the ring stage (no copy: the stage is reloaded after this k-step's MFMAs)
-#ifdef KZ_BC_WLDS
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++) af[nt] = wa[kidx & 1][nt];
-#else
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
-#endif
 #pragma unroll
                 for (int i = 0; i < HT; i++)
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++)
                         acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfA[i], acc[nt][i], 0, 0, 0);
                 // the reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
-#ifndef KZ_BC_WLDS
                 __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT - 1, 0);
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- half 2 ----
                 // T is updated in place for the next tap: rows 0..2 are dead after the last half-2 read of this tap,
@@ -384,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                         acc[nt][MTW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[HT - 1], acc[nt][MTW - 1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef KZ_BC_WLDS
                 // this stage's fragments have been issued to the MFMAs: refill it
                 if (tap * 2 + ks < KPC - PF) {  // (compile time) with the weights of k-step g + PF
 #pragma unroll
@@ -396,7 +335,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                     for (int nt = 0; nt < NTW; nt++)
                         wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po[jj * 4 + nt], tsoff, 0));
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 g++;
             }
@@ -410,11 +348,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
             for (int i = 0; i < 12; i++) erow[i] = *reinterpret_cast<const unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2);
             __syncthreads();
             KZ_STAMP(6 + chunk * 4);
-#ifdef KZ_BC_WLDS
-#pragma unroll
-            for (int i = 0; i < 12; i++)
-                if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + erow[i] * PRS + ls_piece) = pf[i];  // never into the halo
-#else
 #pragma unroll
             for (int i = 0; i < 12; i++)
                 if (po[i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * PRS + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
@@ -422,7 +355,6 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
             for (int st = 0; st < PF; st++)
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) wreg[st][nt] = wp[(size_t)(g + st) * 256 + (wo * NTW + nt) * 64];
-#endif
             KZ_STAMP(7 + chunk * 4);
         }
     }
@@ -437,11 +369,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
     if (with_res) {
 #pragma unroll
-#ifdef KZ_BC_WLDS
-        for (int i = 0; i < 12; i++) *reinterpret_cast<u32x4 *>(lds + out_lds + i * 32 * ORS) = pf[i];
-#else
         for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
-#endif
         __syncthreads();
     }
 #pragma unroll
@@ -486,11 +414,7 @@ namespace {
 struct Geometry {
     int tpb, bpw, pitch, rpb, plane, rm_off, lds_bytes;
 };
-#ifdef KZ_BC_WLDS
-constexpr int RM_BYTES = ROWS * 2 + WSLOTS * WSLOT;  // the row indices and, behind them, the weight ring
-#else
 constexpr int RM_BYTES = ROWS * 2;
-#endif
 Geometry geometry(int h, int w) {
     Geometry g{};
     g.tpb = (h * w + 15) / 16;
@@ -578,7 +502,6 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.rpb = geo.rpb;
     d.plane = geo.plane;
     d.rm_off = geo.rm_off;
-    d.w_off = geo.rm_off + ROWS * 2;
     d.cin = t.cin;
     d.relu = t.relu;
     d.groups = (t.boards + d.bpw - 1) / d.bpw;
