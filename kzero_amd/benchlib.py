@@ -86,11 +86,13 @@ def check_distinct(bus_ids, world: int):
     return f"{world} ranks on {len(set(bus_ids))} distinct GPU(s): {list(bus_ids)}"
 
 
-def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes"):
+def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: str = "/dev/dri"):
     """PCI bus ids ("0000:c1:00.0") of the GPU nodes in KFD topology order — the order HIP enumerates devices in before
     HIP_VISIBLE_DEVICES is applied — read from sysfs, so that a rank can find its GPU's NUMA node BEFORE its first HIP
-    call.  [] when the topology is not readable."""
-    out = []
+    call.  A container may see the whole node's topology but only the render nodes of the GPUs it was given: a GPU whose
+    /dev/dri/renderD<drm_render_minor> this process cannot open is not one HIP will enumerate, and is left out (when no
+    render node is listed at all the filter is off).  [] when the topology is not readable."""
+    out, usable = [], []
     try:
         nodes = sorted((int(n) for n in os.listdir(root) if n.isdigit()))
     except OSError:
@@ -110,6 +112,10 @@ def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes"):
         except (KeyError, ValueError):
             continue
         out.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
+        minor = props.get("drm_render_minor")
+        usable.append(minor is None or os.access(os.path.join(dri_root, f"renderD{minor}"), os.R_OK | os.W_OK))
+    if any(usable) and not all(usable):
+        out = [b for b, ok in zip(out, usable) if ok]
     return out
 
 
@@ -155,7 +161,7 @@ def node_cpus(node: int, root: str = "/sys/devices/system/node"):
 
 def bind_to_gpu_numa(ordinal: int, bus_id: str = None, kfd_root: str = "/sys/class/kfd/kfd/topology/nodes",
                      pci_root: str = "/sys/bus/pci/devices", node_root: str = "/sys/devices/system/node", env=None,
-                     apply: bool = True):
+                     apply: bool = True, dri_root: str = "/dev/dri"):
     """Pins this process to the CPUs of the NUMA node its GPU hangs off, so that the executor threads run and the
     zero-copy pinned staging (hipHostMalloc, first touched by the allocating thread) lands next to the device.  Call it
     before the first HIP call with `bus_id=None` (the bus id is then taken from the KFD topology); call it again with
@@ -164,7 +170,7 @@ def bind_to_gpu_numa(ordinal: int, bus_id: str = None, kfd_root: str = "/sys/cla
     try:
         if bus_id is None:
             idx = visible_index(ordinal, env)
-            ids = kfd_gpu_bus_ids(kfd_root)
+            ids = kfd_gpu_bus_ids(kfd_root, dri_root)
             if idx is None or idx >= len(ids):
                 return rec
             bus_id = rec["bus_id"] = ids[idx]

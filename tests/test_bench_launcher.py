@@ -146,8 +146,10 @@ def test_numa_binding_from_sysfs(tmp_path):
     for n, cpus in ((0, allowed[:half]), (1, allowed[half:] or allowed[:half])):
         (node / f"node{n}").mkdir(parents=True)
         (node / f"node{n}" / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
-    roots = dict(kfd_root=str(kfd), pci_root=str(pci), node_root=str(node), apply=False)
-    assert benchlib.kfd_gpu_bus_ids(str(kfd)) == ["0000:05:00.0", "0000:c5:00.0"]
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    roots = dict(kfd_root=str(kfd), pci_root=str(pci), node_root=str(node), apply=False, dri_root=str(dri))
+    assert benchlib.kfd_gpu_bus_ids(str(kfd), str(dri)) == ["0000:05:00.0", "0000:c5:00.0"]
     r1 = benchlib.bind_to_gpu_numa(1, env={}, **roots)
     assert (r1["bus_id"], r1["numa_node"]) == ("0000:c5:00.0", 1) and r1["cpus"] >= 1 and not r1["bound"]
     # a rank whose launcher masked the GPUs drives ordinal 0 of its mask
@@ -159,6 +161,13 @@ def test_numa_binding_from_sysfs(tmp_path):
     assert benchlib.bind_to_gpu_numa(0, env={"HIP_VISIBLE_DEVICES": "GPU-abc"}, **roots)["numa_node"] is None
     assert benchlib.bind_to_gpu_numa(0, kfd_root=str(tmp_path / "missing"), apply=False)["bound"] is False
     assert benchlib.node_cpus(0, str(node)) == set(allowed[:half])
+    # a container that sees the whole node's topology but was given one GPU's render node: only that GPU is enumerated
+    for i, minor in ((1, 128), (2, 129)):
+        with open(kfd / str(i) / "properties", "a") as f:
+            f.write(f"drm_render_minor {minor}\n")
+    (dri / "renderD129").write_text("")
+    assert benchlib.kfd_gpu_bus_ids(str(kfd), str(dri)) == ["0000:c5:00.0"]
+    assert benchlib.bind_to_gpu_numa(0, env={}, **roots)["bus_id"] == "0000:c5:00.0"
     # pick_device: one per rank, a single masked device, or refusal
     assert benchlib.pick_device(8, 3, 8) == (3, None) and benchlib.pick_device(1, 3, 8) == (0, None)
     assert benchlib.pick_device(2, 3, 8)[0] is None
