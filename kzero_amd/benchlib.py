@@ -86,13 +86,13 @@ def check_distinct(bus_ids, world: int):
     return f"{world} ranks on {len(set(bus_ids))} distinct GPU(s): {list(bus_ids)}"
 
 
-def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: str = "/dev/dri"):
-    """PCI bus ids ("0000:c1:00.0") of the GPU nodes in KFD topology order — the order HIP enumerates devices in before
-    HIP_VISIBLE_DEVICES is applied — read from sysfs, so that a rank can find its GPU's NUMA node BEFORE its first HIP
-    call.  A container may see the whole node's topology but only the render nodes of the GPUs it was given: a GPU whose
-    /dev/dri/renderD<drm_render_minor> this process cannot open is not one HIP will enumerate, and is left out (when no
-    render node is listed at all the filter is off).  [] when the topology is not readable."""
-    out, usable = [], []
+def kfd_gpu_nodes(root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: str = "/dev/dri"):
+    """The GPU nodes of the KFD topology in its order — the order HIP enumerates devices in before HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES are applied — as PCI bus ids ("0000:c1:00.0"), read from sysfs so that a rank can find its GPU's
+    NUMA node BEFORE its first HIP call.  A container may see the whole node's topology but only the GPUs it was given:
+    a node whose properties cannot be read, or whose /dev/dri/renderD<drm_render_minor> this process cannot open, is a
+    GPU HIP will not enumerate here; it keeps its place in the list as None (a device mask may count it)."""
+    out = []
     try:
         nodes = sorted((int(n) for n in os.listdir(root) if n.isdigit()))
     except OSError:
@@ -104,6 +104,7 @@ def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: s
                 k, _, v = line.strip().partition(" ")
                 props[k] = v
         except OSError:
+            out.append(None)  # not ours to look at: another tenant's GPU
             continue
         try:
             if int(props.get("simd_count", "0")) <= 0:
@@ -111,12 +112,17 @@ def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: s
             loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
         except (KeyError, ValueError):
             continue
-        out.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
         minor = props.get("drm_render_minor")
-        usable.append(minor is None or os.access(os.path.join(dri_root, f"renderD{minor}"), os.R_OK | os.W_OK))
-    if any(usable) and not all(usable):
-        out = [b for b, ok in zip(out, usable) if ok]
+        if minor is not None and os.path.isdir(dri_root) and not os.access(os.path.join(dri_root, f"renderD{minor}"), os.R_OK | os.W_OK):
+            out.append(None)
+            continue
+        out.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
     return out
+
+
+def kfd_gpu_bus_ids(root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: str = "/dev/dri"):
+    """Bus ids of the GPUs this process can use, in KFD order."""
+    return [b for b in kfd_gpu_nodes(root, dri_root) if b is not None]
 
 
 def visible_index(ordinal: int, env=None):
@@ -169,11 +175,20 @@ def bind_to_gpu_numa(ordinal: int, bus_id: str = None, kfd_root: str = "/sys/cla
     rec = {"bus_id": bus_id, "numa_node": None, "cpus": None, "bound": False}
     try:
         if bus_id is None:
+            # the mask (if any) may count the node's GPUs or only the ones this container was given: try both readings,
+            # and when exactly one GPU is usable at all it is that one
             idx = visible_index(ordinal, env)
-            ids = kfd_gpu_bus_ids(kfd_root, dri_root)
-            if idx is None or idx >= len(ids):
+            every, usable = kfd_gpu_nodes(kfd_root, dri_root), kfd_gpu_bus_ids(kfd_root, dri_root)
+            guess = None
+            if idx is not None and idx < len(every) and every[idx] is not None:
+                guess = every[idx]
+            elif idx is not None and idx < len(usable):
+                guess = usable[idx]
+            elif len(usable) == 1:
+                guess = usable[0]
+            if guess is None:
                 return rec
-            bus_id = rec["bus_id"] = ids[idx]
+            bus_id = rec["bus_id"] = guess
         node = numa_node_of(bus_id, pci_root)
         rec["numa_node"] = node
         if node is None:

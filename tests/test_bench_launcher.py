@@ -168,6 +168,11 @@ def test_numa_binding_from_sysfs(tmp_path):
     (dri / "renderD129").write_text("")
     assert benchlib.kfd_gpu_bus_ids(str(kfd), str(dri)) == ["0000:c5:00.0"]
     assert benchlib.bind_to_gpu_numa(0, env={}, **roots)["bus_id"] == "0000:c5:00.0"
+    # ... also when a device mask counts the node's GPUs (ROCR_VISIBLE_DEVICES=1 = the second GPU of the node) or names
+    # an index beyond what the container shows (one usable GPU: it is that one)
+    assert benchlib.kfd_gpu_nodes(str(kfd), str(dri)) == [None, "0000:c5:00.0"]
+    assert benchlib.bind_to_gpu_numa(0, env={"ROCR_VISIBLE_DEVICES": "1"}, **roots)["bus_id"] == "0000:c5:00.0"
+    assert benchlib.bind_to_gpu_numa(0, env={"ROCR_VISIBLE_DEVICES": "5"}, **roots)["bus_id"] == "0000:c5:00.0"
     # pick_device: one per rank, a single masked device, or refusal
     assert benchlib.pick_device(8, 3, 8) == (3, None) and benchlib.pick_device(1, 3, 8) == (0, None)
     assert benchlib.pick_device(2, 3, 8)[0] is None
