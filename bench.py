@@ -36,6 +36,7 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+FULL_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set()
 
 WORKLOADS = {
     "chess-20x256": dict(game="chess", depth=20, channels=256, head="attention", batch=256, steps=10000,
@@ -373,9 +374,15 @@ def seam_record(blob, seconds, devices=(0,)):
         path = os.path.join("/tmp", f"kz_bench_seam_{os.getpid()}.kzm")
         with open(path, "wb") as f:
             f.write(blob)
+        # (the child drives every listed device: it gets the affinity this process had before it bound itself to its own
+        # GPU's NUMA node)
+        def unbind():
+            if hasattr(os, "sched_setaffinity"):
+                os.sched_setaffinity(0, FULL_AFFINITY)
         try:
             out = subprocess.run([exe, path, str(seconds), "1", "6", "256", "8", "f16", "3", "0",
-                                  ",".join(str(d) for d in devices)], capture_output=True, text=True, timeout=120)
+                                  ",".join(str(d) for d in devices)], capture_output=True, text=True, timeout=120,
+                                 preexec_fn=unbind if len(devices) > 1 else None)
         finally:
             os.unlink(path)
         rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
