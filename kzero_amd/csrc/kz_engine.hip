@@ -83,6 +83,7 @@ struct DeviceWeights {
     // scalar head
     float *sh_w0 = nullptr, *sh_b0 = nullptr, *sh_w1 = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
     float *sh_w1t = nullptr;  // sh_w1 transposed: [inputs][outputs]
+    float *sh_w0x = nullptr;  // [hc + 1][C]: the scalar head's 1x1 filters followed by ConvPolicyHead's extra-move filter
     // policy
     DevConv p_conv0;                                   // conv / ataxx_conv / dense hidden conv
     float *p_w1 = nullptr, *p_b1 = nullptr;            // last 1x1 conv of the conv heads
@@ -350,6 +351,11 @@ struct DeviceWeights {
                     if (upload_f32(m.p_extra_conv.w, &pe_wc) || upload_f32(m.p_extra_conv.b, &pe_bc) ||
                         upload_f32(m.p_extra_fc.w, &pe_wl) || upload_f32(m.p_extra_fc.b, &pe_bl))
                         return 1;
+                    if (m.sh_conv.cout == 4 && m.p_extra_conv.cout == 1 && m.p_extra_conv.cin == m.sh_conv.cin) {
+                        std::vector<float> w0x(m.sh_conv.w);  // [4][C] ...
+                        w0x.insert(w0x.end(), m.p_extra_conv.w.begin(), m.p_extra_conv.w.end());  // ... + [1][C]
+                        if (upload_f32(w0x, &sh_w0x)) return 1;
+                    }
                 }
                 break;
             case kz::POLICY_ATTENTION:
@@ -763,6 +769,12 @@ struct kz_engine {
         return 0;
     }
 
+    bool extra_in_scalar_head() const {
+        const Model &m = *model;
+        return m.policy_kind == kz::POLICY_CONV && m.policy_extra_moves > 0 && wts->sh_w0x &&
+               kz::scalar_head_takes_extra(dtype == KZ_DTYPE_F32 || split16 ? 0 : 1, cp, m.sh_conv.cout);
+    }
+
     int run_heads(int batch, float *d_scalars, float *d_policy) {
         if (fused_heads || fused32 || fused_split) return 0;  // written by the tower launch
         const Model &m = *model;
@@ -772,6 +784,12 @@ struct kz_engine {
             kz::ScalarHeadArgs a{x, cp, batch, hw, m.channels, m.sh_conv.cout, m.sh_fc0.out,
                                  wts->sh_w0, wts->sh_b0, wts->sh_w1, wts->sh_b1, wts->sh_w2, wts->sh_b2, d_scalars,
                                  nf_flag, nf_epoch, wts->sh_w1t};
+            // ConvPolicyHead's extra moves read the same tower output: one pass for both (post_act.py:63-67)
+            if (extra_in_scalar_head()) {
+                a.extra = m.policy_extra_moves;
+                a.w0x = wts->sh_w0x; a.pe_bc = wts->pe_bc; a.pe_wl = wts->pe_wl; a.pe_bl = wts->pe_bl;
+                a.policy = d_policy; a.policy_len = m.policy_len; a.policy_offset = m.policy_conv_channels * hw;
+            }
             prof.begin("kz_scalar_head", stream);
             kz::launch_scalar_head(dtype, a, stream);
             prof.end(stream);
@@ -779,15 +797,29 @@ struct kz_engine {
         switch (m.policy_kind) {
             case kz::POLICY_ATAXX_CONV:
             case kz::POLICY_CONV: {
-                if (conv(wts->p_conv0, x, cp, head0, wts->p_conv0.cout_p, M, 1, nullptr, false, m.h, m.w, hw, hw, 0))
-                    return 1;
                 const int pc = m.policy_conv_channels;
-                kz::PolicyConvArgs a{head0, wts->p_conv0.cout_p, batch, hw, m.channels, pc, wts->p_w1, wts->p_b1,
-                                     d_policy, m.policy_len, m.policy_kind == kz::POLICY_ATAXX_CONV ? 1 : 0};
-                prof.begin("kz_policy_conv", stream);
-                kz::launch_policy_conv(dtype, a, stream);
-                prof.end(stream);
-                if (m.policy_kind == kz::POLICY_CONV && m.policy_extra_moves) {
+                const DevConv &c0 = wts->p_conv0;
+                if (m.policy_kind == kz::POLICY_CONV && c0.sw && cp >= c0.cin_p &&
+                    kz::conv1x1_policy_epilogue_supported(c0.cin_p, c0.cout_p, c0.cout, pc)) {
+                    // Conv1x1 C->C + ReLU + Conv1x1 C->1 in one launch: the hidden layer never goes to memory
+                    kz::Conv1x1SplitArgs c{};
+                    c.split = split16;
+                    c.x = x; c.ldx = cp; c.weights = c0.sw; c.bias = c0.b; c.y = nullptr; c.ldy = 0;
+                    c.M = M; c.cin_p = c0.cin_p; c.cout_p = c0.cout_p; c.relu = 1;
+                    c.group = hw; c.src_group = hw; c.src_off = 0;
+                    c.pw1 = wts->p_w1; c.pb1 = wts->p_b1; c.policy = d_policy; c.policy_len = m.policy_len; c.hw = hw;
+                    prof.begin("kz_conv1x1_split", stream);
+                    kz::launch_conv1x1_split(c, stream);
+                    prof.end(stream);
+                } else {
+                    if (conv(c0, x, cp, head0, c0.cout_p, M, 1, nullptr, false, m.h, m.w, hw, hw, 0)) return 1;
+                    kz::PolicyConvArgs a{head0, c0.cout_p, batch, hw, m.channels, pc, wts->p_w1, wts->p_b1,
+                                         d_policy, m.policy_len, m.policy_kind == kz::POLICY_ATAXX_CONV ? 1 : 0};
+                    prof.begin("kz_policy_conv", stream);
+                    kz::launch_policy_conv(dtype, a, stream);
+                    prof.end(stream);
+                }
+                if (m.policy_kind == kz::POLICY_CONV && m.policy_extra_moves && !extra_in_scalar_head()) {
                     kz::PolicyExtraArgs e{x, cp, batch, hw, m.channels, m.policy_extra_moves, wts->pe_wc, wts->pe_bc,
                                           wts->pe_wl, wts->pe_bl, d_policy, m.policy_len, pc * hw};
                     prof.begin("kz_policy_extra", stream);

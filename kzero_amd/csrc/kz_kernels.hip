@@ -467,6 +467,10 @@ struct ScalarHeadDev {
     int *nonfinite_flag;
     int epoch;
     const float *w1t;
+    int extra;
+    const float *w0x, *pe_bc, *pe_wl, *pe_bl;
+    float *policy;
+    int policy_len, policy_offset;
 };
 
 template <typename T>
@@ -474,11 +478,23 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     float *act = sh;                 // [hc*hw], channel-major like nn.Flatten on NCHW (post_act.py:16)
     float *hid = sh + a.hc * a.hw;   // [hs]
+    float *sext = hid + a.hs;        // [hw]: the extra-move plane, when this launch carries ConvPolicyHead.seq_extra
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const T *xb = static_cast<const T *>(a.x) + (size_t)b * a.hw * a.ldx;
 
     bool bad = false;  // a non-finite sum = a non-finite value somewhere in this board's tower output
-    if (a.hc == 4 && rows_coalescable<T>(a.ldx)) {
+    if (a.extra && a.hc == 4 && rows_coalescable<T>(a.ldx)) {
+        // the scalar head's four filters and the extra-move filter in ONE pass over the tower output
+        const float bias[5] = {a.b0[0], a.b0[1], a.b0[2], a.b0[3], a.pe_bc[0]};
+        rows_dot<T, 5>(xb, a.ldx, a.hw, a.c, a.w0x, [&](int p, const float(&sum)[5]) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+                bad |= !(fabsf(sum[ch]) <= 3.0e38f);
+                act[ch * a.hw + p] = fmaxf(sum[ch] + bias[ch], 0.0f);
+            }
+            sext[p] = sum[4] + bias[4];
+        });
+    } else if (a.hc == 4 && rows_coalescable<T>(a.ldx)) {
         const float bias[4] = {a.b0[0], a.b0[1], a.b0[2], a.b0[3]};
         rows_dot<T, 4>(xb, a.ldx, a.hw, a.c, a.w0, [&](int p, const float(&sum)[4]) {
 #pragma unroll
@@ -539,12 +555,29 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
         acc = wave_sum(acc);
         if (lane == 0) a.out[(size_t)b * 5 + j] = acc + a.b2[j];
     }
+    if (a.extra) {  // Linear(hw -> extra) behind the policy planes (sext is complete since the first barrier)
+        for (int j = wave; j < a.extra; j += 4) {
+            float acc = 0.0f;
+            for (int p = lane; p < a.hw; p += 64) acc += a.pe_wl[(size_t)j * a.hw + p] * sext[p];
+            acc = wave_sum(acc);
+            if (lane == 0) a.policy[(size_t)b * a.policy_len + a.policy_offset + j] = acc + a.pe_bl[j];
+        }
+    }
+}
+
+// whether kz_scalar_head can carry ConvPolicyHead's extra-move head in its pass over the tower output: four scalar-head
+// filters and whole 16-byte pieces per row in a power-of-two count (rows_dot)
+bool scalar_head_takes_extra(int dtype, int ldx, int hc) {
+    const int epl = dtype == 0 ? 4 : 8, g = ldx / epl;
+    return hc == 4 && ldx % epl == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0;
 }
 
 void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream) {
+    const bool extra = a.extra > 0 && a.w0x && scalar_head_takes_extra(dtype, a.ldx, a.hc);
     ScalarHeadDev d{a.x, a.ldx, a.batch, a.hw, a.c, a.hc, a.hs, a.w0, a.b0, a.w1, a.b1, a.w2, a.b2, a.out,
-                    a.nonfinite_flag, a.epoch, a.w1t};
-    size_t shmem = sizeof(float) * ((size_t)a.hc * a.hw + a.hs);
+                    a.nonfinite_flag, a.epoch, a.w1t, extra ? a.extra : 0, a.w0x, a.pe_bc, a.pe_wl, a.pe_bl, a.policy,
+                    a.policy_len, a.policy_offset};
+    size_t shmem = sizeof(float) * ((size_t)a.hc * a.hw + a.hs + (extra ? a.hw : 0));
     if (dtype == 0) kz_scalar_head<float><<<a.batch, 256, shmem, stream>>>(d);
     else kz_scalar_head<h16><<<a.batch, 256, shmem, stream>>>(d);
 }

@@ -64,7 +64,15 @@ struct ScalarHeadArgs {
     int epoch = 0;
     const float *w1t = nullptr;  // optional: w1 transposed to [hc*hw][hs] (used when hs == 32: every input's 32 weights are
                                  // 128 contiguous bytes, so the first Linear reads coalesced and without dependent loops)
+    // optional: ConvPolicyHead's extra moves (post_act.py:63-67,84-85: Conv1x1 C->1 on the same tower output, Flatten,
+    // Linear hw -> extra) in the same pass over the tower output: w0x = [hc + 1][c], the scalar head's filters followed by
+    // the extra-move filter (hc == 4 only); the logits go to policy[b * policy_len + policy_offset + j]
+    int extra = 0;
+    const float *w0x = nullptr, *pe_bc = nullptr, *pe_wl = nullptr, *pe_bl = nullptr;
+    float *policy = nullptr;
+    int policy_len = 0, policy_offset = 0;
 };
+bool scalar_head_takes_extra(int dtype, int ldx, int hc);  // the launch below can carry ScalarHeadArgs::extra
 void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream);
 
 // Last 1x1 conv of the conv policy heads: y [batch*hw][ldy] (after conv1x1+ReLU) -> policy[b][oc*hw + p]
@@ -215,8 +223,14 @@ struct Conv1x1SplitArgs {
     void *y;              // f32 (split) or f16
     int ldy, M, cin_p, cout_p, relu, group, src_group, src_off;
     bool split;           // false: plain f16 arithmetic and tensors (behind the one-launch f16 tower)
+    // optional epilogue (conv1x1_policy_epilogue_supported; relu must be set, y is not written): the conv policy head's
+    // second 1x1 convolution with ONE output channel — policy[(r / hw) * policy_len + r % hw] = pb1 + pw1 . relu(hidden[r])
+    const float *pw1 = nullptr, *pb1 = nullptr;
+    float *policy = nullptr;
+    int policy_len = 0, hw = 0;
 };
 bool conv1x1_split_supported(int cin_p, int cout_p);
+bool conv1x1_policy_epilogue_supported(int cin_p, int cout_p, int cout, int policy_channels);
 size_t conv1x1_split_weight_elems(int cin_p, int cout_p, bool split);
 void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, int cin_p, bool split, uint16_t *dst);
 void launch_conv1x1_split(const Conv1x1SplitArgs &a, hipStream_t stream);

@@ -987,9 +987,14 @@ struct Conv1x1SplitDev {
     const float *bias;  // [cout_p]
     void *y;            // f32 (SPLIT) or f16
     int ldx, ldy, M, cin, cout_p, relu, group, src_group, src_off;
+    // PEPI: the conv policy head's second 1x1 convolution (one output channel: Go's ConvPolicyHead, post_act.py:70-73)
+    // as the epilogue of its first — the hidden layer never goes to memory.  policy[(r / hw) * policy_len + r % hw]
+    const float *pw1, *pb1;  // [cout], [1]
+    float *policy;
+    int policy_len, hw;
 };
 
-template <int OT, bool SPLIT>
+template <int OT, bool SPLIT, bool PEPI = false>
 __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
     constexpr int PARTS = SPLIT ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1075,6 +1080,46 @@ __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
                     }
                 }
             }
+        }
+        if constexpr (PEPI) {
+            // policy logit of a row = b1 + sum over all output channels of w1[oc] * relu(hidden[oc]), the hidden value
+            // rounded to the tensor type first (f16 unless SPLIT) as the separate launches did: lanes add their 4 x OT
+            // channels, the four lane groups of a row meet by butterfly, the four waves through LDS (one pass: cout_p ==
+            // 64 * OT, checked by the launcher)
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ot = 0; ot < OT; ot++) {
+                const f32x4 w1 = *reinterpret_cast<const f32x4 *>(a.pw1 + oc0 + ot * 16);
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float h = acc[ot][mt][j];
+                        h = h > 0.0f ? h : 0.0f;
+                        if constexpr (!SPLIT) h = (float)(h16)h;
+                        part[mt] += w1[j] * h;
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                part[mt] += __shfl_xor(part[mt], 16, 64);
+                part[mt] += __shfl_xor(part[mt], 32, 64);
+            }
+            __syncthreads();  // every wave is done reading the staged rows: their LDS is free
+            float *red = reinterpret_cast<float *>(lds);  // [wave 4][row 64]
+            if (kq == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) red[wave * 64 + mt * 16 + fr] = part[mt];
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int r = row0 + tid;
+                if (r < a.M) {
+                    const int b = r / a.hw, q = r - b * a.hw;
+                    a.policy[(size_t)b * a.policy_len + q] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid] + a.pb1[0];
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int ot = 0; ot < OT; ot++)
@@ -1291,6 +1336,13 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
 // ---- 1x1 convolution in split arithmetic (head convolutions behind the split tower) ----
 static int conv1x1_split_ot(int cout_p) { return cout_p % 256 == 0 ? 4 : cout_p % 128 == 0 ? 2 : cout_p % 64 == 0 ? 1 : 0; }
 
+// the one-filter second convolution of a conv policy head as the first one's epilogue: a single pass over the output
+// channels (every wave holds all of them for its rows), rows gathered as they are (no source remapping)
+bool conv1x1_policy_epilogue_supported(int cin_p, int cout_p, int cout, int policy_channels) {
+    const int ot = conv1x1_split_ot(cout_p);
+    return policy_channels == 1 && cin_p % 32 == 0 && cin_p >= 32 && cin_p <= 512 && ot != 0 && cout_p == 64 * ot && cout == cout_p;
+}
+
 bool conv1x1_split_supported(int cin_p, int cout_p) {
     return cin_p % 32 == 0 && cin_p >= 32 && cin_p <= 512 && conv1x1_split_ot(cout_p) != 0;
 }
@@ -1352,6 +1404,19 @@ void launch_conv1x1_split(const Conv1x1SplitArgs &t, hipStream_t stream) {
         }
         kernel<<<grid, 256, lds_bytes, stream>>>(d);
     };
+    if (t.policy) {  // (conv1x1_policy_epilogue_supported)
+        d.pw1 = t.pw1; d.pb1 = t.pb1; d.policy = t.policy; d.policy_len = t.policy_len; d.hw = t.hw;
+        if (t.split) {
+            if (ot == 4) go(kz_conv1x1_split<4, true, true>);
+            else if (ot == 2) go(kz_conv1x1_split<2, true, true>);
+            else go(kz_conv1x1_split<1, true, true>);
+        } else {
+            if (ot == 4) go(kz_conv1x1_split<4, false, true>);
+            else if (ot == 2) go(kz_conv1x1_split<2, false, true>);
+            else go(kz_conv1x1_split<1, false, true>);
+        }
+        return;
+    }
     if (t.split) {
         if (ot == 4) go(kz_conv1x1_split<4, true>);
         else if (ot == 2) go(kz_conv1x1_split<2, true>);
