@@ -463,21 +463,6 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
                             }
 }
 
-// The tile-row map ([384]: board << 20 | pixel << 10 | image row, or -1 for a padding row) and the list of halo rows of a
-// workgroup's image; the engine uploads them next to the weights and passes them in BoardConvArgs.
-void board_conv_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo) {
-    const Geometry g = geometry(h, w);
-    rowmap.assign(ROWS, -1);
-    for (int r = 0; r < ROWS; r++) {
-        const int mt = r / 16, b = mt / g.tpb, q = (mt - b * g.tpb) * 16 + r % 16;
-        if (b < g.bpw && q < h * w) rowmap[r] = b << 20 | q << 10 | (b * g.rpb + (q / w + 1) * g.pitch + q % w + 1);
-    }
-    halo.clear();
-    for (int b = 0; b < g.bpw; b++)
-        for (int idx = 0; idx < g.rpb; idx++)
-            if (idx < g.pitch || idx >= (h + 1) * g.pitch || idx % g.pitch == 0) halo.push_back((unsigned short)(b * g.rpb + idx));
-}
-
 void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     BoardConvDev d;
     d.x = static_cast<const h16 *>(t.x);

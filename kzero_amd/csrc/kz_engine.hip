@@ -205,7 +205,7 @@ struct DeviceWeights {
     bool use_board_conv = false;
     int stem_cin_p = 0;  // != 0: the stem goes through the board-tile kernel and wants encoded rows of this many channels
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
-    int *bc_rowmap = nullptr;  // kz_board_conv_f16's tile-row map and halo-row list for this board size
+    int *bc_rowmap = nullptr;  // (experiment build: kz_board_conv2_f16's tile-row map and halo-row list)
     unsigned short *bc_halo = nullptr;
     int bc_n_halo = 0;
     int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32, bool want_split16,
@@ -299,21 +299,21 @@ struct DeviceWeights {
         } else {
             tower.resize(m.tower.size());
             const char *noboard = getenv("KZ_NO_BOARD_CONV");
-            if (use_board_conv && !(noboard && noboard[0] == '1')) {
-                std::vector<int> rowmap;
-                std::vector<unsigned short> halo;
 #ifdef KZ_EXPERIMENTS
+            if (use_board_conv && !(noboard && noboard[0] == '1')) {
                 const char *c2 = getenv("KZ_BOARD_CONV2");
                 // (experiment, opt-in: the second organisation measured 26.2k against 33.5k evals/s on Go-19 40x256)
                 conv2 = c2 && c2[0] == '1' && kz::board_conv2_supported(dtype, m.h, m.w, m.channels, m.channels);
-                if (conv2) kz::board_conv2_tables(m.h, m.w, rowmap, halo);
-                else
-#endif
-                kz::board_conv_tables(m.h, m.w, rowmap, halo);
-                bc_n_halo = (int)halo.size();
-                if (upload(rowmap.data(), rowmap.size() * sizeof(int), (void **)&bc_rowmap)) return 1;
-                if (upload(halo.data(), halo.size() * sizeof(unsigned short), (void **)&bc_halo)) return 1;
+                if (conv2) {  // its tile-row map and halo-row list (the product kernel needs no tables)
+                    std::vector<int> rowmap;
+                    std::vector<unsigned short> halo;
+                    kz::board_conv2_tables(m.h, m.w, rowmap, halo);
+                    bc_n_halo = (int)halo.size();
+                    if (upload(rowmap.data(), rowmap.size() * sizeof(int), (void **)&bc_rowmap)) return 1;
+                    if (upload(halo.data(), halo.size() * sizeof(unsigned short), (void **)&bc_halo)) return 1;
+                }
             }
+#endif
             for (size_t i = 0; i < m.tower.size(); i++) {
                 const bool on = use_board_conv && !(noboard && noboard[0] == '1');
                 // the stem joins the board-tile family with its input planes padded to one 64-channel chunk (the encode

@@ -126,15 +126,16 @@ struct BoardConvArgs {
     const void *res; // optional, [boards*h*w][ldy]
     void *y;
     int ldy, boards, h, w, cin, cout, relu;
-    const int *rowmap;            // board_conv_tables, uploaded by the caller
-    const unsigned short *halo;
-    int n_halo;
+    // (kz_board_conv2.hip, the experiment build's second organisation, only: its tile-row map and halo-row list; the
+    // product kernel computes both from the thread id)
+    const int *rowmap = nullptr;
+    const unsigned short *halo = nullptr;
+    int n_halo = 0;
 };
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout);
 int board_conv_workgroups(int boards, int h, int w, int cout);  // grid size: 64 output channels per workgroup
 size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
-void board_conv_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo);
 void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);
 // second organisation for boards of 193..384 squares (Go 19x19): two boards per workgroup, one workgroup per CU, staging
 // under the MFMAs (kz_board_conv2.hip).  Same BoardConvArgs, with its own weight packing and tables.
