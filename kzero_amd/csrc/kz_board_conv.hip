@@ -1,26 +1,26 @@
 // kz_board_conv.hip — per-layer 3x3 convolution for boards whose whole tower does not fit in LDS (Go 19x19: a
-// 361 x 256 f16 board is 185 KB), f16, input channels a multiple of 32, output channels a multiple of 64.
+// 361 x 256 f16 board is 185 KB), f16, channels a multiple of 64.
 //
-// A workgroup keeps whole boards' pixels in LDS and the 9 taps are 9 shifted views of that image (a tap outside the board
-// reads a zero row), so the activations are fetched ONCE per layer and workgroup instead of once per tap.  One launch per
-// layer (activations round-trip through HBM), shaped for TWO workgroups per CU — one stages or stores while the other
-// multiplies:
+// Same inner loop as the resident tower (kz_tower.hip): a workgroup keeps whole boards' pixels in LDS and the 9 taps
+// are 9 shifted views of that image (a tap outside the board reads a zero row), so the activations are fetched from
+// L2 ONCE per layer and workgroup instead of once per tap; the weights stream from L2 straight into MFMA A-fragment
+// registers in host-packed fragment order.  What differs from the tower: one launch per layer (activations round-trip
+// through HBM: 2-3 x 94.6 MB per layer at Go B=512, the same order of time as the MFMAs), so the kernel is shaped
+// for TWO workgroups per CU — one stages or stores while the other multiplies:
 //
 //   workgroup = 24 tiles of 16 pixel rows (bpw boards, each padded to tpb = ceil(h*w/16) tiles; Go: 23 tiles, bpw = 1)
 //               x 64 output channels; 256 threads = 4 waves; wave = (row quarter: 6 tiles) x (all 64 output channels)
-//   chunk     = 32 input channels = one k-step (24 MFMAs per wave) per tap, 9 k-steps per chunk.  BOTH operands of a
-//               chunk live in LDS: the image chunk WITH a zero halo (board b, pixel (y, x) is image row
-//               b*rpb + (y+1)*(w+1) + x+1, the right halo of a line is the left halo of the next, so a tap is a constant
-//               row offset; rows of 64 B + 16 B pad: conflict-free fragment reads) and the chunk's 36 KB of weights in
-//               fragment order [tap][nt 4][lane 64] x 16 B.  The four waves of a workgroup multiply the same weights:
-//               loading them once per workgroup into LDS instead of once per wave into registers takes three quarters
-//               of the weight bytes off the CU's one L1 / texture path, which every other load and store of the CU
-//               queues behind.  The k-loop of a chunk issues no global load of its own operands
-//               and meets no barrier: it only carries the PREFETCH of the next chunk (6 image pieces + 9 weight pieces
-//               of 16 B per thread, two per tap, into 60 registers), written to LDS between two barriers at the chunk's
-//               end; in the last chunk the same registers fetch the residual.
-//   registers = 96 accumulators + 32 weight fragments (this tap's and the next one's) + 24 activation fragments + 60
-//               staged pieces: two waves per SIMD.
+//   LDS       = one 64-channel chunk of the image, WITH a zero halo: board b, pixel (y, x) is image row
+//               b*rpb + (y+1)*(w+1) + x+1 (the right halo of a line is the left halo of the next), so a tap is a constant
+//               row offset and needs no validity test in the k-loop — per tap and tile ONE v_add, against a
+//               compare/select chain per tile that made the loop issue-bound.  Two planes (channels [0,32) and
+//               [32,64)) of rows x 80 B, a multiple of 256 B apart: the two lane groups that share a ds_read_b128
+//               bank group read the two planes at the same row offset and rows advance by 5 sixteen-byte slots ->
+//               conflict-free fragment reads, except one 2-way pair in tiles that cross a line end.  Go: 66 KB.
+//   registers = 96 accumulators + 24 fragment + 48 weight ring: < 256, two waves per SIMD.  The ring's 48 registers are
+//               also the staging buffer: during the last PF k-steps of a chunk a ring stage that has fed its MFMAs is not
+//               refilled with weights but with this thread's 12 pieces of the NEXT chunk's image (or, in the last chunk,
+//               of the residual), so those loads fly under the MFMAs instead of behind a barrier.
 //   grid      = 1-D, XCD-aware: the cout/64 workgroups of one board group run on ONE XCD back to back, so the
 //               image is read from HBM once and from that XCD's L2 by the others.
 #include <cstdio>
@@ -41,19 +41,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int MT = 24;                 // 16-row tiles per workgroup
-constexpr int NTW = 4;                 // 16-channel output tiles per wave: all 64 channels of the workgroup
-constexpr int MTW = MT / NTW;          // tiles per wave: a row quarter
+#ifndef KZ_BC_NTW
+#define KZ_BC_NTW 4
+#endif
+constexpr int NTW = KZ_BC_NTW;         // 16-channel output tiles per wave: 4 = all 64 channels of the workgroup x a
+                                       // row quarter (6 tiles); 2 = 32 channels x a row half (12 tiles)
+constexpr int MTW = MT / NTW;          // tiles per wave (there are NTW row groups)
 constexpr int ROWS = MT * 16;          // 384
 constexpr int OCW = 64;                // output channels per workgroup
-constexpr int CH = 32;                 // input channels per staged chunk
-constexpr int PRS = CH * 2 + 16;       // image row stride: 32 channels + 16 B pad = 80 B
+constexpr int CH = 64;                 // input channels per staged chunk
+constexpr int PRS = 32 * 2 + 16;       // plane row stride: 32 channels + 16 B pad = 80 B
 constexpr int LDS_MAX = 80 * 1024;     // two workgroups per CU
 constexpr int ORS = OCW * 2 + 16;      // row stride of the epilogue's output tile
-constexpr int KPC = 9;                 // k-steps per chunk: one per tap
-constexpr int WSTEP = NTW * 64 * 16;   // weight bytes of a k-step: 4 KB
-constexpr int WCHUNK = KPC * WSTEP;    // ... of a chunk: 36 KB
-constexpr int NIMG = 6, NWGT = KPC, NSTG = NIMG + NWGT;  // 16-byte pieces a thread stages per chunk: image, weights
-static_assert(ROWS * (CH * 2 / 16) == NIMG * 256 && WCHUNK == NWGT * 256 * 16, "a chunk's pieces divide over 256 threads");
+constexpr int KPC = 18;                // k-steps (32 channels of one tap) per chunk: 9 taps x 2
+#ifndef KZ_BC_PF
+#define KZ_BC_PF 3
+#endif
+constexpr int PF = KZ_BC_PF;           // weight ring depth in k-steps (a k-step is 24 MFMAs = 384 cycles per wave)
+static_assert(KPC % PF == 0, "ring stage of a k-step must not depend on the chunk");
 
 // fragment read from an integer LDS byte address (the dynamic LDS block starts at 0; going through the `lds` symbol
 // costs a v_add per read)
@@ -88,20 +93,18 @@ constexpr int SG_MFMA = 0x8, SG_DS_READ = 0x100;
 #endif
 
 struct BoardConvDev {
-    const h16 *x;       // [boards*hw][ldx]
-    const uint4 *w;     // fragment-packed: [n_quarter][chunk][tap][nt 4][lane 64] x 16 B
+    const h16 *x;       // [boards*hw][ld]
+    const uint4 *w;     // fragment-packed: [n_quarter][k-step][nt 4][lane 64] x 16 B
     const float *bias, *post_scale, *post_shift;  // [cout]
     const h16 *res;     // optional residual [boards*hw][ld]
     h16 *y;             // [boards*hw][ld]
     int bytes;          // size of y (and of the residual): boards * hw * ld * 2 (< 2^31)
-    int bytes_x, ldx;   // the input's (the stem's input tensor is narrower than its output)
-    int bytes_w;        // size of the packed weights of this layer
+    int bytes_x, ldx;   // the input's: ldx == ld unless the convolution has a single chunk (the stem: 64 input channels)
     int ld, boards, h, w_, hw, tpb, bpw, cin, relu, groups, nq;
     unsigned inv_tpb, inv_w, inv_nhb;  // ceil(65536 / tpb), / w, / (halo rows per board): exact quotients for the small
                                        // values they meet
-    int pitch, rpb;     // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board
-    int w_off;          // LDS offset of the chunk's weights, behind the image
-    int rm_off;         // LDS offset of the 384 image-row indices (u16), behind the weights / the epilogue's output tile
+    int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
+    int rm_off;             // LDS offset of the 384 image-row indices (u16), behind the image / the epilogue's output tile
     unsigned long long *stamps;  // diagnostic build only
 };
 
@@ -109,9 +112,12 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave;  // wave = row quarter (6 tiles) x all 64 output channels
+    // wave = (output-channel group wo) x (row group wr): an activation fragment feeds NTW MFMAs, a weight fragment MTW
+    const int wo = wave % (4 / NTW), wr = wave / (4 / NTW);
     const int lane = tid & 63;
     const int fr = lane & 15, kq = lane >> 4;
+    // XCD-aware order: consecutive workgroup ids go to consecutive XCDs, so id = (slot, xcd); the nq channel quarters of
+    // a board group take consecutive slots of one XCD
     KZ_STAMP(0);
 #ifdef KZ_BC_STAMPS
     if (lane == 0) {  // where this workgroup ran: HW_ID, XCC_ID, LDS_ALLOC
@@ -128,21 +134,20 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);  // HW_REG_LDS_ALLOC.LDS_BASE
         if (lds_base == 0) __builtin_amdgcn_s_setprio(3);
     }
-    // XCD-aware order: consecutive workgroup ids go to consecutive XCDs, so id = (slot, xcd); the nq channel quarters of
-    // a board group take consecutive slots of one XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nquarter = slot % a.nq, group = (slot / a.nq) * 8 + xcd;
     if (group >= a.groups) return;
     const int board0 = group * a.bpw;
     const int chunks = a.cin / CH;
+    const int total_ksteps = chunks * KPC;
 
-    // ---- set-up, ordered by latency: (1) the first chunk's pieces are requested FIRST — everything about a tile row
-    // (board, pixel, image row) is arithmetic on the thread id, no table is read — (2) then, under those loads, the halo
-    // clear, the fragment rows and the accumulators.
-    // Output slot i of a thread = tile row (tid >> 3) + 32 i, 16-byte piece tid & 7 of its 64 output channels: the same 12
-    // slots serve the residual and the output stores.  An image chunk is half as wide (4 pieces per row): a thread stages
-    // the 6 of its 12 rows with i % 2 == piece / 4, piece % 4 of each.
-    const int piece = tid & 7, piece4 = piece & 3, ihalf = piece >> 2;
+    // ---- set-up, ordered by latency: (1) this thread's 12 image pieces of chunk 0 are requested FIRST — everything about
+    // a tile row (board, pixel, image row) is arithmetic on the thread id, no table is read — (2) then the weight ring,
+    // (3) then, under those loads, the halo clear, the fragment rows and the accumulators.
+    // Slot i of a thread = tile row (tid >> 3) + 32 i, 16-byte piece tid & 7 of its 64 channels; the same 12 slots serve
+    // the staging of every chunk, the residual and the output stores.
+    const int piece = tid & 7;
+    const int ls_piece = (piece >> 2) * a.plane + (piece & 3) * 16;
     // tile row r -> board b (of this workgroup), pixel q, image row; false for a padding row or a board beyond the batch
     // (every factor is below 2^24: v_mul_u32_u24 / v_mad_u32_u24 run at full rate, a 32-bit v_mul_lo_u32 at a quarter)
     auto locate = [&](int r, int &b, int &q, int &irow) __attribute__((always_inline)) {
@@ -154,82 +159,68 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                (q - (int)__umul24((unsigned)yy, (unsigned)a.w_)) + 1;
         return b < a.bpw && q < a.hw && board0 + b < a.boards;
     };
+    KZ_STAMP(25);
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.x), 0, a.bytes_x, 0x00020000);
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.w), 0, a.bytes_w, 0x00020000);
-    const auto nrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.w), 0, 0, 0x00020000);  // no records: loads return zeros
-    const int wvoff = tid * 16;                       // this thread's piece of every 4 KB of weights
-    const int wbase = nquarter * chunks * WCHUNK;     // this quarter's weights: + chunk * WCHUNK + j * 4096
-    u32x4 stg[NSTG];  // the pieces in flight: [0, NIMG) image, [NIMG, NSTG) weights; in the last chunk [0, 12) the residual
-    bool g0ok[NIMG];  // (prologue only)
-    int lx0[NIMG];
-#pragma unroll
-    for (int k = 0; k < NIMG; k++) {
-        int b, q, irow;
-        g0ok[k] = locate((tid >> 3) + (2 * k + ihalf) * 32, b, q, irow);
-        const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
-        lx0[k] = irow * PRS + piece4 * 16;
-        stg[k] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, g0ok[k] ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece4 * 8) * 2) : -1, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < NWGT; j++) stg[NIMG + j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wbase + j * 4096, 0);
-    // Byte offsets of a thread's slots are NOT kept in registers (the k-loop needs every one of its 256): they are a dozen
-    // full-rate VALU instructions each, recomputed where they are used — under the MFMAs of the k-loop for the prefetch.
-    // out_off(i) = output slot i in the [pixels][ld] output tensor (and the residual), image_off(k) = image slot k in the
-    // [pixels][ldx] input tensor; -1 for a padding row (32-bit offsets on a uniform base)
-    // (`t` = the thread id behind an optimisation barrier of the chunk loop: the offsets are loop-invariant, and the compiler
-    // would otherwise hoist all eighteen out of the loop and spill them)
-    auto out_off = [&](int t, int i) __attribute__((always_inline)) {
-        int b, q, irow;
-        const bool ok = locate((t >> 3) + i * 32, b, q, irow);
-        const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;
-        return ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
-    };
-    auto image_off = [&](int t, int k) __attribute__((always_inline)) {
-        int b, q, irow;
-        const bool ok = locate((t >> 3) + (2 * k + ihalf) * 32, b, q, irow);
-        const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;
-        return ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece4 * 8) * 2) : -1;
-    };
-    // (where an image piece goes in LDS — image row * PRS — or -1 for a padding row: 384 entries behind the weights, read
-    // back at the chunk boundaries)
+    // po[i] = byte offset of slot i in the [pixels][ld] OUTPUT tensor (the residual and, for a convolution of more than
+    // one chunk, the input have the same ld), or -1 for a padding row: 32-bit offsets on a uniform base keep the twelve
+    // addresses in twelve registers.  The image rows (where a piece goes in LDS) are not kept across the k-loops — 12
+    // registers the loop needs: they sit in LDS behind the image, 768 bytes, and are read back at every chunk boundary.
+    int po[12];
+    u32x4 v0[12];  // chunk 0
+    int irow0[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         int b, q, irow;
         const bool ok = locate((tid >> 3) + i * 32, b, q, irow);
-        if (piece == 0) *reinterpret_cast<int *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 4) = ok ? irow * PRS : -1;
+        irow0[i] = irow;
+        const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
+        po[i] = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
+        v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
+        if (piece == 0) *reinterpret_cast<unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2) = (unsigned short)irow;
     }
 
+    KZ_STAMP(26);
+    // weight ring: k-step g of this (layer, quarter): 4 KB = [nt 4][lane] x 16 B, the same for the four waves
+    const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + lane;
+    uint4 wreg[PF][NTW];
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+        const int g = s < total_ksteps ? s : total_ksteps - 1;
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) wreg[s][nt] = wp[(size_t)g * 256 + (wo * NTW + nt) * 64];
+    }
+    int g = 0;  // k-step counter; at a chunk boundary the ring holds k-steps g .. g + PF - 1
+
     KZ_STAMP(21);
-    // zero the halo rows once (5 sixteen-byte pieces per row); they are never written again, and the pixel rows are
-    // overwritten by every chunk.  Halo row k of a board: the line above the board (k < pitch), the left neighbour of
-    // every line (the right neighbour of the line before), the line below plus one.
+    // zero the halo rows once (10 sixteen-byte pieces per row: 5 per plane); they are never written again, and the
+    // pixel rows are overwritten by every chunk.  Halo row k of a board: the line above the board (k < pitch), the left
+    // neighbour of every line (the right neighbour of the line before), the line below plus one.
     {
         const int nhb = 2 * a.pitch + a.h + 1;  // halo rows per board
-        for (int id = tid; id < a.bpw * nhb * 5; id += 256) {
-            const int k = (int)(((unsigned)id * 13108u) >> 16), pc = id - k * 5;  // id / 5 for id < 8192
+        for (int id = tid; id < a.bpw * nhb * 10; id += 256) {
+            const int k = (int)(((unsigned)id * 6554u) >> 16), pc = id - k * 10;  // id / 10 for id < 16384
             const int b = (int)(((unsigned)k * a.inv_nhb) >> 16), kk = k - b * nhb;
             const int row = b * a.rpb + (kk < a.pitch ? kk : kk < a.pitch + a.h ? (kk - a.pitch + 1) * a.pitch : (a.h + 1) * a.pitch + (kk - a.pitch - a.h));
-            *reinterpret_cast<uint4 *>(lds + pc * 16 + row * PRS) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(lds + (pc >= 5 ? a.plane + (pc - 5) * 16 : pc * 16) + row * PRS) = make_uint4(0, 0, 0, 0);
         }
     }
 
     KZ_STAMP(22);
-    // Centre-tap LDS address of this lane's fragment row for each of the wave's 6 tiles (16-byte piece kq of the row's
-    // 32 channels); a lane without a pixel (padding row, missing board) reads pixel (0, 0) of board 0 — its outputs are
-    // never stored.
-    // T[i] walks the nine taps of a chunk by constant steps and returns to the first one at the chunk's end.
-    int T[MTW];
+    // Centre-tap LDS address of this lane's fragment row for each of the wave's 6 tiles (plane kq & 1, 16-byte piece
+    // kq >> 1 of the k-step); a lane without a pixel (padding row, missing board) reads pixel (0, 0) of board 0 — its
+    // outputs are never stored.
+    int T0[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
         int b, q, irow;
         const bool valid = locate((wr * MTW + i) * 16 + fr, b, q, irow);
-        T[i] = (valid ? irow : a.pitch + 1) * PRS + kq * 16 - a.pitch * PRS - PRS;  // tap 0: one line up, one pixel left
+        T0[i] = (valid ? irow : a.pitch + 1) * PRS + (kq & 1) * a.plane + (kq >> 1) * 16;
     }
 
     KZ_STAMP(24);
     f32x4 acc[NTW][MTW];
     {
-        const int oc = nquarter * OCW + kq * 4;
+        const int oc = nquarter * OCW + wo * NTW * 16 + kq * 4;
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + oc + nt * 16);
@@ -240,156 +231,150 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 
     // LDS address of this lane's fragment row per tile for one tap: a constant row offset in the halo image.
     // (pitch_prs is a.pitch * PRS behind an optimisation barrier inside the chunk loop: the rows are the same for every
-    // chunk, and the compiler would otherwise hoist all 9 x 6 of them out of the loop and spill them)
-    // (from tap - 1 to tap: one pixel right, or — at the start of a tap line — one line down and two pixels left)
-    auto tap_rows = [&](int tap, int lo, int hi, int pitch_prs) {
-        const int step = tap % 3 ? PRS : pitch_prs - 2 * PRS;
+    // chunk, and the compiler would otherwise hoist all 9 x 12 of them out of the loop and spill them)
+    auto tap_rows = [&](int tap, int lo, int hi, int pitch_prs, int (&T)[MTW]) {
+        const int off = (tap / 3 - 1) * pitch_prs + (tap % 3 - 1) * PRS;
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
             if (i < lo || i >= hi) continue;
-            T[i] += step;
+            T[i] = T0[i] + off;
         }
-    };
-    // where this thread's staged pieces go: the image slots (never into the halo) and its piece of every 4 KB of weights
-    auto weights_to_lds = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NWGT; j++) *reinterpret_cast<u32x4 *>(lds + a.w_off + j * 4096 + wvoff) = stg[NIMG + j];
     };
 
     KZ_STAMP(1);
+    // (wave-uniform) this wave's sixth tile lies beyond the workgroup's last pixel tile
 #ifdef KZ_BC_NO_SKIP  // (diagnostic builds: the A/B of the padding-tile skip)
     const bool skip_last_tile = false;
 #else
-    // (wave-uniform) this wave's sixth tile lies beyond the workgroup's last pixel tile
     const bool skip_last_tile = (wr * MTW + MTW - 1) >= a.bpw * a.tpb && (wr * MTW + MTW - 2) < a.bpw * a.tpb;
 #endif
     const bool with_res = a.res != nullptr;
     const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res ? a.bytes : 0, 0x00020000);
-    // ---- chunk 0 into LDS (the halo clear of other threads touches other rows: no barrier in front of these writes) ----
+    // ---- chunk 0 into the image: channels [0, 64) of this workgroup's boards, 8 pieces of 16 B per pixel row (never
+    // into the halo: the halo clear of other threads needs no barrier in front of these writes) ----
     KZ_STAMP(2);
 #pragma unroll
-    for (int k = 0; k < NIMG; k++)
-        if (g0ok[k]) *reinterpret_cast<u32x4 *>(lds + lx0[k]) = stg[k];  // never into the halo
-    weights_to_lds();
+    for (int i = 0; i < 12; i++)
+        if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + irow0[i] * PRS + ls_piece) = v0[i];
     KZ_STAMP(3);
-    const int wa_lds = a.w_off + lane * 16;  // fragment nt of tap t: + t * 4096 + nt * 1024
     for (int chunk = 0; chunk < chunks; chunk++) {
         __syncthreads();  // the chunk is staged
-        KZ_STAMP(4 + (chunk & 3) * 4);
-        // What the k-loop prefetches, two pieces per tap (no branch in the loop: descriptors, offsets and voffsets are
-        // selected here): the next chunk's image pieces [0, NIMG) and weight pieces [NIMG, NSTG); in the last chunk the
-        // residual's 12 pieces (without a residual its descriptor has no records: the loads return zeros without traffic)
+        KZ_STAMP(4 + chunk * 4);
+        // what the ring's dying stages fetch during the last PF k-steps of this chunk: the next chunk's image pieces, or
+        // (last chunk) the residual's, or nothing
+        // (no branch in the k-loop: one descriptor and one scalar offset, selected here; without a residual the last
+        // chunk's descriptor has no records, so its tail loads return zeros without touching memory)
         const bool last_chunk = chunk + 1 == chunks;
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        const auto irsrc = last_chunk ? rrsrc : xrsrc;               // pieces [0, NIMG)
-        const auto qrsrc = last_chunk ? rrsrc : wrsrc;               // pieces [NIMG, 12)
-        const auto zrsrc = last_chunk ? nrsrc : wrsrc;               // pieces [12, NSTG): weights, or nothing
-        const int isoff = last_chunk ? nquarter * OCW * 2 : (chunk + 1) * CH * 2;
-        const int wsoff = wbase + (chunk + 1) * WCHUNK;              // (a weight piece beyond the last chunk is out of range)
+        const auto trsrc = last_chunk ? rrsrc : xrsrc;
+        const int tsoff = last_chunk ? nquarter * OCW * 2 : (chunk + 1) * CH * 2;
 
-        // Two half-steps per k-step: the MFMAs of tiles 0..2 run while the fragments of tiles 3..5 and the NEXT tap's
-        // weight fragments are read, the MFMAs of tiles 3..5 while the next tap's fragments of tiles 0..2 are read; the
-        // other wave of the SIMD (the CU's second workgroup) fills whatever latency is left.
+        // Two half-steps per k-step: the MFMAs of tiles 0..2 run while the fragments of tiles 3..5 are read, and
+        // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (the CU's second
+        // workgroup) fills whatever latency is left.
         // A wave whose sixth tile is pure padding (Go's 361 pixels are 22.6 tiles, so tile 23 — wave 3's sixth — holds
         // none) does not issue that tile's fragment read and 4 MFMAs: 4 % of the launch's MFMA work, and of its power.
         constexpr int HT = MTW / 2;
+        int T[MTW];
         h16x8 bfA[HT], bfB[HT] = {};
-        h16x8 wa[NTW];  // the current tap's weight fragments; fragment nt is re-read for the next tap behind its last MFMAs
-        const int pitch_prs = a.pitch * PRS;
-#pragma unroll
-        for (int nt = 0; nt < NTW; nt++) wa[nt] = lds_frag(wa_lds + nt * 1024);
+        int pitch_prs = a.pitch * PRS;
+        asm volatile("" : "+s"(pitch_prs));
+        tap_rows(0, 0, MTW, pitch_prs, T);
 #pragma unroll
         for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i]);
 #pragma unroll
-        for (int tap = 0; tap < KPC; tap++) {
-            const int next_tap = tap < KPC - 1 ? tap + 1 : KPC - 1;
-            // ---- half 1: tiles 0..2, weight fragment outermost ----
+        for (int tap = 0; tap < 9; tap++) {
+            const int next_tap = tap < 8 ? tap + 1 : 8;
 #pragma unroll
-            for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i]);
-            if (!skip_last_tile) bfB[HT - 1] = lds_frag(T[MTW - 1]);
+            for (int ks = 0; ks < 2; ks++) {
+                const int stage = (tap * 2 + ks) % PF;
+                // ---- half 1 ----
 #pragma unroll
-            for (int nt = 0; nt < NTW; nt++)
+                for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i] + ks * 32);
+                if (!skip_last_tile) bfB[HT - 1] = lds_frag(T[MTW - 1] + ks * 32);
+                h16x8 af[NTW];  // aliases of the ring stage (no copy: the stage is reloaded after this k-step's MFMAs)
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
 #pragma unroll
                 for (int i = 0; i < HT; i++)
-                    acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[nt], bfA[i], acc[nt][i], 0, 0, 0);
-            // the reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
-            __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT - 1, 0);
-            __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- half 2: tile 5 (if it holds pixels), then tiles 3 and 4 with the weight fragment outermost; fragment nt is
-            // dead behind its two MFMAs and is read again for the next tap: 6 + nt MFMAs (100-150 cycles) ahead of its use.
-            // T is updated in place for the next tap: rows 0..2 are dead after the half-2 read of the previous tap, rows 3..5
-            // after the half-1 read above
-            if (tap < KPC - 1) {
-                tap_rows(next_tap, 0, HT, pitch_prs);
 #pragma unroll
-                for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i]);
-                tap_rows(next_tap, HT, MTW, pitch_prs);
-            }
-            if (!skip_last_tile) {
+                    for (int nt = 0; nt < NTW; nt++)
+                        acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfA[i], acc[nt][i], 0, 0, 0);
+                // the reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
+                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT - 1, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- half 2 ----
+                // T is updated in place for the next tap: rows 0..2 are dead after the last half-2 read of this tap,
+                // rows 3..5 after the half-1 read above
+                if (ks == 1) tap_rows(next_tap, 0, HT, pitch_prs, T);
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++)
-                    acc[nt][MTW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[nt], bfB[HT - 1], acc[nt][MTW - 1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++) {
+                for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i] + (ks < 1 ? (ks + 1) * 32 : 0));
+                if (ks == 1) tap_rows(next_tap, HT, MTW, pitch_prs, T);
 #pragma unroll
                 for (int i = 0; i < HT - 1; i++)
-                    acc[nt][HT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[nt], bfB[i], acc[nt][HT + i], 0, 0, 0);
-                if (tap < KPC - 1) wa[nt] = lds_frag(wa_lds + (tap + 1) * WSTEP + nt * 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- the prefetch: pieces 2 tap and 2 tap + 1 ----
 #pragma unroll
-            for (int p = 2 * tap; p < 2 * tap + 2 && p < NSTG; p++) {
-                if (p < NIMG) {
-                    stg[p] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, last_chunk ? out_off(tv, p) : image_off(tv, p), isoff, 0);
-                } else if (p < 12) {
-                    stg[p] = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, last_chunk ? out_off(tv, p) : wvoff, last_chunk ? isoff : wsoff + (p - NIMG) * 4096, 0);
-                } else {
-                    stg[p] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, wvoff, wsoff + (p - NIMG) * 4096, 0);
+                    for (int nt = 0; nt < NTW; nt++)
+                        acc[nt][HT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[i], acc[nt][HT + i], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, (HT - 1) * NTW, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!skip_last_tile) {
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++)
+                        acc[nt][MTW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[HT - 1], acc[nt][MTW - 1], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                // this stage's fragments have been issued to the MFMAs: refill it
+                if (tap * 2 + ks < KPC - PF) {  // (compile time) with the weights of k-step g + PF
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)(g + PF) * 256 + (wo * NTW + nt) * 64];
+                } else {  // last PF k-steps: pieces 4 jj .. 4 jj + 3 of the next image chunk / the residual
+                    const int jj = tap * 2 + ks - (KPC - PF);
+                    static_assert(NTW == 4 && PF == 3, "12 pieces = PF stages x NTW registers");
+#pragma unroll
+                    for (int nt = 0; nt < NTW; nt++)
+                        wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po[jj * 4 + nt], tsoff, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                g++;
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        KZ_STAMP(5 + (chunk & 3) * 4);
-#pragma unroll
-        for (int i = 0; i < MTW; i++) T[i] -= 2 * pitch_prs + 2 * PRS;  // back to tap 0
+        KZ_STAMP(5 + chunk * 4);
         if (!last_chunk) {
-            // ---- the next chunk's pieces sit in registers: into LDS once every wave is done with this chunk's fragments ----
-            int erow[NIMG];
+            // ---- the next chunk's 12 pieces sit in the ring registers (piece 4 j + nt in stage j): into the image once
+            // every wave is done with this chunk's fragments; then the ring takes the next chunk's first PF k-steps ----
+            int erow[12];
 #pragma unroll
-            for (int k = 0; k < NIMG; k++)
-                erow[k] = *reinterpret_cast<const int *>(lds + a.rm_off + ((tid >> 3) + (2 * k + ihalf) * 32) * 4);
+            for (int i = 0; i < 12; i++) erow[i] = *reinterpret_cast<const unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2);
             __syncthreads();
-            KZ_STAMP(6 + (chunk & 3) * 4);
+            KZ_STAMP(6 + chunk * 4);
 #pragma unroll
-            for (int k = 0; k < NIMG; k++)
-                if (erow[k] >= 0) *reinterpret_cast<u32x4 *>(lds + erow[k] + piece4 * 16) = stg[k];  // never into the halo
-            weights_to_lds();
-            KZ_STAMP(7 + (chunk & 3) * 4);
+            for (int i = 0; i < 12; i++)
+                if (po[i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * PRS + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
+#pragma unroll
+            for (int st = 0; st < PF; st++)
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) wreg[st][nt] = wp[(size_t)(g + st) * 256 + (wo * NTW + nt) * 64];
+            KZ_STAMP(7 + chunk * 4);
         }
     }
 
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
-    // The result is staged through LDS (image and weights are dead now) so that HBM sees whole 128-byte lines (this
-    // workgroup's 64 output channels of a pixel) instead of 8-byte pieces: O[row][64 oc] f16, row stride 144 B.  The
-    // residual arrived in the staging registers as the same coalesced 16-byte pieces during the last chunk: it goes into O
-    // first, and each lane then replaces the 8 bytes it owns (its 4 channels of a pixel row) by relu(acc) + residual, added
-    // in f32.
+    // The result is staged through LDS (the image is dead now) so that HBM sees whole 128-byte lines (this workgroup's
+    // 64 output channels of a pixel) instead of 8-byte pieces: O[row][64 oc] f16, row stride 144 B.  The residual arrived
+    // in the ring registers as the same coalesced 16-byte pieces during the last three k-steps: it goes into O first, and
+    // each lane then replaces the 8 bytes it owns (its 4 channels of a pixel row) by relu(acc) + residual, added in f32.
     __syncthreads();  // every wave is done with the last chunk's fragments
     KZ_STAMP(18);
     const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
     if (with_res) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) *reinterpret_cast<u32x4 *>(lds + out_lds + i * 32 * ORS) = stg[i];
+        for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
         __syncthreads();
     }
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
-        const int ocl = nt * 16 + kq * 4;  // within this workgroup's 64 channels
+        const int ocl = (wo * NTW + nt) * 16 + kq * 4;  // within this workgroup's 64 channels
         f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.post_scale) {
             ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nquarter * OCW + ocl);
@@ -417,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 12; i++)  // a padding row's store is out of range and dropped
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, out_off(tid, i),
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
                                                nquarter * OCW * 2, KZ_BC_STORE_AUX);
     KZ_STAMP(20);
 }
@@ -425,27 +410,24 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 }  // namespace
 
 namespace {
-// halo image geometry: boards per workgroup limited by the 24 tiles and by the LDS left beside a chunk's weights (two
-// workgroups per CU)
+// halo image geometry: boards per workgroup limited by the 24 tiles and by 40 KB per plane (two workgroups per CU)
 struct Geometry {
     int tpb, bpw, pitch, rpb, plane, rm_off, lds_bytes;
 };
-constexpr int RM_BYTES = ROWS * 4;
+constexpr int RM_BYTES = ROWS * 2;
 Geometry geometry(int h, int w) {
     Geometry g{};
     g.tpb = (h * w + 15) / 16;
     g.pitch = w + 1;
     g.rpb = (h + 2) * g.pitch + 1;
-    const int by_tiles = g.tpb <= MT ? MT / g.tpb : 0, by_lds = ((LDS_MAX - RM_BYTES - WCHUNK) / PRS) / g.rpb;
+    const int by_tiles = g.tpb <= MT ? MT / g.tpb : 0, by_lds = ((LDS_MAX - RM_BYTES) / 2 / PRS) / g.rpb;
     g.bpw = by_tiles < by_lds ? by_tiles : by_lds;
-    g.plane = (g.bpw * g.rpb * PRS + 255) / 256 * 256;  // the image; the chunk's weights follow
-    g.rm_off = g.plane + WCHUNK > ROWS * ORS ? g.plane + WCHUNK : ROWS * ORS;  // the epilogue reuses both for the output tile
+    g.plane = (g.bpw * g.rpb * PRS + 255) / 256 * 256;
+    g.rm_off = 2 * g.plane > ROWS * ORS ? 2 * g.plane : ROWS * ORS;  // the epilogue reuses the image for the output tile
     g.lds_bytes = g.rm_off + RM_BYTES;
     return g;
 }
 }  // namespace
-
-int board_conv_cin_granule() { return CH; }
 
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout) {
     return dtype == 1 && cin % CH == 0 && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 &&
@@ -459,25 +441,26 @@ int board_conv_workgroups(int boards, int h, int w, int cout) {
 
 size_t board_conv_weight_elems(int cin, int cout) { return (size_t)9 * cin * cout; }
 
-// OIHW f32 (BN folded) -> [n_quarter][chunk][tap][nt 4][lane 64][8] f16: element j of lane (fr, kq) is
-// W[oc = 64*n_quarter + 16*nt + fr][channel = 32*chunk + 8*kq + j][tap]
+// OIHW f32 (BN folded) -> [n_quarter][chunk][tap][ks 2][nt 4][lane 64][8] f16: element j of lane (fr, kq) is
+// W[oc = 64*n_quarter + 16*nt + fr][channel = 64*chunk + 32*(kq&1) + 16*ks + 8*(kq>>1) + j][tap]
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst) {
     const int chunks = cin / CH, quarters = cout / OCW;
     size_t o = 0;
     for (int nq = 0; nq < quarters; nq++)
         for (int chunk = 0; chunk < chunks; chunk++)
             for (int tap = 0; tap < 9; tap++)
-                for (int nt = 0; nt < OCW / 16; nt++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int j = 0; j < 8; j++) {
-                            const int kq = lane >> 4;
-                            const int oc = OCW * nq + 16 * nt + (lane & 15);
-                            const int ch = CH * chunk + 8 * kq + j;
-                            const _Float16 hv = (_Float16)oihw[((size_t)oc * cin + ch) * 9 + tap];
-                            uint16_t bits;
-                            __builtin_memcpy(&bits, &hv, 2);
-                            dst[o++] = bits;
-                        }
+                for (int ks = 0; ks < 2; ks++)
+                    for (int nt = 0; nt < OCW / 16; nt++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int j = 0; j < 8; j++) {
+                                const int kq = lane >> 4;
+                                const int oc = OCW * nq + 16 * nt + (lane & 15);
+                                const int ch = CH * chunk + 32 * (kq & 1) + 16 * ks + 8 * (kq >> 1) + j;
+                                const _Float16 hv = (_Float16)oihw[((size_t)oc * cin + ch) * 9 + tap];
+                                uint16_t bits;
+                                __builtin_memcpy(&bits, &hv, 2);
+                                dst[o++] = bits;
+                            }
 }
 
 void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
@@ -491,9 +474,8 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.y = static_cast<h16 *>(t.y);
     d.bytes = (int)((size_t)t.boards * t.h * t.w * t.ldy * 2);
     d.bytes_x = (int)((size_t)t.boards * t.h * t.w * t.ldx * 2);
-    d.bytes_w = (int)((size_t)9 * t.cin * t.cout * 2);
     d.ld = t.ldy;
-    d.ldx = t.ldx;
+    d.ldx = t.ldx;  // (ldx != ldy only for a single-chunk convolution: the stem)
     d.boards = t.boards;
     d.h = t.h;
     d.w_ = t.w;
@@ -503,7 +485,7 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.bpw = geo.bpw;
     d.pitch = geo.pitch;
     d.rpb = geo.rpb;
-    d.w_off = geo.plane;
+    d.plane = geo.plane;
     d.rm_off = geo.rm_off;
     d.cin = t.cin;
     d.relu = t.relu;

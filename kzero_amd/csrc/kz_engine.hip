@@ -120,7 +120,7 @@ struct DeviceWeights {
     }
 
     // 3x3 tower conv for the board-tile kernel (kz_board_conv.hip)
-    // (the stem's few input planes are padded with zero weights to the kernel's channel chunk: cin_pad)
+    // (the stem's few input planes are padded with zero weights to the kernel's 64-channel chunk: cin_pad)
     int upload_board_conv(const Conv &cv, DevConv &d, int cin_pad = 0) {
         d.k = 3;
         d.cout = d.cout_p = cv.cout;
@@ -316,17 +316,14 @@ struct DeviceWeights {
 #endif
             for (size_t i = 0; i < m.tower.size(); i++) {
                 const bool on = use_board_conv && !(noboard && noboard[0] == '1');
-                // the stem joins the board-tile family with its input planes padded to the kernel's channel chunk (the encode
-                // kernel then writes rows of that many channels): an eighth of a tower layer's work instead of an
-                // implicit GEMM
-                const int granule = kz::board_conv_cin_granule();
-                const int stem_pad = (m.tower[0].cin + granule - 1) / granule * granule;
+                // the stem joins the board-tile family with its input planes padded to one 64-channel chunk (the encode
+                // kernel then writes 64-channel rows): a quarter of a tower layer's work instead of an implicit GEMM
                 const bool stem64 = on && i == 0 && !conv2 && m.tower[0].cin <= 64 && m.tower[0].k == 3 &&
-                                    kz::board_conv_supported(dtype, m.h, m.w, stem_pad, m.tower[0].cout);
+                                    kz::board_conv_supported(dtype, m.h, m.w, 64, m.tower[0].cout);
                 const bool board = on && kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
                 if (stem64) {
-                    stem_cin_p = stem_pad;
-                    if (upload_board_conv(m.tower[0], tower[0], stem_pad)) return 1;
+                    stem_cin_p = 64;
+                    if (upload_board_conv(m.tower[0], tower[0], 64)) return 1;
                 } else if (board ? upload_board_conv(m.tower[i], tower[i]) : upload_conv(m.tower[i], tower[i])) {
                     return 1;
                 }

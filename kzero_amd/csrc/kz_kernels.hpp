@@ -133,7 +133,6 @@ struct BoardConvArgs {
     int n_halo = 0;
 };
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout);
-int board_conv_cin_granule();  // cin must be a multiple of this (the kernel's channel chunk)
 int board_conv_workgroups(int boards, int h, int w, int cout);  // grid size: 64 output channels per workgroup
 size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
