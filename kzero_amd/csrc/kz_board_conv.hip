@@ -372,30 +372,49 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
         __syncthreads();
     }
+    // All 24 residual slots are read before the first one is rewritten — one LDS round trip instead of 24 in a row (the
+    // compiler cannot move a slot's read past the previous slot's write by itself) — and the launch's wave-uniform
+    // options pick one of four straight-line bodies instead of branching at every slot.
+    auto finish = [&](auto RES, auto POST) __attribute__((always_inline)) {
+        constexpr bool with_residual = decltype(RES)::value, post = decltype(POST)::value;
+        const float floor_ = a.relu ? 0.0f : -__builtin_inff();
+        h16x4 rres[NTW][MTW];
+        if constexpr (with_residual) {
 #pragma unroll
-    for (int nt = 0; nt < NTW; nt++) {
-        const int ocl = (wo * NTW + nt) * 16 + kq * 4;  // within this workgroup's 64 channels
-        f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.post_scale) {
-            ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nquarter * OCW + ocl);
-            pt = *reinterpret_cast<const f32x4 *>(a.post_shift + nquarter * OCW + ocl);
+            for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+                for (int i = 0; i < MTW; i++)
+                    rres[nt][i] = *reinterpret_cast<const h16x4 *>(lds + ((wr * MTW + i) * 16 + fr) * ORS + ((wo * NTW + nt) * 16 + kq * 4) * 2);
         }
 #pragma unroll
-        for (int i = 0; i < MTW; i++) {
-            unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + ocl * 2;  // owned by exactly this lane
-            f32x4 v = acc[nt][i];
-            if (a.relu) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+        for (int nt = 0; nt < NTW; nt++) {
+            const int ocl = (wo * NTW + nt) * 16 + kq * 4;  // within this workgroup's 64 channels
+            f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (post) {
+                ps = *reinterpret_cast<const f32x4 *>(a.post_scale + nquarter * OCW + ocl);
+                pt = *reinterpret_cast<const f32x4 *>(a.post_shift + nquarter * OCW + ocl);
             }
-            if (with_res) {
-                const h16x4 r = *reinterpret_cast<const h16x4 *>(slot);
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] += (float)r[j];  // added in f32, AFTER the ReLU (post_act.py:227-228)
+            for (int i = 0; i < MTW; i++) {
+                unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + ocl * 2;  // owned by exactly this lane
+                f32x4 v = acc[nt][i];
+#pragma unroll
+                for (int j = 0; j < 4; j++) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu] (one instruction: no compare mask, no canonicalising copy)
+                if constexpr (with_residual) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] += (float)rres[nt][i][j];  // added in f32, AFTER the ReLU (post_act.py:227-228)
+                }
+                if constexpr (post) v = v * ps + pt;
+                *reinterpret_cast<h16x4 *>(slot) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
             }
-            if (a.post_scale) v = v * ps + pt;
-            *reinterpret_cast<h16x4 *>(slot) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
         }
+    };
+    if (with_res) {
+        if (a.post_scale) finish(std::true_type{}, std::true_type{});
+        else finish(std::true_type{}, std::false_type{});
+    } else {
+        if (a.post_scale) finish(std::false_type{}, std::true_type{});
+        else finish(std::false_type{}, std::false_type{});
     }
     __syncthreads();
     KZ_STAMP(19);
