@@ -151,12 +151,11 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     // tile row r -> board b (of this workgroup), pixel q, image row; false for a padding row or a board beyond the batch
     // (every factor is below 2^24: v_mul_u32_u24 / v_mad_u32_u24 run at full rate, a 32-bit v_mul_lo_u32 at a quarter)
     auto locate = [&](int r, int &b, int &q, int &irow) __attribute__((always_inline)) {
-        const int mt = r >> 4;
-        b = (int)(__umul24((unsigned)mt, a.inv_tpb) >> 16);           // mt / tpb (exact: mt < 24)
-        q = (mt - (int)__umul24((unsigned)b, (unsigned)a.tpb)) * 16 + (r & 15);
+        b = (int)(__umul24((unsigned)(r >> 4), a.inv_tpb) >> 16);     // tile / tpb (exact: tile < 24)
+        q = r - (int)__umul24((unsigned)b, (unsigned)a.tpb * 16u);
         const int yy = (int)(__umul24((unsigned)q, a.inv_w) >> 16);   // q / w (exact: q < 512, w <= 32)
-        irow = (int)(__umul24((unsigned)b, (unsigned)a.rpb) + __umul24((unsigned)(yy + 1), (unsigned)a.pitch)) +
-               (q - (int)__umul24((unsigned)yy, (unsigned)a.w_)) + 1;
+        // (yy + 1) * pitch + (q - yy * w) + 1 with pitch = w + 1
+        irow = (int)__umul24((unsigned)b, (unsigned)a.rpb) + q + yy + a.pitch + 1;
         return b < a.bpw && q < a.hw && board0 + b < a.boards;
     };
     KZ_STAMP(25);
@@ -370,8 +369,10 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     if (with_res) {
 #pragma unroll
         for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
+        KZ_STAMP(23);
         __syncthreads();
     }
+    KZ_STAMP(27);
     // All 24 residual slots are read before the first one is rewritten — one LDS round trip instead of 24 in a row (the
     // compiler cannot move a slot's read past the previous slot's write by itself) — and the launch's wave-uniform
     // options pick one of four straight-line bodies instead of branching at every slot.
@@ -400,12 +401,24 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                 f32x4 v = acc[nt][i];
 #pragma unroll
                 for (int j = 0; j < 4; j++) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu] (one instruction: no compare mask, no canonicalising copy)
-                if constexpr (with_residual) {
+                if constexpr (with_residual && !post) {
+                    // relu(acc) + residual, added in f32 AFTER the ReLU (post_act.py:227-228) and rounded to f16 once:
+                    // v_fma_mixlo/mixhi_f16 take the f16 residual and the f32 sum in one instruction each
+                    unsigned lo01, lo23;  // (mixlo keeps the destination's high half: whatever it was, mixhi overwrites it)
+                    const unsigned r01 = reinterpret_cast<const unsigned *>(&rres[nt][i])[0], r23 = reinterpret_cast<const unsigned *>(&rres[nt][i])[1];
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo01) : "v"(r01), "v"(v[0]));
+                    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo01) : "v"(r01), "v"(v[1]));
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo23) : "v"(r23), "v"(v[2]));
+                    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo23) : "v"(r23), "v"(v[3]));
+                    *reinterpret_cast<uint2 *>(slot) = make_uint2(lo01, lo23);
+                } else {
+                    if constexpr (with_residual) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] += (float)rres[nt][i][j];  // added in f32, AFTER the ReLU (post_act.py:227-228)
+                        for (int j = 0; j < 4; j++) v[j] += (float)rres[nt][i][j];  // added in f32, AFTER the ReLU
+                    }
+                    if constexpr (post) v = v * ps + pt;
+                    *reinterpret_cast<h16x4 *>(slot) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 }
-                if constexpr (post) v = v * ps + pt;
-                *reinterpret_cast<h16x4 *>(slot) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
             }
         }
     };
@@ -416,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         if (a.post_scale) finish(std::false_type{}, std::true_type{});
         else finish(std::false_type{}, std::false_type{});
     }
+    KZ_STAMP(28);
     __syncthreads();
     KZ_STAMP(19);
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
@@ -528,13 +542,14 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     const size_t stamp_bytes = (size_t)grid * 4 * 32 * sizeof(unsigned long long);
     if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, (size_t)8192 * 4 * 32 * 8);
     d.stamps = stamp_buf;
-    if (launches == 20) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, stream);
+    static const int stamp_launch = getenv("KZ_BC_STAMP_LAUNCH") ? atoi(getenv("KZ_BC_STAMP_LAUNCH")) : 20;  // 20: a layer with a residual
+    if (launches == stamp_launch) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, stream);
 #else
     d.stamps = nullptr;
 #endif
     kz_board_conv_f16<<<grid, 256, geo.lds_bytes, stream>>>(d);
 #ifdef KZ_BC_STAMPS
-    if (launches++ == 20 && getenv("KZ_BC_STAMP_FILE")) {
+    if (launches++ == stamp_launch && getenv("KZ_BC_STAMP_FILE")) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> host(stamp_bytes / 8);
         (void)hipMemcpy(host.data(), stamp_buf, stamp_bytes, hipMemcpyDeviceToHost);

@@ -65,3 +65,18 @@ if (d[:, :, 21] > 0).all():
     for (k0, _), (k1, n1) in zip(seq, seq[1:]):
         seg = d[:, :, k1] - d[:, :, k0]
         print(f"  set-up: {n1:42s} mean {seg.mean():7.0f}  p10 {np.percentile(seg, 10):7.0f}  p90 {np.percentile(seg, 90):7.0f}")
+
+# ---- finer epilogue stamps, when present (layers with a residual only have slot 23) ----
+if (d[:, :, 27] > 0).all() and (d[:, :, 28] > 0).all():
+    res = d[:, 0, 23] > 0
+    for name, sel in (("with residual", res), ("without residual", ~res)):
+        if not sel.any():
+            continue
+        e = d[sel]
+        parts = [("residual pieces -> O tile (waits for the loads)", e[:, :, 23] - e[:, :, 18])] if name == "with residual" else []
+        parts += [("barrier", e[:, :, 27] - (e[:, :, 23] if name == "with residual" else e[:, :, 18])),
+                  ("relu / + residual / -> f16 into O", e[:, :, 28] - e[:, :, 27]), ("barrier", e[:, :, 19] - e[:, :, 28]),
+                  ("stores issued", e[:, :, 20] - e[:, :, 19])]
+        print(f"  epilogue, {name} ({int(sel.sum())} workgroups):")
+        for n, seg in parts:
+            print(f"    {n:52s} mean {seg.mean():7.0f}  p10 {np.percentile(seg, 10):7.0f}  p90 {np.percentile(seg, 90):7.0f}")
