@@ -57,13 +57,14 @@ KERNEL_OF_PATH = {
     "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_f32+heads": "kz_tower_resident_f32",
     "tower_resident_split16": "kz_tower_resident_split", "tower_resident_split16+heads": "kz_tower_resident_split",
     "tower_resident_f16g": "kz_tower_resident_f16g", "board_conv_f16": "kz_board_conv_f16",
+    "board_conv_split16": "kz_board_conv_split16",
     "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32",
 }
 # source file of each dominant kernel: the committed PMC traffic figure is only reported while this file is unchanged
 KERNEL_SOURCE = {
     "kz_tower_resident_f16": "kz_tower.hip", "kz_tower_resident_f32": "kz_tower_f32.hip",
     "kz_tower_resident_split": "kz_tower_split.hip", "kz_tower_resident_f16g": "kz_tower_split.hip",
-    "kz_board_conv_f16": "kz_board_conv.hip", "kz_conv_igemm_f16": "kz_kernels.hip", "kz_conv_igemm_f32": "kz_kernels.hip",
+    "kz_board_conv_f16": "kz_board_conv.hip", "kz_board_conv_split16": "kz_board_conv.hip", "kz_conv_igemm_f16": "kz_kernels.hip", "kz_conv_igemm_f32": "kz_kernels.hip",
 }
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "hbm_traffic.json")
 
@@ -307,8 +308,8 @@ class Workload:
             return info.flops_per_eval * B  # one launch = tower + heads for one batch
         if p.startswith("tower_resident"):
             return tower * B  # one launch = the whole tower for one batch
-        if p == "board_conv_f16":
-            return 2.0 * hw * 9 * C * C * B  # one launch per 3x3 tower convolution (the stem goes through conv_igemm)
+        if p in ("board_conv_f16", "board_conv_split16"):
+            return 2.0 * hw * 9 * C * C * B  # one launch per 3x3 tower convolution (split16: algorithmic FLOP, a third of the executed)
         return info.flops_per_eval * B / max(launches_per_step, 1)  # per-layer launches: average over the step
 
     def roofline(self, k_ms, k_n, steps, evals_per_s_per_gpu):

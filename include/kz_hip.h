@@ -32,9 +32,11 @@ extern "C" {
                           KZ_DTYPE_F32_SPLIT16 (its (hi, lo) pairs are f16 too) */
 #define KZ_DTYPE_F32_SPLIT16 2 /* f32 tensors and the same <=1e-4 parity as KZ_DTYPE_F32, but the tower's products run on
                                   the f16 matrix cores: every activation and weight as a (hi, lo) f16 pair, three MFMAs per
-                                  product, f32 accumulate.  256 tower channels on <= 64 squares or 64 / 128 channels on
-                                  <= 96 squares (kz_engine_create fails otherwise); everything outside the tower is the
-                                  KZ_DTYPE_F32 path */
+                                  product, f32 accumulate.  One launch per batch for 256 tower channels on <= 64 squares
+                                  or 64 / 128 channels on <= 96 squares; one launch per layer for larger boards (Go 19x19:
+                                  channels a multiple of 64, max_batch * squares * channels * 4 bytes < 2 GiB);
+                                  kz_engine_create fails for other shapes (kz_model_supports_dtype tells).  Everything
+                                  outside the tower is the KZ_DTYPE_F32 path */
 
 #define KZ_POLICY_ATAXX_CONV 0 /* AtaxxConvPolicyHead, python/lib/model/post_act.py:91-112 */
 #define KZ_POLICY_CONV 1       /* ConvPolicyHead,      post_act.py:54-88 */
@@ -186,7 +188,8 @@ int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_m
  * (exact f32, other heads), "tower_resident_split16+heads" (KZ_DTYPE_F32_SPLIT16, chess attention network at 256 channels:
  * encode, tower, scalar head and attention policy head in one launch), "tower_resident_split16" (the other shapes of
  * KZ_DTYPE_F32_SPLIT16: tower launch + f32 head kernels).  One launch per layer:
- * "board_conv_f16" (whole boards as LDS tiles, Go-size boards), "conv_igemm_f16", "conv_igemm_f32". */
+ * "board_conv_f16" (whole boards as LDS tiles, Go-size boards), "board_conv_split16" (the same per-layer kernel in split
+ * arithmetic: KZ_DTYPE_F32_SPLIT16 on boards the one-launch split tower cannot hold), "conv_igemm_f16", "conv_igemm_f32". */
 const char *kz_engine_tower_path(const kz_engine *engine);
 /* How the dominant launch of that path covers the chip for a batch of `batch` boards: workgroups per launch and boards
  * per workgroup (per-layer paths: boards_per_workgroup = 0 when a workgroup holds a tile, not whole boards). */

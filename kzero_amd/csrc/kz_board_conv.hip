@@ -88,6 +88,17 @@ constexpr int SG_MFMA = 0x8, SG_DS_READ = 0x100;
         __builtin_amdgcn_sched_barrier(0);                                                     \
         if (lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (slot)] = t_;           \
     } while (0)
+// (-DKZ_BC_REALTIME on top: slots 25 / 26 hold s_memrealtime at a wave's start / end instead of two set-up stamps, and the
+// launcher keeps the stamps of four consecutive launches — tools/go_clock.sh derives the clock the CUs really run at and
+// the idle time between two launches from them)
+#define KZ_RSTAMP(slot)                                                                        \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (slot)] = t_;           \
+    } while (0)
 #else
 #define KZ_STAMP(slot) do { } while (0)
 #endif
@@ -105,10 +116,19 @@ struct BoardConvDev {
                                        // values they meet
     int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
     int rm_off;             // LDS offset of the 384 image-row indices (u16), behind the image / the epilogue's output tile
+    // split arithmetic (kz_board_conv_split16) only: a tensor row is [hi C | lo C] f16 (ld = 2 C), `lo_x` / `lo_y` the byte
+    // offset of the lo half in an input / output (and residual) row; y32 != nullptr: the result as f32 [pixels][ld32]
+    // instead (the tower's last layer, for the f32 heads)
+    int lo_x, lo_y, ld32, bytes32;
+    float *y32;
     unsigned long long *stamps;  // diagnostic build only
 };
 
-__global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
+// SPLIT: every activation and weight is a (hi, lo) f16 pair, x = hi + lo to 22 bits, and a product is three MFMAs
+// (hi*hi + lo*hi + hi*lo, f32 accumulation) — the arithmetic of kz_tower_split.hip, per layer: a chunk is 32 channels, its
+// hi halves in plane 0 and lo halves in plane 1 of the same image, a tap takes a hi and a lo weight step from the ring.
+template <bool SPLIT>
+__device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,7 +158,8 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const int nquarter = slot % a.nq, group = (slot / a.nq) * 8 + xcd;
     if (group >= a.groups) return;
     const int board0 = group * a.bpw;
-    const int chunks = a.cin / CH;
+    constexpr int CHS = SPLIT ? 32 : CH;  // input channels per staged chunk
+    const int chunks = a.cin / CHS;
     const int total_ksteps = chunks * KPC;
 
     // ---- set-up, ordered by latency: (1) this thread's 12 image pieces of chunk 0 are requested FIRST — everything about
@@ -158,7 +179,11 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         irow = (int)__umul24((unsigned)b, (unsigned)a.rpb) + q + yy + a.pitch + 1;
         return b < a.bpw && q < a.hw && board0 + b < a.boards;
     };
+#ifdef KZ_BC_REALTIME
+    KZ_RSTAMP(25);
+#else
     KZ_STAMP(25);
+#endif
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(a.x), 0, a.bytes_x, 0x00020000);
     // po[i] = byte offset of slot i in the [pixels][ld] OUTPUT tensor (the residual and, for a convolution of more than
     // one chunk, the input have the same ld), or -1 for a padding row: 32-bit offsets on a uniform base keep the twelve
@@ -173,12 +198,19 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         const bool ok = locate((tid >> 3) + i * 32, b, q, irow);
         irow0[i] = irow;
         const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
-        po[i] = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
-        v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
+        if constexpr (SPLIT) {  // pieces 0..3: the chunk's 32 hi halves, 4..7: its lo halves (ldx == ld; po serves the input only)
+            po[i] = ok ? (int)(__umul24(pix, (unsigned)a.ldx) * 2) + (piece >> 2) * a.lo_x + (piece & 3) * 16 : -1;
+            v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], 0, 0);
+        } else {
+            po[i] = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
+            v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
+        }
         if (piece == 0) *reinterpret_cast<unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2) = (unsigned short)irow;
     }
 
+#ifndef KZ_BC_REALTIME
     KZ_STAMP(26);
+#endif
     // weight ring: k-step g of this (layer, quarter): 4 KB = [nt 4][lane] x 16 B, the same for the four waves
     const uint4 *wp = a.w + (size_t)nquarter * total_ksteps * 256 + lane;
     uint4 wreg[PF][NTW];
@@ -213,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     for (int i = 0; i < MTW; i++) {
         int b, q, irow;
         const bool valid = locate((wr * MTW + i) * 16 + fr, b, q, irow);
-        T0[i] = (valid ? irow : a.pitch + 1) * PRS + (kq & 1) * a.plane + (kq >> 1) * 16;
+        T0[i] = (valid ? irow : a.pitch + 1) * PRS + (SPLIT ? kq * 16 : (kq & 1) * a.plane + (kq >> 1) * 16);
     }
 
     KZ_STAMP(24);
@@ -248,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
     const bool skip_last_tile = (wr * MTW + MTW - 1) >= a.bpw * a.tpb && (wr * MTW + MTW - 2) < a.bpw * a.tpb;
 #endif
     const bool with_res = a.res != nullptr;
-    const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res ? a.bytes : 0, 0x00020000);
+    // (SPLIT: the residual is fetched by the epilogue itself; the last chunk's tail loads meet a descriptor without records)
+    const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res && !SPLIT ? a.bytes : 0, 0x00020000);
     // ---- chunk 0 into the image: channels [0, 64) of this workgroup's boards, 8 pieces of 16 B per pixel row (never
     // into the halo: the halo clear of other threads needs no barrier in front of these writes) ----
     KZ_STAMP(2);
@@ -265,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         // chunk's descriptor has no records, so its tail loads return zeros without touching memory)
         const bool last_chunk = chunk + 1 == chunks;
         const auto trsrc = last_chunk ? rrsrc : xrsrc;
-        const int tsoff = last_chunk ? nquarter * OCW * 2 : (chunk + 1) * CH * 2;
+        const int tsoff = last_chunk ? nquarter * OCW * 2 : (chunk + 1) * CHS * 2;
 
         // Two half-steps per k-step: the MFMAs of tiles 0..2 run while the fragments of tiles 3..5 are read, and
         // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (the CU's second
@@ -283,13 +316,20 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int next_tap = tap < 8 ? tap + 1 : 8;
+            // MFMA steps of a tap: f16 — two, each with its own weight step (channels [0,32) and [32,64) of the chunk);
+            // SPLIT — three on the chunk's 32 channels: hi x W_hi, lo x W_hi (same weight step), hi x W_lo
+            constexpr int KS = SPLIT ? 3 : 2;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const int stage = (tap * 2 + ks) % PF;
+            for (int ks = 0; ks < KS; ks++) {
+                const int wstep = SPLIT ? tap * 2 + (ks == 2 ? 1 : 0) : tap * 2 + ks;  // weight step within the chunk
+                const int stage = wstep % PF;
+                const bool stage_done = SPLIT ? ks != 0 : true;  // this MFMA step is the last one that reads the stage
+                const int ao = SPLIT ? (ks == 1 ? a.plane : 0) : ks * 32;  // where this step's fragments sit in a row
+                const int ao_next = ks == KS - 1 ? 0 : SPLIT ? (ks + 1 == 1 ? a.plane : 0) : (ks + 1) * 32;
                 // ---- half 1 ----
 #pragma unroll
-                for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i] + ks * 32);
-                if (!skip_last_tile) bfB[HT - 1] = lds_frag(T[MTW - 1] + ks * 32);
+                for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i] + ao);
+                if (!skip_last_tile) bfB[HT - 1] = lds_frag(T[MTW - 1] + ao);
                 h16x8 af[NTW];  // aliases of the ring stage (no copy: the stage is reloaded after this k-step's MFMAs)
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
@@ -305,10 +345,10 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                 // ---- half 2 ----
                 // T is updated in place for the next tap: rows 0..2 are dead after the last half-2 read of this tap,
                 // rows 3..5 after the half-1 read above
-                if (ks == 1) tap_rows(next_tap, 0, HT, pitch_prs, T);
+                if (ks == KS - 1) tap_rows(next_tap, 0, HT, pitch_prs, T);
 #pragma unroll
-                for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i] + (ks < 1 ? (ks + 1) * 32 : 0));
-                if (ks == 1) tap_rows(next_tap, HT, MTW, pitch_prs, T);
+                for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i] + ao_next);
+                if (ks == KS - 1) tap_rows(next_tap, HT, MTW, pitch_prs, T);
 #pragma unroll
                 for (int i = 0; i < HT - 1; i++)
 #pragma unroll
@@ -324,18 +364,19 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // this stage's fragments have been issued to the MFMAs: refill it
-                if (tap * 2 + ks < KPC - PF) {  // (compile time) with the weights of k-step g + PF
+                if (!stage_done) {
+                } else if (wstep < KPC - PF) {  // (compile time) with the weights of k-step g + PF
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)(g + PF) * 256 + (wo * NTW + nt) * 64];
                 } else {  // last PF k-steps: pieces 4 jj .. 4 jj + 3 of the next image chunk / the residual
-                    const int jj = tap * 2 + ks - (KPC - PF);
+                    const int jj = wstep - (KPC - PF);
                     static_assert(NTW == 4 && PF == 3, "12 pieces = PF stages x NTW registers");
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++)
                         wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po[jj * 4 + nt], tsoff, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                g++;
+                if (stage_done) g++;
             }
         }
         KZ_STAMP(5 + chunk * 4);
@@ -358,6 +399,74 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         }
     }
 
+    if constexpr (SPLIT) {
+        // ---- epilogue, split arithmetic: [relu]; [+ residual (hi + lo)]; [final BN]; -> (hi, lo) f16 halves of the output
+        // row, or f32 for the heads.  Straight from the accumulator layout (a lane owns 4 consecutive channels of a pixel
+        // row: 8-byte pieces) — three times the MFMA work per stored byte of the f16 kernel pays for the narrower stores.
+        // Without a residual its descriptor has no records: the loads return zeros and move nothing.
+        const auto r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res ? a.bytes : 0, 0x00020000);
+        const auto yrsrc = a.y32 ? __builtin_amdgcn_make_buffer_rsrc(a.y32, 0, a.bytes32, 0x00020000)
+                                 : __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        int pixel[MTW];  // of this lane's row of tile i, or -1
+#pragma unroll
+        for (int i = 0; i < MTW; i++) {
+            int b, q, irow;
+            const bool ok = locate((wr * MTW + i) * 16 + fr, b, q, irow);
+            pixel[i] = ok ? (int)(__umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q) : -1;
+        }
+        const float floor_ = a.relu ? 0.0f : -__builtin_inff();
+        constexpr int NH = NTW / 2;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            u32x2 rh[NH][MTW], rl[NH][MTW];
+#pragma unroll
+            for (int n2 = 0; n2 < NH; n2++)
+#pragma unroll
+                for (int i = 0; i < MTW; i++) {
+                    const int oc2 = (nquarter * OCW + ((wo * NTW + half * NH + n2) * 16 + kq * 4)) * 2;
+                    const int row = pixel[i] >= 0 ? (int)(__umul24((unsigned)pixel[i], (unsigned)a.ld) * 2) : -1;
+                    rh[n2][i] = __builtin_amdgcn_raw_buffer_load_b64(r2, row, oc2, 0);
+                    rl[n2][i] = __builtin_amdgcn_raw_buffer_load_b64(r2, row, oc2 + a.lo_y, 0);
+                }
+#pragma unroll
+            for (int n2 = 0; n2 < NH; n2++) {
+                const int nt = half * NH + n2;
+                const int oc = nquarter * OCW + (wo * NTW + nt) * 16 + kq * 4;
+                f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.post_scale) {
+                    ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
+                    pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
+                }
+#pragma unroll
+                for (int i = 0; i < MTW; i++) {
+                    f32x4 v = acc[nt][i];
+                    const h16x4 h = __builtin_bit_cast(h16x4, rh[n2][i]), l = __builtin_bit_cast(h16x4, rl[n2][i]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu]
+                        v[j] += (float)h[j] + (float)l[j];  // hi + lo is exact in f32; added AFTER the ReLU (post_act.py:227-228)
+                    }
+                    v = v * ps + pt;
+                    if (a.y32) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrsrc,
+                                                               pixel[i] >= 0 ? (int)(__umul24((unsigned)pixel[i], (unsigned)a.ld32) * 4) : -1, oc * 4, 0);
+                    } else {
+                        h16x4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            hi[j] = (h16)v[j];
+                            lo[j] = (h16)(v[j] - (float)hi[j]);
+                        }
+                        const int row = pixel[i] >= 0 ? (int)(__umul24((unsigned)pixel[i], (unsigned)a.ld) * 2) : -1;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), yrsrc, row, oc * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), yrsrc, row, oc * 2 + a.lo_y, 0);
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
     // The result is staged through LDS (the image is dead now) so that HBM sees whole 128-byte lines (this workgroup's
     // 64 output channels of a pixel) instead of 8-byte pieces: O[row][64 oc] f16, row stride 144 B.  The residual arrived
@@ -438,7 +547,13 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) {
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
                                                nquarter * OCW * 2, KZ_BC_STORE_AUX);
     KZ_STAMP(20);
+#ifdef KZ_BC_REALTIME
+    KZ_RSTAMP(26);
+#endif
 }
+
+__global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) { board_conv_body<false>(a); }
+__global__ __launch_bounds__(256, 2) void kz_board_conv_split16(BoardConvDev a) { board_conv_body<true>(a); }
 
 }  // namespace
 
@@ -496,8 +611,44 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
                             }
 }
 
-void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
+// ---- split arithmetic: tensors of [pixels][hi C | lo C] f16 rows, 32-channel chunks ----
+bool board_conv_split_supported(int h, int w, int cin, int cout) {
+    return NTW == 4 && cin % 32 == 0 && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 && geometry(h, w).bpw >= 1;
+}
+
+size_t board_conv_split_weight_elems(int cin, int cout) { return (size_t)2 * 9 * cin * cout; }
+
+// OIHW f32 (BN folded) -> [n_quarter][chunk][tap][hi, lo][nt 4][lane 64][8] f16: element j of lane (fr, kq) is the hi
+// (lo) half of W[oc = 64*n_quarter + 16*nt + fr][channel = 32*chunk + 8*kq + j][tap]; hi = f16(w), lo = f16(w - hi)
+void board_conv_split_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst) {
+    const int chunks = cin / 32, quarters = cout / OCW;
+    size_t o = 0;
+    for (int nq = 0; nq < quarters; nq++)
+        for (int chunk = 0; chunk < chunks; chunk++)
+            for (int tap = 0; tap < 9; tap++)
+                for (int half = 0; half < 2; half++)
+                    for (int nt = 0; nt < OCW / 16; nt++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int j = 0; j < 8; j++) {
+                                const int oc = OCW * nq + 16 * nt + (lane & 15);
+                                const int ch = 32 * chunk + 8 * (lane >> 4) + j;
+                                const float wv = oihw[((size_t)oc * cin + ch) * 9 + tap];
+                                const _Float16 hi = (_Float16)wv;
+                                const _Float16 hv = half ? (_Float16)(wv - (float)hi) : hi;
+                                uint16_t bits;
+                                __builtin_memcpy(&bits, &hv, 2);
+                                dst[o++] = bits;
+                            }
+}
+
+namespace {
+void launch_board_conv_any(const BoardConvArgs &t, bool split, hipStream_t stream) {
     BoardConvDev d;
+    d.lo_x = t.cin * 2;
+    d.lo_y = t.cout * 2;
+    d.y32 = t.y32;
+    d.ld32 = t.ldy32;
+    d.bytes32 = (int)((size_t)t.boards * t.h * t.w * t.ldy32 * 4);
     d.x = static_cast<const h16 *>(t.x);
     d.w = static_cast<const uint4 *>(t.weights);
     d.bias = t.bias;
@@ -533,32 +684,43 @@ void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) {
     d.inv_nhb = (65536u + nhb - 1) / nhb;
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)kz_board_conv_split16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         done_mask |= 1ull << (dev & 63);
     }
     const int grid = ((d.groups + 7) / 8) * 8 * d.nq;
 #ifdef KZ_BC_STAMPS
+#ifdef KZ_BC_REALTIME
+    constexpr int KEPT = 4;  // the stamps of launches stamp_launch .. stamp_launch + 3, one after the other
+#else
+    constexpr int KEPT = 1;
+#endif
     static unsigned long long *stamp_buf = nullptr;
     static int launches = 0;
     const size_t stamp_bytes = (size_t)grid * 4 * 32 * sizeof(unsigned long long);
-    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, (size_t)8192 * 4 * 32 * 8);
-    d.stamps = stamp_buf;
+    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, (size_t)8192 * 4 * 32 * 8 * KEPT);
     static const int stamp_launch = getenv("KZ_BC_STAMP_LAUNCH") ? atoi(getenv("KZ_BC_STAMP_LAUNCH")) : 20;  // 20: a layer with a residual
-    if (launches == stamp_launch) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, stream);
+    d.stamps = stamp_buf + (size_t)((launches - stamp_launch) & (KEPT - 1)) * (stamp_bytes / 8);
+    if (launches == stamp_launch) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes * KEPT, stream);
 #else
     d.stamps = nullptr;
 #endif
-    kz_board_conv_f16<<<grid, 256, geo.lds_bytes, stream>>>(d);
+    if (split) kz_board_conv_split16<<<grid, 256, geo.lds_bytes, stream>>>(d);
+    else kz_board_conv_f16<<<grid, 256, geo.lds_bytes, stream>>>(d);
 #ifdef KZ_BC_STAMPS
-    if (launches++ == stamp_launch && getenv("KZ_BC_STAMP_FILE")) {
+    if (launches++ == stamp_launch + KEPT - 1 && getenv("KZ_BC_STAMP_FILE")) {
         (void)hipStreamSynchronize(stream);
-        std::vector<unsigned long long> host(stamp_bytes / 8);
-        (void)hipMemcpy(host.data(), stamp_buf, stamp_bytes, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> host(stamp_bytes / 8 * KEPT);
+        (void)hipMemcpy(host.data(), stamp_buf, stamp_bytes * KEPT, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(getenv("KZ_BC_STAMP_FILE"), "wb")) {
-            fwrite(host.data(), 1, stamp_bytes, f);
+            fwrite(host.data(), 1, stamp_bytes * KEPT, f);
             fclose(f);
         }
     }
 #endif
 }
+}  // namespace
+
+void launch_board_conv(const BoardConvArgs &t, hipStream_t stream) { launch_board_conv_any(t, false, stream); }
+void launch_board_conv_split(const BoardConvArgs &t, hipStream_t stream) { launch_board_conv_any(t, true, stream); }
 
 }  // namespace kz

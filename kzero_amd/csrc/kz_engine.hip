@@ -61,6 +61,7 @@ struct DevConv {  // packed for kz_conv_igemm: [k*k][cout_p][cin_p] in T, bias f
     int cin_p = 0, cout_p = 0, cout = 0, k = 1;
     void *bw = nullptr;  // instead of w: packed for kz_board_conv_f16 (3x3, f16, channels % 64 == 0)
     bool bw2 = false;    // ... packed for kz_board_conv2_f16 (two Go-size boards per workgroup)
+    void *bws = nullptr; // instead of w: (hi, lo) pairs packed for kz_board_conv_split16 (3x3, split arithmetic)
     void *sw = nullptr;  // in addition to w: (hi, lo) f16 pairs for kz_conv1x1_split (1x1 head convolutions, split16)
 };
 
@@ -146,6 +147,17 @@ struct DeviceWeights {
         return upload_f32(cv.b, &d.b);
     }
 
+    // the same convolution for the board-tile kernel in split arithmetic
+    int upload_board_conv_split(const Conv &cv, DevConv &d) {
+        d.k = 3;
+        d.cout = d.cout_p = cv.cout;
+        d.cin_p = cv.cin;
+        std::vector<uint16_t> packed(kz::board_conv_split_weight_elems(cv.cin, cv.cout));
+        kz::board_conv_split_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        if (upload(packed.data(), packed.size() * 2, &d.bws)) return 1;
+        return upload_f32(cv.b, &d.b);
+    }
+
     // OIHW conv -> [tap][cout_p][cin_p]; tap = ky*k + kx
     int upload_conv(const Conv &cv, DevConv &d) {
         d.k = cv.k;
@@ -203,6 +215,7 @@ struct DeviceWeights {
     }
 
     bool use_board_conv = false;
+    bool use_board_split = false;  // split16 on a board too large for the resident launch: per-layer board-tile kernel
     int stem_cin_p = 0;  // != 0: the stem goes through the board-tile kernel and wants encoded rows of this many channels
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
     int *bc_rowmap = nullptr;  // (experiment build: kz_board_conv2_f16's tile-row map and halo-row list)
@@ -225,7 +238,7 @@ struct DeviceWeights {
         }
         if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
 
-        if (split16 || pairs16) {
+        if ((split16 && !use_board_split) || pairs16) {
             // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 stem k-steps, then 9*C/32 per convolution
             // (+ the attention heads' five passes and bias rows when the split launch carries the heads)
             const bool heads = split16 && fused_split;
@@ -321,7 +334,9 @@ struct DeviceWeights {
                 const bool stem64 = on && i == 0 && !conv2 && m.tower[0].cin <= 64 && m.tower[0].k == 3 &&
                                     kz::board_conv_supported(dtype, m.h, m.w, 64, m.tower[0].cout);
                 const bool board = on && kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
-                if (stem64) {
+                if (use_board_split && i >= 1) {  // (the stem stays an exact-f32 implicit GEMM: its inputs are f32 planes)
+                    if (upload_board_conv_split(m.tower[i], tower[i])) return 1;
+                } else if (stem64) {
                     stem_cin_p = 64;
                     if (upload_board_conv(m.tower[0], tower[0], 64)) return 1;
                 } else if (board ? upload_board_conv(m.tower[i], tower[i]) : upload_conv(m.tower[i], tower[i])) {
@@ -452,6 +467,7 @@ struct kz_engine {
     }
     std::vector<void *> allocs, pinned;
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
+    bool bsplit = false;  // split16 per layer through kz_board_conv_split16 (Go-size boards)
     bool fused32 = false;  // the exact-f32 resident launch with the conv policy head and the scalar head inside
     bool fused_split = false;  // the split-f16 launch with the scalar head and the attention policy head inside
     bool nb4 = false;        // resident chess tower with four boards per workgroup (KZ_TOWER_NB=4)
@@ -623,6 +639,19 @@ struct kz_engine {
 
     int conv(const DevConv &w, const void *x, int ldx, void *y, int ldy, int M, int relu, const void *res, bool post,
              int h, int wd, int group, int src_group, int src_off, float *y32 = nullptr, int ldy32 = 0) {
+        if (w.bws) {  // whole boards as LDS-resident spatial tiles, split arithmetic: (hi, lo) rows of 2 C halves
+            kz::BoardConvArgs b{};
+            b.x = x; b.ldx = 2 * ldx; b.weights = w.bws; b.bias = w.b; b.res = res; b.y = y; b.ldy = 2 * ldy;
+            b.y32 = y32; b.ldy32 = ldy32;
+            b.post_scale = post ? wts->post_scale : nullptr;
+            b.post_shift = post ? wts->post_shift : nullptr;
+            b.boards = M / (h * wd); b.h = h; b.w = wd; b.cin = w.cin_p; b.cout = w.cout; b.relu = relu;
+            prof.begin("kz_board_conv_split16", stream);
+            kz::launch_board_conv_split(b, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         if (w.bw) {  // whole boards as LDS-resident spatial tiles
             kz::BoardConvArgs b{};
             b.x = x; b.ldx = ldx; b.weights = w.bw; b.bias = w.b; b.res = res; b.y = y; b.ldy = ldy;
@@ -747,6 +776,27 @@ struct kz_engine {
             prof.end(stream);
             HIP_TRY(hipGetLastError());
             tower_out = 0;
+            return 0;
+        }
+        if (bsplit) {
+            // the stem in exact f32 (its inputs are f32 planes), its output split into (hi, lo) halves — an f32 tensor and a
+            // (hi, lo) tensor of the same shape have the same size, so the three activation buffers serve both —, the
+            // 2·depth tower convolutions in split arithmetic, the last one writing f32 for the heads
+            if (conv(wts->tower[0], x_in, cin_p, act[2], cp, M, 0, nullptr, false, m.h, m.w, hw, hw, 0)) return 1;
+            prof.begin("kz_split_rows", stream);
+            kz::launch_split_rows((const float *)act[2], act[0], (size_t)M, cp, stream);
+            prof.end(stream);
+            int cur = 0;
+            for (int i = 1; i <= m.depth; i++) {
+                const int mid = (cur + 1) % 3, nxt = (cur + 2) % 3;
+                const bool last = i == m.depth;
+                if (conv(wts->tower[2 * i - 1], act[cur], cp, act[mid], cp, M, 1, nullptr, false, m.h, m.w, hw, hw, 0)) return 1;
+                if (conv(wts->tower[2 * i], act[mid], cp, last ? nullptr : act[nxt], cp, M, 1, act[cur], last, m.h, m.w, hw, hw, 0,
+                         last ? (float *)act[nxt] : nullptr, cp))
+                    return 1;
+                cur = nxt;
+            }
+            tower_out = cur;
             return 0;
         }
         // stem: conv + bias, no activation (post_act.py:205)
@@ -1051,7 +1101,13 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     // exact-f32 resident launch (the per-layer activation taps of KZ_KEEP_ACTIVATIONS need the per-layer path)
     e->resident32 = kz::tower32_supported(dtype, m.h, m.w, m.channels, m.depth) && m.c_in <= e->cin_p &&
                     !(force && force[0] == '1') && !e->keep;
-    if (split16) {
+    // split arithmetic per layer for boards the resident split launch cannot hold (Go 19x19)
+    const bool board_split_ok = split16 && !(kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) && e->cin_p == 32) &&
+                                m.depth >= 1 && !e->keep && kz::board_conv_split_supported(m.h, m.w, m.channels, m.channels) &&
+                                m.channels % 32 == 0 && (size_t)max_batch * m.h * m.w * m.channels * 4 < ((size_t)1 << 31);
+    if (board_split_ok) {
+        e->split16 = e->bsplit = true;
+    } else if (split16) {
         if (!kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) || e->cin_p != 32)
             return fail("kz_engine_create: KZ_DTYPE_F32_SPLIT16 needs 256 tower channels on a board of at most 64 squares or "
                         "64 / 128 channels on at most 96 squares, and at most 32 input planes");
@@ -1063,7 +1119,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->pairs16 = dtype == KZ_DTYPE_F16 && !e->resident && !(force && force[0] == '1') && !e->keep &&
                  !(nopairs && nopairs[0] == '1') && e->cin_p == 32 &&
                  kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
-    const bool board_conv = board_conv_ok && !e->pairs16;
+    const bool board_conv = board_conv_ok && !e->pairs16 && !e->bsplit;
     e->fused32 = e->resident32 && !e->split16 && !(nofuse && nofuse[0] == '1') &&
                  kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
                                              m.channels, m.sh_conv.cout, m.sh_fc0.out);
@@ -1072,6 +1128,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                                                      m.channels, m.sh_conv.cout, m.sh_fc0.out);
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
+              : e->bsplit    ? "board_conv_split16"
               : e->fused_split ? "tower_resident_split16+heads"
               : e->split16   ? "tower_resident_split16"
               : e->fused32   ? "tower_resident_f32+heads"
@@ -1097,6 +1154,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->device = device;
             w->dtype = dtype;
             w->use_board_conv = board_conv;
+            w->use_board_split = e->bsplit;
             w->fused_split = e->fused_split;
             if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16, e->pairs16)) return 1;
             g_cache[key] = w;
@@ -1174,8 +1232,11 @@ KZ_API int kz_model_supports_dtype(const kz_model *model, int dtype) {
     if (!model) return -1;
     const Model &m = *model->m;
     if (dtype == KZ_DTYPE_F32 || dtype == KZ_DTYPE_F16) return 1;
-    if (dtype == KZ_DTYPE_F32_SPLIT16)
-        return kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) && round_up(m.c_in, 32) == 32 ? 1 : 0;
+    if (dtype == KZ_DTYPE_F32_SPLIT16) {
+        if (kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) && round_up(m.c_in, 32) == 32) return 1;
+        // larger boards: per layer (the engine additionally needs max_batch * h * w * channels * 4 bytes < 2 GiB)
+        return m.depth >= 1 && m.channels % 32 == 0 && kz::board_conv_split_supported(m.h, m.w, m.channels, m.channels) ? 1 : 0;
+    }
     return -1;
 }
 
@@ -1189,9 +1250,10 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     const Model &m = *e->model;
     int per = 0, wgs = 0;
     if (e->resident) per = e->nb4 ? 4 : kz::tower_resident_boards_per_workgroup();
-    else if (e->split16 || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
+    else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
     else if (e->resident32) per = kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
+    else if (e->path == "board_conv_split16") wgs = kz::board_conv_workgroups(batch, m.h, m.w, m.channels);
     else if (e->path == "board_conv_f16")
 #ifdef KZ_EXPERIMENTS
         wgs = e->wts->conv2 ? kz::board_conv2_workgroups(batch, m.channels) : kz::board_conv_workgroups(batch, m.h, m.w, m.channels);

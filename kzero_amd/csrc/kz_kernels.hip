@@ -122,6 +122,30 @@ void launch_encode_dense(int dtype, const float *nchw, int batch, int c, int hw,
         kz_encode_dense<h16><<<grid_for(total, 256), 256, 0, stream>>>(nchw, batch, c, hw, (h16 *)x, ldx);
 }
 
+// f32 [rows][c] -> [rows][hi c | lo c] f16, hi = f16(x), lo = f16(x - hi): the (hi, lo) tensors of the per-layer split
+// convolution (kz_board_conv.hip).  HBM-bound: 4 B read + 4 B written per element; a thread takes 4 consecutive channels.
+__global__ void kz_split_rows(const float *__restrict__ x, h16 *__restrict__ y, long rows, int c) {
+    const long total = rows * (c / 4);
+    for (long id = blockIdx.x * (long)blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const long r = id / (c / 4);
+        const int g = (int)(id - r * (c / 4));
+        const float4 v = *reinterpret_cast<const float4 *>(x + r * c + g * 4);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        h16 hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hi[j] = (h16)f[j];
+            lo[j] = (h16)(f[j] - (float)hi[j]);
+        }
+        *reinterpret_cast<uint2 *>(y + r * 2 * c + g * 4) = *reinterpret_cast<const uint2 *>(hi);
+        *reinterpret_cast<uint2 *>(y + r * 2 * c + c + g * 4) = *reinterpret_cast<const uint2 *>(lo);
+    }
+}
+
+void launch_split_rows(const float *x, void *y, size_t rows, int c, hipStream_t stream) {
+    kz_split_rows<<<grid_for((long)rows * (c / 4), 256), 256, 0, stream>>>(x, (h16 *)y, (long)rows, c);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution.
 //

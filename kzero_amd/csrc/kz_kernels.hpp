@@ -131,12 +131,23 @@ struct BoardConvArgs {
     const int *rowmap = nullptr;
     const unsigned short *halo = nullptr;
     int n_halo = 0;
+    // launch_board_conv_split only: y32 != nullptr writes the result as f32 [boards*h*w][ldy32] instead of (hi, lo) halves
+    float *y32 = nullptr;
+    int ldy32 = 0;
 };
 bool board_conv_supported(int dtype, int h, int w, int cin, int cout);
 int board_conv_workgroups(int boards, int h, int w, int cout);  // grid size: 64 output channels per workgroup
 size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
 void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);
+// the same convolution in split arithmetic (f32-equivalent results on the f16 matrix cores, kz_tower_split.hip's): x, res
+// and y are [boards*h*w][hi C | lo C] f16 rows (ldx = 2 cin, ldy = 2 cout), cin a multiple of 32
+bool board_conv_split_supported(int h, int w, int cin, int cout);
+size_t board_conv_split_weight_elems(int cin, int cout);
+void board_conv_split_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
+void launch_board_conv_split(const BoardConvArgs &a, hipStream_t stream);
+// f32 [rows][c] -> [rows][hi c | lo c] f16 (hi = f16(x), lo = f16(x - hi)): the stem's output enters the split layers
+void launch_split_rows(const float *x, void *y, size_t rows, int c, hipStream_t stream);
 // second organisation for boards of 193..384 squares (Go 19x19): two boards per workgroup, one workgroup per CU, staging
 // under the MFMAs (kz_board_conv2.hip).  Same BoardConvArgs, with its own weight packing and tables.
 bool board_conv2_supported(int dtype, int h, int w, int cin, int cout);

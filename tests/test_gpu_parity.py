@@ -617,6 +617,65 @@ def test_go19_generic_path_vs_oracle(dev):
     assert_f32(p, p_ref, "policy")
 
 
+@pytest.mark.parametrize("game,depth,channels,batch", [("go-19", 2, 128, 5), ("go-19", 3, 64, 9), ("go-19", 1, 256, 3)])
+def test_board_conv_split16_vs_oracle(dev, game, depth, channels, batch):
+    """KZ_DTYPE_F32_SPLIT16 on a board the one-launch split tower cannot hold: one kz_board_conv_split16 launch per layer
+    ((hi, lo) f16 rows in HBM, three MFMAs per product), stem in exact f32, f32 heads.  The north_star's 1e-4 against the
+    oracle, and against the exact-f32 path of this library; odd batches leave the last workgroups ragged."""
+    blob = synth.random_model(game, depth, channels, "conv", seed=51)
+    bits, scalars_in = synth.random_boards(game, batch, seed=52)
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    model = capi.Model(blob=blob)
+    assert model.supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)
+    eng = capi.Engine(model, dev, 16, capi.KZ_DTYPE_F32_SPLIT16)
+    assert eng.tower_path == "board_conv_split16"
+    s, p = eng.eval_packed(bits, scalars_in)
+    print(f"board conv split16 {game} {depth}x{channels}: max |d scalars| {np.abs(s - s_ref).max():.2e}, "
+          f"max |d policy| {np.abs(p - p_ref).max():.2e}")
+    assert_f32(s, s_ref, "scalars vs oracle")
+    assert_f32(p, p_ref, "policy vs oracle")
+    f32 = capi.Engine(model, dev, 16, capi.KZ_DTYPE_F32)
+    s32, p32 = f32.eval_packed(bits, scalars_in)
+    assert_f32(s, s32, "scalars vs exact f32")
+    assert_f32(p, p32, "policy vs exact f32")
+    s1, p1 = eng.eval_packed(bits[:1], scalars_in[:1])
+    assert np.array_equal(s1, s[:1]) and np.array_equal(p1, p[:1]), "result depends on the batch size"
+
+
+def test_go19_40x256_split16_at_executor_batch_512(dev):
+    """The G8 network at its executor batch in the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity):
+    82 per-layer launches in split arithmetic.  All 512 boards: finite, deterministic, batch-size invariant; 1e-4
+    against the exact-f32 path of this library on a 32-board sample and against the real oracle on 8 boards."""
+    blob = synth.random_model("go-19", 40, 256, "conv", seed=33)
+    bits, scalars_in = synth.random_boards("go-19", 512, seed=34)
+    model = capi.Model(blob=blob)
+    eng = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F32_SPLIT16)
+    assert eng.tower_path == "board_conv_split16" and eng.max_batch == 512
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert s.shape == (512, 5) and p.shape == (512, 362)
+    assert np.isfinite(s).all() and np.isfinite(p).all()
+    s2, p2 = eng.eval_packed(bits, scalars_in)
+    assert np.array_equal(s, s2) and np.array_equal(p, p2), "not deterministic"
+    for lo, n in ((0, 7), (300, 64), (511, 1)):
+        sn, pn = eng.eval_packed(bits[lo:lo + n], scalars_in[lo:lo + n])
+        assert np.array_equal(sn, s[lo:lo + n]) and np.array_equal(pn, p[lo:lo + n]), "result depends on the batch size"
+    sample = np.arange(0, 512, 16)
+    f32 = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32)
+    s_ref, p_ref = f32.eval_packed(bits[sample], scalars_in[sample])
+    print(f"go-19 40x256 B=512 split16 vs exact f32 on 32 boards: max |d scalars| {np.abs(s[sample] - s_ref).max():.2e}, "
+          f"max |d policy| {np.abs(p[sample] - p_ref).max():.2e}")
+    assert_f32(s[sample], s_ref, "scalars, 32 of 512 boards vs exact f32")
+    assert_f32(p[sample], p_ref, "policy, 32 of 512 boards vs exact f32")
+    net = O.OracleNet(blob)
+    eight = sample[::4]
+    dense = O.encode_input_full(bits[eight], scalars_in[eight], net.n_scalar, net.n_bool, net.h, net.w)
+    so, po = net.forward(dense, threads=os.cpu_count() or 1)
+    assert_f32(s[eight], so, "split16 vs oracle, scalars")
+    assert_f32(p[eight], po, "split16 vs oracle, policy")
+
+
 @pytest.mark.parametrize("game,depth,batch", [("go-19", 2, 5), ("go-9", 2, 11), ("ataxx-7", 2, 13)])
 def test_board_conv_path_vs_oracle(dev, game, depth, batch):
     """f16 per-layer path with whole boards as LDS-resident spatial tiles (kz_board_conv_f16): 128-channel towers on
