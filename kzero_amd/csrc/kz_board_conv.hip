@@ -198,7 +198,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         const bool ok = locate((tid >> 3) + i * 32, b, q, irow);
         irow0[i] = irow;
         const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
-        if constexpr (SPLIT) {  // pieces 0..3: the chunk's 32 hi halves, 4..7: its lo halves (ldx == ld; po serves the input only)
+        if constexpr (SPLIT) {  // pieces 0..3: the chunk's 32 hi halves, 4..7: its lo halves (cin == cout: po serves the residual and the output too)
             po[i] = ok ? (int)(__umul24(pix, (unsigned)a.ldx) * 2) + (piece >> 2) * a.lo_x + (piece & 3) * 16 : -1;
             v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], 0, 0);
         } else {
@@ -280,8 +280,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     const bool skip_last_tile = (wr * MTW + MTW - 1) >= a.bpw * a.tpb && (wr * MTW + MTW - 2) < a.bpw * a.tpb;
 #endif
     const bool with_res = a.res != nullptr;
-    // (SPLIT: the residual is fetched by the epilogue itself; the last chunk's tail loads meet a descriptor without records)
-    const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res && !SPLIT ? a.bytes : 0, 0x00020000);
+    const auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res ? a.bytes : 0, 0x00020000);
     // ---- chunk 0 into the image: channels [0, 64) of this workgroup's boards, 8 pieces of 16 B per pixel row (never
     // into the halo: the halo clear of other threads needs no barrier in front of these writes) ----
     KZ_STAMP(2);
@@ -291,7 +290,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     KZ_STAMP(3);
     for (int chunk = 0; chunk < chunks; chunk++) {
         __syncthreads();  // the chunk is staged
-        KZ_STAMP(4 + chunk * 4);
+        KZ_STAMP(4 + (chunk & 3) * 4);
         // what the ring's dying stages fetch during the last PF k-steps of this chunk: the next chunk's image pieces, or
         // (last chunk) the residual's, or nothing
         // (no branch in the k-loop: one descriptor and one scalar offset, selected here; without a residual the last
@@ -379,7 +378,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 if (stage_done) g++;
             }
         }
-        KZ_STAMP(5 + chunk * 4);
+        KZ_STAMP(5 + (chunk & 3) * 4);
         if (!last_chunk) {
             // ---- the next chunk's 12 pieces sit in the ring registers (piece 4 j + nt in stage j): into the image once
             // every wave is done with this chunk's fragments; then the ring takes the next chunk's first PF k-steps ----
@@ -387,7 +386,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
 #pragma unroll
             for (int i = 0; i < 12; i++) erow[i] = *reinterpret_cast<const unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2);
             __syncthreads();
-            KZ_STAMP(6 + chunk * 4);
+            KZ_STAMP(6 + (chunk & 3) * 4);
 #pragma unroll
             for (int i = 0; i < 12; i++)
                 if (po[i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * PRS + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
@@ -395,44 +394,51 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
             for (int st = 0; st < PF; st++)
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) wreg[st][nt] = wp[(size_t)(g + st) * 256 + (wo * NTW + nt) * 64];
-            KZ_STAMP(7 + chunk * 4);
+            KZ_STAMP(7 + (chunk & 3) * 4);
         }
     }
 
     if constexpr (SPLIT) {
-        // ---- epilogue, split arithmetic: [relu]; [+ residual (hi + lo)]; [final BN]; -> (hi, lo) f16 halves of the output
-        // row, or f32 for the heads.  Straight from the accumulator layout (a lane owns 4 consecutive channels of a pixel
-        // row: 8-byte pieces) — three times the MFMA work per stored byte of the f16 kernel pays for the narrower stores.
-        // Without a residual its descriptor has no records: the loads return zeros and move nothing.
-        const auto r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16 *>(with_res ? a.res : a.x), 0, with_res ? a.bytes : 0, 0x00020000);
+        // ---- epilogue, split arithmetic: [relu]; [+ residual (hi + lo)]; [final BN]; -> the (hi, lo) f16 halves of the
+        // output row, or f32 for the heads.  Through the same output tile in LDS as the f16 epilogue below, in two passes of
+        // 32 output channels: a tile row is [hi 64 B | lo 64 B] (or 32 f32), so its eight 16-byte pieces are again what a
+        // thread's slot moves, coalesced, between registers and HBM.  The residual of pass 0 arrived in the ring registers
+        // during the last three weight steps; that of pass 1 is requested as soon as those registers are free.
+        KZ_STAMP(18);
         const auto yrsrc = a.y32 ? __builtin_amdgcn_make_buffer_rsrc(a.y32, 0, a.bytes32, 0x00020000)
                                  : __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        int pixel[MTW];  // of this lane's row of tile i, or -1
-#pragma unroll
-        for (int i = 0; i < MTW; i++) {
-            int b, q, irow;
-            const bool ok = locate((wr * MTW + i) * 16 + fr, b, q, irow);
-            pixel[i] = ok ? (int)(__umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q) : -1;
-        }
+        const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
         const float floor_ = a.relu ? 0.0f : -__builtin_inff();
         constexpr int NH = NTW / 2;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            u32x2 rh[NH][MTW], rl[NH][MTW];
+        for (int pass = 0; pass < 2; pass++) {
+            __syncthreads();  // pass 0: every wave is done with the last chunk's fragments; pass 1: with pass 0's tile
+            if (with_res) {
 #pragma unroll
-            for (int n2 = 0; n2 < NH; n2++)
+                for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
+                if (pass == 0) {
 #pragma unroll
-                for (int i = 0; i < MTW; i++) {
-                    const int oc2 = (nquarter * OCW + ((wo * NTW + half * NH + n2) * 16 + kq * 4)) * 2;
-                    const int row = pixel[i] >= 0 ? (int)(__umul24((unsigned)pixel[i], (unsigned)a.ld) * 2) : -1;
-                    rh[n2][i] = __builtin_amdgcn_raw_buffer_load_b64(r2, row, oc2, 0);
-                    rl[n2][i] = __builtin_amdgcn_raw_buffer_load_b64(r2, row, oc2 + a.lo_y, 0);
+                    for (int i = 0; i < 12; i++)
+                        wreg[i / NTW][i % NTW] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, po[i], nquarter * OCW * 2 + 64, 0));
                 }
+                __syncthreads();
+            }
+            u32x2 rh[NH][MTW], rl[NH][MTW];
+            if (with_res) {
+#pragma unroll
+                for (int n2 = 0; n2 < NH; n2++)
+#pragma unroll
+                    for (int i = 0; i < MTW; i++) {
+                        const unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + (n2 * 16 + kq * 4) * 2;
+                        rh[n2][i] = *reinterpret_cast<const u32x2 *>(slot);
+                        rl[n2][i] = *reinterpret_cast<const u32x2 *>(slot + 64);
+                    }
+            }
 #pragma unroll
             for (int n2 = 0; n2 < NH; n2++) {
-                const int nt = half * NH + n2;
-                const int oc = nquarter * OCW + (wo * NTW + nt) * 16 + kq * 4;
+                const int nt = pass * NH + n2;
+                const int oc = nquarter * OCW + nt * 16 + kq * 4;
                 f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (a.post_scale) {
                     ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
@@ -440,17 +446,18 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 }
 #pragma unroll
                 for (int i = 0; i < MTW; i++) {
+                    unsigned char *row = lds + ((wr * MTW + i) * 16 + fr) * ORS;  // this lane's 4 channels of it: owned by the lane
                     f32x4 v = acc[nt][i];
-                    const h16x4 h = __builtin_bit_cast(h16x4, rh[n2][i]), l = __builtin_bit_cast(h16x4, rl[n2][i]);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu]
-                        v[j] += (float)h[j] + (float)l[j];  // hi + lo is exact in f32; added AFTER the ReLU (post_act.py:227-228)
+                    for (int j = 0; j < 4; j++) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu]
+                    if (with_res) {
+                        const h16x4 h = __builtin_bit_cast(h16x4, rh[n2][i]), l = __builtin_bit_cast(h16x4, rl[n2][i]);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] += (float)h[j] + (float)l[j];  // hi + lo is exact in f32; AFTER the ReLU (post_act.py:227-228)
                     }
                     v = v * ps + pt;
                     if (a.y32) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrsrc,
-                                                               pixel[i] >= 0 ? (int)(__umul24((unsigned)pixel[i], (unsigned)a.ld32) * 4) : -1, oc * 4, 0);
+                        *reinterpret_cast<f32x4 *>(row + (n2 * 16 + kq * 4) * 4) = v;
                     } else {
                         h16x4 hi, lo;
 #pragma unroll
@@ -458,13 +465,26 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                             hi[j] = (h16)v[j];
                             lo[j] = (h16)(v[j] - (float)hi[j]);
                         }
-                        const int row = pixel[i] >= 0 ? (int)(__umul24((unsigned)pixel[i], (unsigned)a.ld) * 2) : -1;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), yrsrc, row, oc * 2, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), yrsrc, row, oc * 2 + a.lo_y, 0);
+                        *reinterpret_cast<h16x4 *>(row + (n2 * 16 + kq * 4) * 2) = hi;
+                        *reinterpret_cast<h16x4 *>(row + 64 + (n2 * 16 + kq * 4) * 2) = lo;
                     }
                 }
             }
+            __syncthreads();
+            // a padding row's store is out of range and dropped.  (hi, lo): piece p of the tile row is piece p & 3 of the hi
+            // (p < 4) or lo half of the output row, exactly the input slot po[i] describes; f32: piece p of 128 contiguous bytes
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const u32x4 piece_v = *reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS);
+                if (a.y32)
+                    __builtin_amdgcn_raw_buffer_store_b128(piece_v, yrsrc, po[i] >= 0 ? po[i] + (piece >> 2) * (64 - a.lo_y) : -1,
+                                                           nquarter * OCW * 4 + pass * 128, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(piece_v, yrsrc, po[i], nquarter * OCW * 2 + pass * 64, 0);
+            }
         }
+        KZ_STAMP(19);
+        KZ_STAMP(20);
         return;
     }
     // ---- epilogue: [relu]; [+ residual]; [final BN]; -> f16 -> NHWC rows in global memory ----
@@ -613,7 +633,7 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
 
 // ---- split arithmetic: tensors of [pixels][hi C | lo C] f16 rows, 32-channel chunks ----
 bool board_conv_split_supported(int h, int w, int cin, int cout) {
-    return NTW == 4 && cin % 32 == 0 && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 && geometry(h, w).bpw >= 1;
+    return NTW == 4 && cin == cout && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 && geometry(h, w).bpw >= 1;
 }
 
 size_t board_conv_split_weight_elems(int cin, int cout) { return (size_t)2 * 9 * cin * cout; }

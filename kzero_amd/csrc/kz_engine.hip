@@ -1110,7 +1110,8 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     } else if (split16) {
         if (!kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) || e->cin_p != 32)
             return fail("kz_engine_create: KZ_DTYPE_F32_SPLIT16 needs 256 tower channels on a board of at most 64 squares or "
-                        "64 / 128 channels on at most 96 squares, and at most 32 input planes");
+                        "64 / 128 channels on at most 96 squares, and at most 32 input planes; or, per layer, tower channels a "
+                        "multiple of 64, at least one block and max_batch * squares * channels * 4 bytes < 2 GiB");
         e->split16 = e->resident32 = true;  // same tensors in and out as the exact-f32 resident launch
     }
     // plain-f16 board-resident tower for the shapes the chess launch (kz_tower.hip) does not take: the split kernel

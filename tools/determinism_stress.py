@@ -13,7 +13,8 @@ CASES = [("chess", 20, 256, "attention", 256, capi.KZ_DTYPE_F16, 200),
          ("ataxx-7", 8, 128, "ataxx_conv", 255, capi.KZ_DTYPE_F32, 300),   # one-launch f32 network, ragged last workgroup
          ("go-9", 6, 128, "conv", 200, capi.KZ_DTYPE_F32, 200),            # the same with the extra-move head, one board per workgroup
          ("go-19", 6, 256, "conv", 509, capi.KZ_DTYPE_F16, 150),           # round 3 board-tile kernel: ring-register prefetch, odd batch
-         ("chess", 6, 256, "attention", 251, capi.KZ_DTYPE_F32_SPLIT16, 150)]  # round 3: split launch with the heads inside
+         ("chess", 6, 256, "attention", 251, capi.KZ_DTYPE_F32_SPLIT16, 150),  # round 3: split launch with the heads inside
+         ("go-19", 3, 128, "conv", 203, capi.KZ_DTYPE_F32_SPLIT16, 100)]       # round 3: per-layer split board-tile kernel
 bad = 0
 for game, depth, ch, head, batch, dtype, reps in CASES:
     blob = synth.random_model(game, depth, ch, head, seed=9)
