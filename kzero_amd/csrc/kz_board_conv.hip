@@ -116,17 +116,17 @@ struct BoardConvDev {
                                        // values they meet
     int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
     int rm_off;             // LDS offset of the 384 image-row indices (u16), behind the image / the epilogue's output tile
-    // split arithmetic (kz_board_conv_split16) only: a tensor row is [hi C | lo C] f16 (ld = 2 C), `lo_x` / `lo_y` the byte
-    // offset of the lo half in an input / output (and residual) row; y32 != nullptr: the result as f32 [pixels][ld32]
-    // instead (the tower's last layer, for the f32 heads)
-    int lo_x, lo_y, ld32, bytes32;
+    // split arithmetic (kz_board_conv_split16) only: a tensor row is [hi 32 | lo 32] f16 per group of 32 channels (ld = 2 C);
+    // y32 != nullptr: the result as f32 [pixels][ld32 = C] instead (the tower's last layer, for the f32 heads)
+    int ld32, bytes32;
     float *y32;
     unsigned long long *stamps;  // diagnostic build only
 };
 
 // SPLIT: every activation and weight is a (hi, lo) f16 pair, x = hi + lo to 22 bits, and a product is three MFMAs
 // (hi*hi + lo*hi + hi*lo, f32 accumulation) — the arithmetic of kz_tower_split.hip, per layer: a chunk is 32 channels, its
-// hi halves in plane 0 and lo halves in plane 1 of the same image, a tap takes a hi and a lo weight step from the ring.
+// hi halves in plane 0 and lo halves in plane 1 of the same image, a tap takes a hi and a lo weight step from the ring.  In
+// HBM a pixel row is [hi 32 | lo 32] per group of 32 channels: a chunk, and a pass of the epilogue, are whole 128-byte lines.
 template <bool SPLIT>
 __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -198,13 +198,10 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         const bool ok = locate((tid >> 3) + i * 32, b, q, irow);
         irow0[i] = irow;
         const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
-        if constexpr (SPLIT) {  // pieces 0..3: the chunk's 32 hi halves, 4..7: its lo halves (cin == cout: po serves the residual and the output too)
-            po[i] = ok ? (int)(__umul24(pix, (unsigned)a.ldx) * 2) + (piece >> 2) * a.lo_x + (piece & 3) * 16 : -1;
-            v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, po[i], 0, 0);
-        } else {
-            po[i] = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
-            v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
-        }
+        // (SPLIT: a row is [hi 32 | lo 32] per group of 32 channels — a chunk is again 128 contiguous bytes, pieces 0..3 its
+        // hi halves, 4..7 its lo halves, and the same offsets serve input, residual and output)
+        po[i] = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
+        v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
         if (piece == 0) *reinterpret_cast<unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2) = (unsigned short)irow;
     }
 
@@ -297,7 +294,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         // chunk's descriptor has no records, so its tail loads return zeros without touching memory)
         const bool last_chunk = chunk + 1 == chunks;
         const auto trsrc = last_chunk ? rrsrc : xrsrc;
-        const int tsoff = last_chunk ? nquarter * OCW * 2 : (chunk + 1) * CHS * 2;
+        const int tsoff = last_chunk ? nquarter * OCW * (SPLIT ? 4 : 2) : (chunk + 1) * 128;  // (a chunk is 128 bytes of a row either way)
 
         // Two half-steps per k-step: the MFMAs of tiles 0..2 run while the fragments of tiles 3..5 are read, and
         // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (the CU's second
@@ -420,7 +417,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 if (pass == 0) {
 #pragma unroll
                     for (int i = 0; i < 12; i++)
-                        wreg[i / NTW][i % NTW] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, po[i], nquarter * OCW * 2 + 64, 0));
+                        wreg[i / NTW][i % NTW] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, po[i], nquarter * OCW * 4 + 128, 0));
                 }
                 __syncthreads();
             }
@@ -471,17 +468,13 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 }
             }
             __syncthreads();
-            // a padding row's store is out of range and dropped.  (hi, lo): piece p of the tile row is piece p & 3 of the hi
-            // (p < 4) or lo half of the output row, exactly the input slot po[i] describes; f32: piece p of 128 contiguous bytes
+            // a padding row's store is out of range and dropped.  The pass's 32 channels are 128 contiguous bytes of the output
+            // row in either form — [hi 32 | lo 32] f16 or 32 f32, and an f32 row is as long as a (hi, lo) row — so the slot
+            // offsets po[i] serve both
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const u32x4 piece_v = *reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS);
-                if (a.y32)
-                    __builtin_amdgcn_raw_buffer_store_b128(piece_v, yrsrc, po[i] >= 0 ? po[i] + (piece >> 2) * (64 - a.lo_y) : -1,
-                                                           nquarter * OCW * 4 + pass * 128, 0);
-                else
-                    __builtin_amdgcn_raw_buffer_store_b128(piece_v, yrsrc, po[i], nquarter * OCW * 2 + pass * 64, 0);
-            }
+            for (int i = 0; i < 12; i++)
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
+                                                       nquarter * OCW * 4 + pass * 128, 0);
         }
         KZ_STAMP(19);
         KZ_STAMP(20);
@@ -631,7 +624,7 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
                             }
 }
 
-// ---- split arithmetic: tensors of [pixels][hi C | lo C] f16 rows, 32-channel chunks ----
+// ---- split arithmetic: tensors of [pixels][C / 32][hi 32 | lo 32] f16 rows, 32-channel chunks ----
 bool board_conv_split_supported(int h, int w, int cin, int cout) {
     return NTW == 4 && cin == cout && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 && geometry(h, w).bpw >= 1;
 }
@@ -664,8 +657,6 @@ void board_conv_split_pack_weights(const float *oihw, int cout, int cin, uint16_
 namespace {
 void launch_board_conv_any(const BoardConvArgs &t, bool split, hipStream_t stream) {
     BoardConvDev d;
-    d.lo_x = t.cin * 2;
-    d.lo_y = t.cout * 2;
     d.y32 = t.y32;
     d.ld32 = t.ldy32;
     d.bytes32 = (int)((size_t)t.boards * t.h * t.w * t.ldy32 * 4);

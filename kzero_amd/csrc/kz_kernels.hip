@@ -122,7 +122,7 @@ void launch_encode_dense(int dtype, const float *nchw, int batch, int c, int hw,
         kz_encode_dense<h16><<<grid_for(total, 256), 256, 0, stream>>>(nchw, batch, c, hw, (h16 *)x, ldx);
 }
 
-// f32 [rows][c] -> [rows][hi c | lo c] f16, hi = f16(x), lo = f16(x - hi): the (hi, lo) tensors of the per-layer split
+// f32 [rows][c] -> [rows][c / 32][hi 32 | lo 32] f16, hi = f16(x), lo = f16(x - hi): the (hi, lo) tensors of the per-layer split
 // convolution (kz_board_conv.hip).  HBM-bound: 4 B read + 4 B written per element; a thread takes 4 consecutive channels.
 __global__ void kz_split_rows(const float *__restrict__ x, h16 *__restrict__ y, long rows, int c) {
     const long total = rows * (c / 4);
@@ -137,8 +137,9 @@ __global__ void kz_split_rows(const float *__restrict__ x, h16 *__restrict__ y, 
             hi[j] = (h16)f[j];
             lo[j] = (h16)(f[j] - (float)hi[j]);
         }
-        *reinterpret_cast<uint2 *>(y + r * 2 * c + g * 4) = *reinterpret_cast<const uint2 *>(hi);
-        *reinterpret_cast<uint2 *>(y + r * 2 * c + c + g * 4) = *reinterpret_cast<const uint2 *>(lo);
+        h16 *dst = y + r * 2 * c + ((g * 4) >> 5) * 64 + ((g * 4) & 31);  // group of 32 channels: [hi 32 | lo 32]
+        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(hi);
+        *reinterpret_cast<uint2 *>(dst + 32) = *reinterpret_cast<const uint2 *>(lo);
     }
 }
 

@@ -141,12 +141,12 @@ size_t board_conv_weight_elems(int cin, int cout);
 void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
 void launch_board_conv(const BoardConvArgs &a, hipStream_t stream);
 // the same convolution in split arithmetic (f32-equivalent results on the f16 matrix cores, kz_tower_split.hip's): x, res
-// and y are [boards*h*w][hi C | lo C] f16 rows (ldx = 2 cin, ldy = 2 cout), cin a multiple of 32
+// and y are [boards*h*w][C / 32][hi 32 | lo 32] f16 rows (ldx = ldy = 2 C), cin == cout a multiple of 64
 bool board_conv_split_supported(int h, int w, int cin, int cout);
 size_t board_conv_split_weight_elems(int cin, int cout);
 void board_conv_split_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst);
 void launch_board_conv_split(const BoardConvArgs &a, hipStream_t stream);
-// f32 [rows][c] -> [rows][hi c | lo c] f16 (hi = f16(x), lo = f16(x - hi)): the stem's output enters the split layers
+// f32 [rows][c] -> [rows][c / 32][hi 32 | lo 32] f16 (hi = f16(x), lo = f16(x - hi)): the stem's output enters the split layers
 void launch_split_rows(const float *x, void *y, size_t rows, int c, hipStream_t stream);
 // second organisation for boards of 193..384 squares (Go 19x19): two boards per workgroup, one workgroup per CU, staging
 // under the MFMAs (kz_board_conv2.hip).  Same BoardConvArgs, with its own weight packing and tables.
