@@ -617,7 +617,8 @@ def test_go19_generic_path_vs_oracle(dev):
     assert_f32(p, p_ref, "policy")
 
 
-@pytest.mark.parametrize("game,depth,channels,batch", [("go-19", 2, 128, 5), ("go-19", 3, 64, 9), ("go-19", 1, 256, 3)])
+@pytest.mark.parametrize("game,depth,channels,batch", [("go-19", 2, 128, 5), ("go-19", 3, 64, 9), ("go-19", 1, 256, 3),
+                                                       ("go-9", 2, 256, 11)])  # 256 channels on 81 squares: four boards per workgroup
 def test_board_conv_split16_vs_oracle(dev, game, depth, channels, batch):
     """KZ_DTYPE_F32_SPLIT16 on a board the one-launch split tower cannot hold: one kz_board_conv_split16 launch per layer
     ((hi, lo) f16 rows in HBM, three MFMAs per product), stem in exact f32, f32 heads.  The north_star's 1e-4 against the
