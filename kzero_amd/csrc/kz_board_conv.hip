@@ -23,6 +23,11 @@
 //               of the residual), so those loads fly under the MFMAs instead of behind a barrier.
 //   grid      = 1-D, XCD-aware: the cout/64 workgroups of one board group run on ONE XCD back to back, so the
 //               image is read from HBM once and from that XCD's L2 by the others.
+//
+// Two instances of one body: kz_board_conv_f16, and kz_board_conv_split16 — the same loop in the split arithmetic of
+// kz_tower_split.hip ((hi, lo) f16 pairs, three MFMAs per product) for KZ_DTYPE_F32_SPLIT16 on Go-size boards: chunks of 32
+// channels whose hi and lo halves fill the two planes, 128-byte [hi 32 | lo 32] groups in HBM, the epilogue in two passes
+// through the same output tile.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
