@@ -55,6 +55,19 @@ def test_flops_match_baseline_md():
     assert abs(go.info.flops_per_eval / 34.13e9 - 1) < 3e-3
 
 
+def test_which_models_the_parity_arithmetic_takes():
+    """kz_model_supports_dtype needs no GPU: it is what the Rust binding's default (`KZ_HIP_DTYPE=parity`, hip.rs) asks before
+    it creates an engine.  KZ_DTYPE_F32_SPLIT16: the one-launch shapes, and since round 3 Go-size boards per layer."""
+    S = capi.KZ_DTYPE_F32_SPLIT16
+    for game, depth, ch, head, want in [("chess", 20, 256, "attention", True), ("ataxx-7", 8, 128, "ataxx_conv", True),
+                                        ("go-9", 4, 128, "conv", True), ("go-19", 40, 256, "conv", True),
+                                        ("go-19", 2, 64, "conv", True), ("go-9", 2, 256, "conv", True),
+                                        ("chess", 2, 32, "attention", False), ("go-19", 2, 96, "conv", False)]:
+        model = capi.Model(blob=synth.random_model(game, depth, ch, head))
+        assert model.supports_dtype(capi.KZ_DTYPE_F32) and model.supports_dtype(capi.KZ_DTYPE_F16)
+        assert model.supports_dtype(S) == want, (game, depth, ch)
+
+
 def test_environment_switches_are_exactly_the_documented_ones():
     """include/kz_hip.h promises a complete list of the environment switches libkzhip.so reads: compare it with the
     KZ_* strings of the built library.  Experiments and ablation knobs live in libkzhip_exp.so only."""
