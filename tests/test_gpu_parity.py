@@ -481,6 +481,7 @@ def _scaled_stem(blob, factor):
     ("ataxx-7", 2, 128, "ataxx_conv", "f16", "tower_resident_f16g", {}),
     ("go-9", 2, 128, "conv", "f16", "board_conv_f16", {"KZ_NO_RESIDENT_F16G": "1"}),
     ("go-9", 2, 128, "conv", "f16", "conv_igemm_f16", {"KZ_NO_RESIDENT_F16G": "1", "KZ_NO_BOARD_CONV": "1"}),
+    ("go-19", 2, 128, "conv", "split16", "board_conv_split16", {}),
 ])
 def test_f16_range_overflow_is_reported(dev, game, depth, channels, head, dtype, path, env):
     """f16 storage overflows beyond +-65504 (include/kz_hip.h, KZ_DTYPE_F16): a network whose residual stream leaves that
