@@ -1,0 +1,177 @@
+// kz_conv_heads.hpp — the scalar head and the conv policy heads (ConvPolicyHead, AtaxxConvPolicyHead) on two f32 row images
+// that already sit in LDS: the tail of the one-launch networks.  Shared by the exact-f32 launch (kz_tower_f32.hip) and the
+// split-f16 launch (kz_tower_split.hip, which converts its (hi, lo) images to f32 rows first).  Arithmetic follows
+// python/lib/model/post_act.py:8-31 (scalar head) and :75-110 (conv policy heads).
+//
+// Device code only; included INSIDE `namespace kz { namespace {` of a .hip file, after f32x4 is defined.  `Dev` is the
+// launch's argument struct: it must have the members hc, hs, pc, policy_len, zero_tail, extra, epoch, hw, nb, inv_hw,
+// sh_b0, sh_w1t, sh_b1, sh_w2, sh_b2, p_b1, pe_bc, pe_wl, pe_bl, small_w (tower32_pack_small_weights), scalars, policy,
+// nonfinite_flag.
+#pragma once
+
+#ifndef KZ_HEADS_STAMP
+#define KZ_HEADS_STAMP(slot) do { } while (0)
+#endif
+
+template <int C>
+__device__ __forceinline__ int plane_of(int kq) {  // byte offset of lane group kq's 16-byte piece within a step
+    return C == 256 ? 256 * kq : 256 * (kq & 1) + 128 * (kq >> 1);
+}
+
+// Images: rows of C f32 (natural channel order), row stride RS = 4 C + 16 bytes, NT tiles of 16 rows; `xin` = LDS offset of
+// the tower output (after the final BN), `hin` = of the policy head's hidden layer (Conv1x1 C->C + ReLU), `scratch` = of
+// 16 * RS bytes the tail may overwrite (the f32 launch's zero rows).  board0 / boards / rows_valid: this workgroup's
+// boards.  Every thread of the 256 calls it; the caller has synchronised the workgroup behind the images' last writes.
+template <int C, int NT, typename Dev>
+__device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds, int scratch, int xin, int hin, int board0,
+                                               int boards, int rows_valid) {
+    constexpr int G = C / 16, RS = C * 4 + 16, ZERO = 0;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int fr = lane & 15, kq = lane >> 4;
+    const int koff = plane_of<C>(kq);
+    (void)ZERO;
+    // A 1x1 convolution with at most 32 output channels (two 16-channel tiles, zero-padded by the host) on the MFMAs:
+    // the row tiles are split over the waves (wave w: tiles w and w + 4), every wave streams the whole (small)
+    // weight fragment set: 16 * C/16 MFMAs per wave.  emit(oc, row, value) for this lane's 2 x 2 x 4 results.
+    auto small_conv = [&](int img, const f32x4 *wfrag /* [G][2][64] */, auto emit) {
+        f32x4 sa[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) sa[mt][t] = f32x4{0, 0, 0, 0};
+        const bool two = wave + 4 < NT;
+        const int base0 = img + (wave * 16 + fr) * RS + koff;
+        const int base1 = two ? base0 + 64 * RS : base0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const f32x4 w0 = wfrag[(g * 2 + 0) * 64 + lane], w1 = wfrag[(g * 2 + 1) * 64 + lane];
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(lds + base0 + g * 16);
+            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(lds + base1 + g * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                sa[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], b0[q], sa[0][0], 0, 0, 0);
+                sa[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], b0[q], sa[1][0], 0, 0, 0);
+                sa[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], b1[q], sa[0][1], 0, 0, 0);
+                sa[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], b1[q], sa[1][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int row = (wave + 4 * t) * 16 + fr;
+            if ((t == 0 || two) && row < rows_valid) {
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) emit(mt, q, row, sa[mt][t][q]);
+            }
+        }
+    };
+    // the zero rows are dead by now: scratch for the scalar head
+    const int n_in = a.hc * a.hw, nseg = 256 / a.hs;
+    float *sact = reinterpret_cast<float *>(lds + scratch);  // [nb][hc*hw] channel-major like nn.Flatten on NCHW (post_act.py:16)
+    float *sext = sact + a.nb * n_in;                     // [nb][hw] extra-move plane
+    float *shid = sext + a.nb * a.hw;                     // [nb][hs]
+    float *sw2 = shid + a.nb * a.hs;                      // [5][hs]
+    float *sred = sw2 + 5 * a.hs;                         // [nseg][nb*hs]
+    // Everything the tail reads from global memory is requested up front — a dependent L2 round trip per use costs
+    // ~1 us with one wave per SIMD, and there were forty of them in a row: the biases of the two small convolutions
+    // for this lane's output channels, the first 32 of this thread's Linear weights, the hidden layer's bias
+    float sb[2][4], pb[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int oc = mt * 16 + kq * 4 + q;
+            sb[mt][q] = oc < a.hc ? a.sh_b0[oc] : (oc == a.hc && a.extra) ? a.pe_bc[0] : 0.0f;
+            pb[mt][q] = oc < a.pc ? a.p_b1[oc] : 0.0f;
+        }
+    const int fseg = tid / a.hs, fj = tid - fseg * a.hs;
+    constexpr int WPRE = 32;
+    float wpre[WPRE];
+#pragma unroll
+    for (int k = 0; k < WPRE; k++) {
+        const int i = fseg + k * nseg;
+        wpre[k] = (fseg < nseg && i < n_in) ? a.sh_w1t[(size_t)i * a.hs + fj] : 0.0f;
+    }
+    const float b1v = tid < a.nb * a.hs ? a.sh_b1[tid % a.hs] : 0.0f;
+    const float b2v = tid < boards * 5 ? a.sh_b2[tid % 5] : 0.0f;
+    for (int i = tid; i < 5 * a.hs; i += 256) sw2[i] = a.sh_w2[i];
+    // scalar head Conv1x1 C->hc + ReLU and the extra moves' Conv1x1 C->1 (post_act.py:8-31, :86-96): one small conv over x
+    bool bad = false;  // a non-finite sum = a non-finite value somewhere in this board's tower output
+    small_conv(xin, a.small_w, [&](int mt, int q, int row, float v) {
+        const int oc = mt * 16 + kq * 4 + q;
+        const int bb = (int)(((unsigned)row * a.inv_hw) >> 16), p = row - bb * a.hw;
+        if (oc < a.hc) {
+            bad |= !(fabsf(v) <= 3.0e38f);
+            sact[bb * n_in + oc * a.hw + p] = fmaxf(v + sb[mt][q], 0.0f);
+        } else if (oc == a.hc && a.extra) {
+            sext[row] = v + sb[mt][q];
+        }
+    });
+    if (bad && a.nonfinite_flag) *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may live in pinned host memory)
+    // policy (post_act.py:75-110): Conv1x1 C->pc on the hidden layer, channel-major flatten
+    small_conv(hin, a.small_w + G * 2 * 64, [&](int mt, int q, int row, float v) {
+        const int oc = mt * 16 + kq * 4 + q;
+        const int bb = (int)(((unsigned)row * a.inv_hw) >> 16), p = row - bb * a.hw;
+        if (oc < a.pc) a.policy[(size_t)(board0 + bb) * a.policy_len + oc * a.hw + p] = v + pb[mt][q];
+    });
+    // AtaxxConvPolicyHead appends a constant-zero pass logit (post_act.py:106-110)
+    if (a.zero_tail && tid < boards) a.policy[(size_t)(board0 + tid) * a.policy_len + a.pc * a.hw] = 0.0f;
+    KZ_HEADS_STAMP(60);
+    __syncthreads();
+    // Linear(n_in -> hs): thread (segment, output) walks every nseg-th input of the transposed matrix (the hs weights of
+    // one input are contiguous) for all boards of the workgroup at once; the segments meet through LDS
+    {
+        const int seg = fseg, j = fj;
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (seg < nseg) {
+#pragma unroll
+            for (int k = 0; k < WPRE; k++) {
+                const int i = seg + k * nseg;
+                if (i < n_in) {
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++)
+                        if (bb < a.nb) part[bb] += wpre[k] * sact[bb * n_in + i];
+                }
+            }
+#pragma unroll 8
+            for (int i = seg + WPRE * nseg; i < n_in; i += nseg) {
+                const float w = a.sh_w1t[(size_t)i * a.hs + j];
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+                    if (bb < a.nb) part[bb] += w * sact[bb * n_in + i];
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++)
+                if (bb < a.nb) sred[(seg * a.nb + bb) * a.hs + j] = part[bb];
+        }
+    }
+    if (a.extra) {  // Linear(hw -> extra) behind the policy planes
+        for (int o = tid >> 2; o < boards * a.extra; o += 64) {
+            const int bb = o / a.extra, j = o - bb * a.extra, seg = tid & 3;
+            float s = 0.0f;
+#pragma unroll 8
+            for (int p = seg; p < a.hw; p += 4) s += a.pe_wl[(size_t)j * a.hw + p] * sext[bb * a.hw + p];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            if (seg == 0) a.policy[(size_t)(board0 + bb) * a.policy_len + a.pc * a.hw + j] = s + a.pe_bl[j];
+        }
+    }
+    __syncthreads();
+    // (nb * hs may exceed the 256 threads — e.g. three 6x6 boards with a hidden size of 96: every hidden unit of every
+    // board gets a turn; the first turn's bias was fetched before the small convolutions)
+    for (int o = tid; o < a.nb * a.hs; o += 256) {
+        float s = o == tid ? b1v : a.sh_b1[o % a.hs];
+        for (int seg = 0; seg < nseg; seg++) s += sred[seg * a.nb * a.hs + o];
+        shid[o] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    if (tid < boards * 5) {
+        const int bb = tid / 5, j = tid - bb * 5;
+        float s = b2v;
+        for (int i = 0; i < a.hs; i++) s += sw2[j * a.hs + i] * shid[bb * a.hs + i];
+        a.scalars[(size_t)(board0 + bb) * 5 + j] = s;
+    }
+}

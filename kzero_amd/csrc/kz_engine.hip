@@ -241,18 +241,29 @@ struct DeviceWeights {
         if ((split16 && !use_board_split) || pairs16) {
             // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 stem k-steps, then 9*C/32 per convolution
             // (+ the attention heads' five passes and bias rows when the split launch carries the heads)
-            const bool heads = split16 && fused_split;
+            const bool conv_heads = split16 && fused_split && m.policy_kind != kz::POLICY_ATTENTION;  // (Ataxx, Go 9x9)
+            const bool heads = split16 && fused_split && !conv_heads;
             const size_t tower_elems = kz::tower_split_weight_elems(C, m.depth, split16);
-            std::vector<uint16_t> packed(tower_elems + (heads ? kz::tower_split_heads_weight_elems() : 0));
+            std::vector<uint16_t> packed(tower_elems + (heads ? kz::tower_split_heads_weight_elems() : 0) +
+                                         (conv_heads ? kz::tower_split_conv_heads_weight_elems(C) : 0));
             const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = 9 * step_elems,
                          layer_elems = (size_t)9 * (C / 32) * step_elems;
             kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, hw, true, split16, packed.data());
             for (int l = 0; l < 2 * m.depth; l++)
                 kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, hw, false, split16,
                                              packed.data() + stem_elems + layer_elems * l);
-            std::vector<float> bias((size_t)(1 + 2 * m.depth + (heads ? 5 : 0)) * C);
+            std::vector<float> bias((size_t)(1 + 2 * m.depth + (heads ? 5 : conv_heads ? 1 : 0)) * C);
             for (int l = 0; l < 1 + 2 * m.depth; l++)
                 for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
+            if (conv_heads) {  // the policy head's hidden layer as one more pass; the small convolutions as for the f32 launch
+                kz::tower_split_pack_conv_heads(m.p_conv0.w.data(), C, packed.data() + tower_elems);
+                for (int o = 0; o < C; o++) bias[(size_t)(1 + 2 * m.depth) * C + o] = m.p_conv0.b[o];
+                std::vector<float> small(kz::tower32_small_weight_elems(C));
+                kz::tower32_pack_small_weights(m.sh_conv.w.data(), m.sh_conv.cout,
+                                               m.policy_extra_moves ? m.p_extra_conv.w.data() : nullptr, m.p_conv1.w.data(),
+                                               m.policy_conv_channels, C, small.data());
+                if (upload_f32(small, &h32_small)) return 1;
+            }
             if (heads) {
                 kz::tower_split_pack_heads(m.p_bulk.w.data(), m.p_bulk.b.data(), m.p_under.w.data(), m.p_under.b.data(),
                                            packed.data() + tower_elems, bias.data() + (size_t)(1 + 2 * m.depth) * C);
@@ -745,7 +756,7 @@ struct kz_engine {
                 t.n_scalar = m.n_scalar;
                 t.n_bool = m.n_bool;
             }
-            if (fused_split) {
+            if (fused_split && m.policy_kind == kz::POLICY_ATTENTION) {
                 kz::Tower32Args::Heads &hd = t.heads;
                 hd.on = true;
                 hd.sh_w0 = wts->sh_w0; hd.sh_b0 = wts->sh_b0; hd.sh_w1 = wts->sh_w1; hd.sh_b1 = wts->sh_b1;
@@ -754,7 +765,7 @@ struct kz_engine {
                 hd.scalars = d_scalars; hd.policy = d_policy;
                 hd.nonfinite_flag = nf_flag; hd.epoch = nf_epoch;
             }
-            if (fused32) {
+            if (fused32 || (fused_split && m.policy_kind != kz::POLICY_ATTENTION)) {  // conv policy heads: the f32 tail
                 kz::Tower32Args::Heads &hd = t.heads;
                 hd.on = true;
                 hd.hc = m.sh_conv.cout; hd.hs = m.sh_fc0.out;
@@ -1124,9 +1135,11 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->fused32 = e->resident32 && !e->split16 && !(nofuse && nofuse[0] == '1') &&
                  kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
                                              m.channels, m.sh_conv.cout, m.sh_fc0.out);
-    e->fused_split = e->split16 && !(nofuse && nofuse[0] == '1') &&
-                     kz::tower_split_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.h, m.w,
-                                                     m.channels, m.sh_conv.cout, m.sh_fc0.out);
+    e->fused_split = e->split16 && !e->bsplit && !(nofuse && nofuse[0] == '1') &&
+                     (kz::tower_split_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.h, m.w,
+                                                      m.channels, m.sh_conv.cout, m.sh_fc0.out) ||
+                      kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h,
+                                                           m.w, m.channels, m.sh_conv.cout, m.sh_fc0.out));
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
               : e->bsplit    ? "board_conv_split16"

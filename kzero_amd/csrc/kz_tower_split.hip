@@ -31,6 +31,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#include "kz_conv_heads.hpp"  // conv_heads_f32: the conv policy heads and the scalar head on f32 row images in LDS
+
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
 // Shapes: C tower channels (256 or 128), NT tiles of 16 pixel rows per workgroup = floor(16 NT / hw) whole boards packed
@@ -76,6 +78,11 @@ struct SplitDev {
     // three s-major passes, conv_bulk[Q:2Q)), the bias table 5 more rows in the same order.
     const float *sh_w0, *sh_b0, *sh_w1, *sh_b1, *sh_w2, *sh_b2;
     const int32_t *att_idx;  // [1880]: (flat_to_att / 88) * 96 + flat_to_att % 88
+    // fused heads (HEADS == 2: conv policy heads — Ataxx, Go 9x9): the policy head's Conv1x1 C->C + ReLU as one more pass of
+    // the weight stream (+ one bias row), then kz_conv_heads.hpp on f32 copies of the two images (its members:)
+    int hc, hs, pc, policy_len, zero_tail, extra;
+    const float *sh_w1t, *p_b1, *pe_bc, *pe_wl, *pe_bl;
+    const f32x4 *small_w;
     float *scalars, *policy;
     int *nonfinite_flag;
     int epoch;
@@ -90,9 +97,11 @@ __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
     }
 }
 
-template <int C, int NT, bool SPLIT, bool HEADS = false>
+// HEADS: 0 = the tower alone; 1 = + the chess attention network's heads; 2 = + conv policy heads and the scalar head
+template <int C, int NT, bool SPLIT, int HEADS = 0>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
-    static_assert(!HEADS || (C == 256 && NT == 4 && SPLIT), "fused heads: the chess attention network in split arithmetic");
+    static_assert(HEADS != 1 || (C == 256 && NT == 4 && SPLIT), "attention heads: the chess network in split arithmetic");
+    static_assert(HEADS != 2 || (SPLIT && (C == 256 || C == 128)), "conv heads: split arithmetic, a shape of kz_tower_f32.hip");
     using L = Geo<C, NT, SPLIT>;
     constexpr int PARTS = L::PARTS, PF = L::PF;
     constexpr int RS = L::RS, OT = L::OT, G = L::G, DELTA = L::DELTA, XH = L::XH, YH = L::YH, ZH = L::ZH;
@@ -106,8 +115,8 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     const int rows_valid = boards * a.hw;
     const int layers = 2 * a.depth;
     // of the ring: the 9 stem k-steps in front of them are read directly; the heads' passes follow the tower's
-    const int total_ksteps = layers * 9 * G + (HEADS ? HEAD_PASSES * G : 0);
-    const int bias_rows = layers + (HEADS ? HEAD_PASSES : 0);
+    const int total_ksteps = layers * 9 * G + (HEADS == 1 ? HEAD_PASSES * G : HEADS == 2 ? G : 0);
+    const int bias_rows = layers + (HEADS == 1 ? HEAD_PASSES : HEADS == 2 ? 1 : 0);
 
     // ---- weight stream: prime PF stages (stage s = k-step g % PF) ----
     const uint4 *wp_stem = a.w + wave * OT * 64 + lane;
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                         for (int j = 0; j < 4; j++) v[j] += (float)rl[j];
                     }
                     v = v * ps + pt;
-                    if constexpr (HEADS) {  // the heads read the tower output from X (in place: this lane owns the slot)
+                    if constexpr (HEADS != 0) {  // the heads read the tower output from X (in place: this lane owns the slot)
                         h16x4 hi, lo;
                         split4(v, hi, lo);
                         *reinterpret_cast<h16x4 *>(lds + XH + off) = hi;
@@ -407,7 +416,61 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         __syncthreads();
     }
 
-    if constexpr (HEADS) {
+    if constexpr (HEADS == 2) {
+        // ---- conv policy heads (post_act.py:75-110) and scalar head (post_act.py:8-31) ----
+        // The policy head's hidden layer, Conv1x1 C->C + ReLU, is one more pass of the weight stream over X (centre tap only,
+        // three MFMAs per product) into Y.
+        init_acc();
+#pragma unroll
+        for (int ch = 0; ch < G; ch++) {
+            h16x8 ah[OT], al[OT], bh[NT], bl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                const int t = XH + frag_base + nt * 16 * RS + ch * 16;
+                bh[nt] = *reinterpret_cast<const h16x8 *>(lds + t);
+                bl[nt] = *reinterpret_cast<const h16x8 *>(lds + t + DELTA);
+            }
+            ring_take(ch & (PF - 1), ah, al);
+            mfma3(ah, al, bh, bl);
+            g++;
+        }
+        epilogue(YH, true, false);
+        __syncthreads();
+        // Both images, (hi, lo) -> f32 rows in the layout of kz_tower_f32.hip ([16 scratch rows][X][Y], row stride 4 C + 16),
+        // through registers (everything else in LDS is dead); then the exact-f32 launch's own tail.
+        constexpr int RS32 = C * 4 + 16, X32 = 16 * RS32, Y32 = X32 + L::ROWS * RS32;
+        static_assert(Y32 + L::ROWS * RS32 <= L::LDS_BYTES, "the f32 images fit the launch's LDS");
+        constexpr int PIECES = L::ROWS * (C / 4), PER = (PIECES + 255) / 256;
+        f32x4 vx[PER], vy[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int id = tid + k * 256;
+            if (id < PIECES) {
+                const int r = id / (C / 4), p4 = id - r * (C / 4), off = r * RS + p4 * 8;
+                const h16x4 xh = *reinterpret_cast<const h16x4 *>(lds + XH + off), xl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
+                const h16x4 yh = *reinterpret_cast<const h16x4 *>(lds + YH + off), yl = *reinterpret_cast<const h16x4 *>(lds + YH + DELTA + off);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    vx[k][j] = (float)xh[j] + (float)xl[j];
+                    vy[k][j] = (float)yh[j] + (float)yl[j];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int id = tid + k * 256;
+            if (id < PIECES) {
+                const int r = id / (C / 4), p4 = id - r * (C / 4);
+                *reinterpret_cast<f32x4 *>(lds + X32 + r * RS32 + p4 * 16) = vx[k];
+                *reinterpret_cast<f32x4 *>(lds + Y32 + r * RS32 + p4 * 16) = vy[k];
+            }
+        }
+        __syncthreads();
+        conv_heads_f32<C, NT>(a, lds, 0, X32, Y32, board0, boards, rows_valid);
+    }
+
+    if constexpr (HEADS == 1) {
         // =====================================================================================================
         // Heads on the LDS-resident tower output X (hi, lo; already through the final BN), in the same split arithmetic:
         // every 1x1 convolution is one more pass of the weight stream (three MFMAs per product, f32 accumulators), every
@@ -962,7 +1025,7 @@ int split_tiles_for(int hw, int channels, bool split) {
     return 0;
 }
 
-template <int C, int NT, bool SPLIT, bool HEADS = false>
+template <int C, int NT, bool SPLIT, int HEADS = 0>
 void launch(const SplitDev &d, int grid, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
@@ -1269,6 +1332,42 @@ void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const floa
     for (int q = 0; q < 256; q++) bias5[4 * 256 + q] = b_bulk[256 + q];
 }
 
+// ---- conv policy heads in the split launch: the shapes of the exact-f32 launch's fused heads at 128 / 256 channels ----
+bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs) {
+    if (channels != 128 && channels != 256) return false;
+    const int nt = split_tiles_for(h * w, channels, true);
+    return nt != 0 && nt * 16 / (h * w) == tower32_boards_per_workgroup(h, w, channels) &&
+           tower32_heads_supported(policy_kind, extra_moves, pc, h, w, channels, hc, hs);
+}
+
+size_t tower_split_conv_heads_weight_elems(int channels) { return (size_t)(channels / 32) * 2 * channels * 32; }  // one pass
+
+// The policy head's first 1x1 convolution [C out][C in] as one pass of C/32 k-steps in the tower layers' (hi, lo) fragment
+// order (lane group kq takes channels 8 chunk + {0, C/2, C/4, 3C/4}[kq] + j)
+void tower_split_pack_conv_heads(const float *w, int channels, uint16_t *dst) {
+    const int C = channels, ot_n = C / 64;
+    const size_t part = (size_t)C * 32;
+    for (int chunk = 0; chunk < C / 32; chunk++) {
+        uint16_t *step = dst + (size_t)chunk * 2 * part;
+        for (int wave = 0; wave < 4; wave++)
+            for (int ot = 0; ot < ot_n; ot++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int kq = lane >> 4;
+                        const int oc = 16 * (wave * ot_n + ot) + (lane & 15);
+                        const int ch = 8 * chunk + (C / 2) * (kq & 1) + (C / 4) * (kq >> 1) + j;
+                        const float v = w[(size_t)oc * C + ch];
+                        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                        uint16_t hb, lb;
+                        __builtin_memcpy(&hb, &hi, 2);
+                        __builtin_memcpy(&lb, &lo, 2);
+                        const size_t e = (((size_t)wave * ot_n + ot) * 64 + lane) * 8 + j;
+                        step[e] = hb;
+                        step[part + e] = lb;
+                    }
+    }
+}
+
 void launch_tower_split(const Tower32Args &t, hipStream_t stream) { launch_tower_pairs(t, true, stream); }
 
 void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
@@ -1302,7 +1401,17 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         d.att_idx = hd.att_idx;
         d.scalars = hd.scalars; d.policy = hd.policy;
         d.nonfinite_flag = hd.nonfinite_flag; d.epoch = hd.epoch;
-        launch<256, 4, true, true>(d, grid, stream);
+        if (hd.small_w) {  // conv policy heads (tower_split_conv_heads_supported)
+            d.hc = hd.hc; d.hs = hd.hs; d.pc = hd.pc; d.policy_len = hd.policy_len; d.zero_tail = hd.zero_tail; d.extra = hd.extra;
+            d.sh_w1t = hd.sh_w1t; d.p_b1 = hd.p_b1; d.pe_bc = hd.pe_bc; d.pe_wl = hd.pe_wl; d.pe_bl = hd.pe_bl;
+            d.small_w = reinterpret_cast<const f32x4 *>(hd.small_w);
+            if (t.channels == 256) launch<256, 4, true, 2>(d, grid, stream);
+            else if (nt == 7) launch<128, 7, true, 2>(d, grid, stream);
+            else if (nt == 6) launch<128, 6, true, 2>(d, grid, stream);
+            else launch<128, 4, true, 2>(d, grid, stream);
+            return;
+        }
+        launch<256, 4, true, 1>(d, grid, stream);
         return;
     }
     if (split) {

@@ -815,7 +815,9 @@ def test_one_launch_f32_network_decode_and_range_check(dev):
     ("chess", 3, 256, "attention", (5, 17)),
     ("ataxx-7", 8, 128, "ataxx_conv", (1, 2, 13)),    # BASELINE configs[1]'s network: two boards per workgroup, ragged
     ("chess", 2, 128, "attention", (3,)),             # 128 channels on an 8x8 board
-    ("go-9", 2, 128, "conv", (3,)),                   # 81 pixels: six tiles
+    ("go-9", 2, 128, "conv", (3,)),                   # 81 pixels: six tiles; conv head with the extra (pass) move
+    ("go-9", 3, 128, "conv", (1, 4)),
+    ("ataxx-5", 2, 128, "ataxx_conv", (7,)),          # 25 pixels: four boards per workgroup
     ("ataxx-7", 4, 64, "ataxx_conv", (5,)),           # BASELINE configs[0]'s network (64 channels)
     ("chess", 2, 32, "dense", (4,)),                  # not a shape of the kernel
 ])
@@ -831,8 +833,10 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     net = O.OracleNet(blob)
     model = capi.Model(blob=blob)
     eng = capi.Engine(model, dev, 32, capi.KZ_DTYPE_F32_SPLIT16)
-    # the chess attention network at 256 channels is ONE launch (tower + scalar head + attention head in split arithmetic)
-    fused = game == "chess" and channels == 256 and head == "attention"
+    # ONE launch (tower + scalar head + policy head): the chess attention network at 256 channels in split arithmetic, and
+    # since round 3 the conv-policy networks at 128 / 256 channels (the policy head's hidden layer as one more pass of the
+    # split stream, then the exact-f32 launch's tail on f32 copies of the images)
+    fused = (game == "chess" and channels == 256 and head == "attention") or (head in ("ataxx_conv", "conv") and channels >= 128)
     assert eng.tower_path == ("tower_resident_split16+heads" if fused else "tower_resident_split16")
     unfused = None
     if fused:  # the same tower launch followed by the separate f32 head kernels
