@@ -50,7 +50,8 @@ WORKLOADS = {
                         label="Go 19x19 40x256 ResNet b=512"),
 }
 # the other single-GPU BASELINE configs, reported as sub-records of the default line
-OTHERS = [("ataxx-8x128", "f32"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"), ("go19-40x256", "f32split16")]
+OTHERS = [("ataxx-8x128", "f32"), ("ataxx-8x128", "f32split16"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"),
+          ("go19-40x256", "f32split16")]
 
 KERNEL_OF_PATH = {
     "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",

@@ -98,6 +98,7 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
     const float b1v = tid < a.nb * a.hs ? a.sh_b1[tid % a.hs] : 0.0f;
     const float b2v = tid < boards * 5 ? a.sh_b2[tid % 5] : 0.0f;
     for (int i = tid; i < 5 * a.hs; i += 256) sw2[i] = a.sh_w2[i];
+    KZ_HEADS_STAMP(56);
     // scalar head Conv1x1 C->hc + ReLU and the extra moves' Conv1x1 C->1 (post_act.py:8-31, :86-96): one small conv over x
     bool bad = false;  // a non-finite sum = a non-finite value somewhere in this board's tower output
     small_conv(xin, a.small_w, [&](int mt, int q, int row, float v) {
@@ -110,6 +111,7 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
             sext[row] = v + sb[mt][q];
         }
     });
+    KZ_HEADS_STAMP(57);
     if (bad && a.nonfinite_flag) *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may live in pinned host memory)
     // policy (post_act.py:75-110): Conv1x1 C->pc on the hidden layer, channel-major flatten
     small_conv(hin, a.small_w + G * 2 * 64, [&](int mt, int q, int row, float v) {
@@ -148,6 +150,7 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
                 if (bb < a.nb) sred[(seg * a.nb + bb) * a.hs + j] = part[bb];
         }
     }
+    KZ_HEADS_STAMP(58);
     if (a.extra) {  // Linear(hw -> extra) behind the policy planes
         for (int o = tid >> 2; o < boards * a.extra; o += 64) {
             const int bb = o / a.extra, j = o - bb * a.extra, seg = tid & 3;
@@ -168,6 +171,7 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
         shid[o] = fmaxf(s, 0.0f);
     }
     __syncthreads();
+    KZ_HEADS_STAMP(59);
     if (tid < boards * 5) {
         const int bb = tid / 5, j = tid - bb * 5;
         float s = b2v;

@@ -25,6 +25,13 @@ print("epilogues          ", [round(x) for x in epi])
 print("barrier waits      ", [round(x) for x in bar])
 print("sum loops", sum(loop), "epilogues", sum(epi), "barriers", sum(bar))
 if a[:, 60].max() > 0:
+    if a[:, 56].max() > 0:  # finer stamps of kz_conv_heads.hpp
+        print("tail: preloads issued            ", med(a[:, 56] - prev))
+        print("tail: small conv over x (scalar) ", med(a[:, 57] - a[:, 56]))
+        print("tail: small conv over hidden     ", med(a[:, 60] - a[:, 57]))
+        print("tail: barrier + Linear partials  ", med(a[:, 58] - a[:, 60]))
+        print("tail: extra moves, barrier, hidden, barrier", med(a[:, 59] - a[:, 58]))
+        print("tail: last Linear                ", med(a[:, 61] - a[:, 59]))
     print("tail: small convs  ", med(a[:, 60] - prev))
     print("tail: rest         ", med(a[:, 61] - a[:, 60]))
 print("whole (median wave)", med(a[:, 62] - a[:, 0]), " launch span", a[:, 62].max() - t0)
