@@ -297,6 +297,22 @@ def test_config_a1_ataxx_8x128_f32_batch256(dev):
     s16, p16 = eng16.eval_packed(bits, scalars_in)
     assert_f16(s16, s_ref, "f16 scalars")
     assert_f16(p16, p_ref, "f16 policy")
+    # and through the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity): ONE launch per batch since round 3 —
+    # the same 1e-4, on every entry point (the asynchronous pair writes straight into the slot's pinned staging)
+    split = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F32_SPLIT16)
+    assert split.tower_path == "tower_resident_split16+heads" and split.launch_geometry(256) == (128, 2)
+    ss, sp = split.eval_packed(bits, scalars_in)
+    assert_f32(ss, s_ref, "split16 scalars")
+    assert_f32(sp, p_ref, "split16 policy")
+    n = split.submit_packed(0, bits[:77], scalars_in[:77])  # ragged last workgroup
+    sv, pv = split.wait_view(0, n)
+    assert np.array_equal(sv, ss[:77]) and np.array_equal(pv, sp[:77])
+    d_s, d_p = capi.DeviceBuffer(dev, 256 * 5 * 4), capi.DeviceBuffer(dev, 256 * net.policy_len * 4)
+    split.enqueue_packed_device(capi.DeviceBuffer.from_host(dev, bits), bits.shape[1],
+                                capi.DeviceBuffer.from_host(dev, scalars_in), 256, d_s, d_p)
+    split.synchronize()
+    assert np.array_equal(d_s.to_host(np.float32, (256, 5)), ss)
+    assert np.array_equal(d_p.to_host(np.float32, (256, net.policy_len)), sp)
 
 
 @pytest.fixture(scope="module")
