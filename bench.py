@@ -57,7 +57,8 @@ KERNEL_OF_PATH = {
     "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
     "tower_resident_f32": "kz_tower_resident_f32", "tower_resident_f32+heads": "kz_tower_resident_f32",
     "tower_resident_split16": "kz_tower_resident_split", "tower_resident_split16+heads": "kz_tower_resident_split",
-    "tower_resident_f16g": "kz_tower_resident_f16g", "board_conv_f16": "kz_board_conv_f16",
+    "tower_resident_f16g": "kz_tower_resident_f16g", "tower_resident_f16g+heads": "kz_tower_resident_f16g",
+    "board_conv_f16": "kz_board_conv_f16",
     "board_conv_split16": "kz_board_conv_split16",
     "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32",
 }

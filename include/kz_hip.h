@@ -184,6 +184,7 @@ int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_m
  *
  * Name of the path the engine chose.  One launch for the whole tower: "tower_resident_f16+heads" (chess attention
  * network, heads included), "tower_resident_f16", "tower_resident_f16g" (other board-resident f16 shapes),
+ * "tower_resident_f16g+heads" (the same with the conv policy head and the scalar head inside: 128 / 256 channels),
  * "tower_resident_f32+heads" (exact f32, conv policy heads: decode, tower and heads in one launch), "tower_resident_f32"
  * (exact f32, other heads), "tower_resident_split16+heads" (KZ_DTYPE_F32_SPLIT16: the chess attention network at 256
  * channels and the conv-policy networks at 128 / 256 channels: encode, tower, scalar head and policy head in one launch),

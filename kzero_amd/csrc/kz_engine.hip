@@ -74,7 +74,8 @@ struct DeviceWeights {
 
     // resident tower
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
-    bool fused_split = false;  // the split launch carries the attention heads (set before build)
+    bool fused_split = false;  // the split launch carries the heads (set before build)
+    bool fused_pairs = false;  // the plain-f16 generic launch carries the conv policy heads (set before build)
     float *h32_small = nullptr;  // the fused f32 heads' small 1x1 convolutions (tower32_pack_small_weights)
     void *res32_w = nullptr;  // f32 resident launch (exact f32, or split f16 pairs): one packed weight stream
     void *res_w_stem = nullptr, *res_w_tower = nullptr;
@@ -241,11 +242,11 @@ struct DeviceWeights {
         if ((split16 && !use_board_split) || pairs16) {
             // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 stem k-steps, then 9*C/32 per convolution
             // (+ the attention heads' five passes and bias rows when the split launch carries the heads)
-            const bool conv_heads = split16 && fused_split && m.policy_kind != kz::POLICY_ATTENTION;  // (Ataxx, Go 9x9)
+            const bool conv_heads = (split16 && fused_split && m.policy_kind != kz::POLICY_ATTENTION) || (pairs16 && fused_pairs);  // (Ataxx, Go 9x9)
             const bool heads = split16 && fused_split && !conv_heads;
             const size_t tower_elems = kz::tower_split_weight_elems(C, m.depth, split16);
             std::vector<uint16_t> packed(tower_elems + (heads ? kz::tower_split_heads_weight_elems() : 0) +
-                                         (conv_heads ? kz::tower_split_conv_heads_weight_elems(C) : 0));
+                                         (conv_heads ? kz::tower_split_conv_heads_weight_elems(C, split16) : 0));
             const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = 9 * step_elems,
                          layer_elems = (size_t)9 * (C / 32) * step_elems;
             kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, hw, true, split16, packed.data());
@@ -256,7 +257,7 @@ struct DeviceWeights {
             for (int l = 0; l < 1 + 2 * m.depth; l++)
                 for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
             if (conv_heads) {  // the policy head's hidden layer as one more pass; the small convolutions as for the f32 launch
-                kz::tower_split_pack_conv_heads(m.p_conv0.w.data(), C, packed.data() + tower_elems);
+                kz::tower_split_pack_conv_heads(m.p_conv0.w.data(), C, split16, packed.data() + tower_elems);
                 for (int o = 0; o < C; o++) bias[(size_t)(1 + 2 * m.depth) * C + o] = m.p_conv0.b[o];
                 std::vector<float> small(kz::tower32_small_weight_elems(C));
                 kz::tower32_pack_small_weights(m.sh_conv.w.data(), m.sh_conv.cout,
@@ -480,7 +481,8 @@ struct kz_engine {
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
     bool bsplit = false;  // split16 per layer through kz_board_conv_split16 (Go-size boards)
     bool fused32 = false;  // the exact-f32 resident launch with the conv policy head and the scalar head inside
-    bool fused_split = false;  // the split-f16 launch with the scalar head and the attention policy head inside
+    bool fused_split = false;  // the split-f16 launch with the scalar head and the policy head inside
+    bool fused_pairs = false;  // the plain-f16 generic launch with the conv policy head and the scalar head inside
     bool nb4 = false;        // resident chess tower with four boards per workgroup (KZ_TOWER_NB=4)
     void *xres = nullptr;    // its residual scratch
     std::string path;
@@ -765,7 +767,7 @@ struct kz_engine {
                 hd.scalars = d_scalars; hd.policy = d_policy;
                 hd.nonfinite_flag = nf_flag; hd.epoch = nf_epoch;
             }
-            if (fused32 || (fused_split && m.policy_kind != kz::POLICY_ATTENTION)) {  // conv policy heads: the f32 tail
+            if (fused32 || fused_pairs || (fused_split && m.policy_kind != kz::POLICY_ATTENTION)) {  // conv policy heads: the f32 tail
                 kz::Tower32Args::Heads &hd = t.heads;
                 hd.on = true;
                 hd.hc = m.sh_conv.cout; hd.hs = m.sh_fc0.out;
@@ -837,7 +839,7 @@ struct kz_engine {
     }
 
     int run_heads(int batch, float *d_scalars, float *d_policy) {
-        if (fused_heads || fused32 || fused_split) return 0;  // written by the tower launch
+        if (fused_heads || fused32 || fused_split || fused_pairs) return 0;  // written by the tower launch
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         const void *x = act[tower_out];
@@ -1132,6 +1134,9 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                  !(nopairs && nopairs[0] == '1') && e->cin_p == 32 &&
                  kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
     const bool board_conv = board_conv_ok && !e->pairs16 && !e->bsplit;
+    e->fused_pairs = e->pairs16 && !(nofuse && nofuse[0] == '1') &&
+                     kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h,
+                                                          m.w, m.channels, m.sh_conv.cout, m.sh_fc0.out, false);
     e->fused32 = e->resident32 && !e->split16 && !(nofuse && nofuse[0] == '1') &&
                  kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
                                              m.channels, m.sh_conv.cout, m.sh_fc0.out);
@@ -1139,7 +1144,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                      (kz::tower_split_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.h, m.w,
                                                       m.channels, m.sh_conv.cout, m.sh_fc0.out) ||
                       kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h,
-                                                           m.w, m.channels, m.sh_conv.cout, m.sh_fc0.out));
+                                                           m.w, m.channels, m.sh_conv.cout, m.sh_fc0.out, true));
     e->path = e->fused_heads ? "tower_resident_f16+heads"
               : e->resident  ? "tower_resident_f16"
               : e->bsplit    ? "board_conv_split16"
@@ -1147,6 +1152,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
               : e->split16   ? "tower_resident_split16"
               : e->fused32   ? "tower_resident_f32+heads"
               : e->resident32 ? "tower_resident_f32"
+              : e->fused_pairs ? "tower_resident_f16g+heads"
               : e->pairs16   ? "tower_resident_f16g"
               : board_conv   ? "board_conv_f16"
                              : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
@@ -1160,7 +1166,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 #endif
         auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + variant,
                                    e->resident || e->resident32,
-                                   e->fused_heads || e->fused_split, board_conv);
+                                   e->fused_heads || e->fused_split || e->fused_pairs, board_conv);
         auto it = g_cache.find(key);
         if (it != g_cache.end()) e->wts = it->second.lock();
         if (!e->wts) {
@@ -1170,6 +1176,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->use_board_conv = board_conv;
             w->use_board_split = e->bsplit;
             w->fused_split = e->fused_split;
+            w->fused_pairs = e->fused_pairs;
             if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16, e->pairs16)) return 1;
             g_cache[key] = w;
             e->wts = w;
@@ -1179,12 +1186,12 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 #ifdef KZ_EXPERIMENTS
     {
         const char *hg = getenv("KZ_HIP_GRAPH");
-        e->use_graph = hg && hg[0] == '1' && !e->fused_heads && !e->fused32 && !e->fused_split;
+        e->use_graph = hg && hg[0] == '1' && !e->fused_heads && !e->fused32 && !e->fused_split && !e->fused_pairs;
     }
 #endif
     HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[0], hipStreamNonBlocking));
     e->stream = e->slot_stream[0];
-    if (e->fused_heads || e->fused32 || e->fused_split) {  // one launch per batch that touches nothing but its slot's buffers
+    if (e->fused_heads || e->fused32 || e->fused_split || e->fused_pairs) {  // one launch per batch that touches nothing but its slot's buffers
         HIP_TRY(hipStreamCreateWithFlags(&e->slot_stream[1], hipStreamNonBlocking));
         for (int i = 2; i < KZ_ENGINE_SLOTS; i++) e->slot_stream[i] = e->slot_stream[i & 1];
         e->zero_copy = true;
@@ -1636,7 +1643,7 @@ KZ_API int kz_engine_read_activation(kz_engine *e, const char *name, int batch, 
     if (!e || !name || !out_nchw) return fail("kz_engine_read_activation: null argument");
     // "tower.out": the tower output of the last evaluation, on every path that materialises it (all but the fused-heads
     // launch)
-    const bool tower_out = std::string(name) == "tower.out" && !e->fused_heads && !e->fused32 && !e->fused_split;
+    const bool tower_out = std::string(name) == "tower.out" && !e->fused_heads && !e->fused32 && !e->fused_split && !e->fused_pairs;
     if (!e->keep && !tower_out)
         return fail("kz_engine_read_activation: engine keeps no activations (create it with KZ_FORCE_GENERIC=1 and "
                     "KZ_KEEP_ACTIVATIONS=1; \"tower.out\" is available on every path without fused heads)");

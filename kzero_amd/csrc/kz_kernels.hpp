@@ -224,9 +224,11 @@ void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const floa
 // ... and for the conv policy heads (Ataxx, Go 9x9) at 128 / 256 channels: the policy head's Conv1x1 C->C rides behind the
 // tower as one more pass (its bias as one more bias row), the rest is the exact-f32 launch's tail (Tower32Args::Heads with
 // small_w set, as for launch_tower32) on f32 copies of the LDS images
-bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs);
-size_t tower_split_conv_heads_weight_elems(int channels);
-void tower_split_pack_conv_heads(const float *w /* [C][C] */, int channels, uint16_t *dst);
+// (split = false: the same in the plain-f16 launch, launch_tower_pairs(t, false): "tower_resident_f16g+heads")
+bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs,
+                                      bool split);
+size_t tower_split_conv_heads_weight_elems(int channels, bool split);
+void tower_split_pack_conv_heads(const float *w /* [C][C] */, int channels, bool split, uint16_t *dst);
 // the same launch without the lo halves (split = false): plain f16 arithmetic, x0 and y are f16 tensors behind the
 // float pointers of Tower32Args — the board-resident f16 tower for the shapes kz_tower.hip does not take
 void launch_tower_pairs(const Tower32Args &a, bool split, hipStream_t stream);

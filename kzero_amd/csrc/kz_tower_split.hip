@@ -101,7 +101,7 @@ __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {
 template <int C, int NT, bool SPLIT, int HEADS = 0>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     static_assert(HEADS != 1 || (C == 256 && NT == 4 && SPLIT), "attention heads: the chess network in split arithmetic");
-    static_assert(HEADS != 2 || (SPLIT && (C == 256 || C == 128)), "conv heads: split arithmetic, a shape of kz_tower_f32.hip");
+    static_assert(HEADS != 2 || C == 256 || C == 128, "conv heads: a channel count of kz_tower_f32.hip");
     using L = Geo<C, NT, SPLIT>;
     constexpr int PARTS = L::PARTS, PF = L::PF;
     constexpr int RS = L::RS, OT = L::OT, G = L::G, DELTA = L::DELTA, XH = L::XH, YH = L::YH, ZH = L::ZH;
@@ -398,10 +398,14 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                     }
                     v = v * ps + pt;
                     if constexpr (HEADS != 0) {  // the heads read the tower output from X (in place: this lane owns the slot)
-                        h16x4 hi, lo;
-                        split4(v, hi, lo);
-                        *reinterpret_cast<h16x4 *>(lds + XH + off) = hi;
-                        *reinterpret_cast<h16x4 *>(lds + XH + DELTA + off) = lo;
+                        if constexpr (SPLIT) {
+                            h16x4 hi, lo;
+                            split4(v, hi, lo);
+                            *reinterpret_cast<h16x4 *>(lds + XH + off) = hi;
+                            *reinterpret_cast<h16x4 *>(lds + XH + DELTA + off) = lo;
+                        } else {
+                            *reinterpret_cast<h16x4 *>(lds + XH + off) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                        }
                         continue;
                     }
                     const int r = nt * 16 + fr;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             for (int nt = 0; nt < NT; nt++) {
                 const int t = XH + frag_base + nt * 16 * RS + ch * 16;
                 bh[nt] = *reinterpret_cast<const h16x8 *>(lds + t);
-                bl[nt] = *reinterpret_cast<const h16x8 *>(lds + t + DELTA);
+                if constexpr (SPLIT) bl[nt] = *reinterpret_cast<const h16x8 *>(lds + t + DELTA);
             }
             ring_take(ch & (PF - 1), ah, al);
             mfma3(ah, al, bh, bl);
@@ -436,10 +440,10 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         }
         epilogue(YH, true, false);
         __syncthreads();
-        // Both images, (hi, lo) -> f32 rows in the layout of kz_tower_f32.hip ([16 scratch rows][X][Y], row stride 4 C + 16),
+        // Both images, (hi, lo) — or plain f16 — -> f32 rows in the layout of kz_tower_f32.hip ([16 scratch rows][X][Y], row stride 4 C + 16),
         // through registers (everything else in LDS is dead); then the exact-f32 launch's own tail.
         constexpr int RS32 = C * 4 + 16, X32 = 16 * RS32, Y32 = X32 + L::ROWS * RS32;
-        static_assert(Y32 + L::ROWS * RS32 <= L::LDS_BYTES, "the f32 images fit the launch's LDS");
+        static_assert(Y32 + L::ROWS * RS32 <= 160 * 1024, "the f32 images fit a CU's LDS (the launcher asks for them)");
         constexpr int PIECES = L::ROWS * (C / 4), PER = (PIECES + 255) / 256;
         f32x4 vx[PER], vy[PER];
 #pragma unroll
@@ -447,12 +451,19 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             const int id = tid + k * 256;
             if (id < PIECES) {
                 const int r = id / (C / 4), p4 = id - r * (C / 4), off = r * RS + p4 * 8;
-                const h16x4 xh = *reinterpret_cast<const h16x4 *>(lds + XH + off), xl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off);
-                const h16x4 yh = *reinterpret_cast<const h16x4 *>(lds + YH + off), yl = *reinterpret_cast<const h16x4 *>(lds + YH + DELTA + off);
+                const h16x4 xh = *reinterpret_cast<const h16x4 *>(lds + XH + off), yh = *reinterpret_cast<const h16x4 *>(lds + YH + off);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    vx[k][j] = (float)xh[j] + (float)xl[j];
-                    vy[k][j] = (float)yh[j] + (float)yl[j];
+                    vx[k][j] = (float)xh[j];
+                    vy[k][j] = (float)yh[j];
+                }
+                if constexpr (SPLIT) {
+                    const h16x4 xl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off), yl = *reinterpret_cast<const h16x4 *>(lds + YH + DELTA + off);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        vx[k][j] += (float)xl[j];
+                        vy[k][j] += (float)yl[j];
+                    }
                 }
             }
         }
@@ -1030,12 +1041,15 @@ void launch(const SplitDev &d, int grid, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    // (the conv heads' tail wants the two images as f32 rows: more than the plain-f16 launch's own LDS)
+    constexpr int F32_IMAGES = (16 + 2 * NT * 16) * (C * 4 + 16);
+    constexpr int LDS = HEADS == 2 && F32_IMAGES > Geo<C, NT, SPLIT>::LDS_BYTES ? F32_IMAGES : Geo<C, NT, SPLIT>::LDS_BYTES;
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT, SPLIT, HEADS>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Geo<C, NT, SPLIT>::LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         done_mask |= 1ull << (dev & 63);
     }
-    kz_tower_resident_split<C, NT, SPLIT, HEADS><<<grid, 256, Geo<C, NT, SPLIT>::LDS_BYTES, stream>>>(d);
+    kz_tower_resident_split<C, NT, SPLIT, HEADS><<<grid, 256, LDS, stream>>>(d);
 }
 
 
@@ -1333,22 +1347,23 @@ void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const floa
 }
 
 // ---- conv policy heads in the split launch: the shapes of the exact-f32 launch's fused heads at 128 / 256 channels ----
-bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs) {
+bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs,
+                                      bool split) {
     if (channels != 128 && channels != 256) return false;
-    const int nt = split_tiles_for(h * w, channels, true);
+    const int nt = split_tiles_for(h * w, channels, split);
     return nt != 0 && nt * 16 / (h * w) == tower32_boards_per_workgroup(h, w, channels) &&
            tower32_heads_supported(policy_kind, extra_moves, pc, h, w, channels, hc, hs);
 }
 
-size_t tower_split_conv_heads_weight_elems(int channels) { return (size_t)(channels / 32) * 2 * channels * 32; }  // one pass
+size_t tower_split_conv_heads_weight_elems(int channels, bool split) { return (size_t)(channels / 32) * (split ? 2 : 1) * channels * 32; }  // one pass
 
 // The policy head's first 1x1 convolution [C out][C in] as one pass of C/32 k-steps in the tower layers' (hi, lo) fragment
 // order (lane group kq takes channels 8 chunk + {0, C/2, C/4, 3C/4}[kq] + j)
-void tower_split_pack_conv_heads(const float *w, int channels, uint16_t *dst) {
+void tower_split_pack_conv_heads(const float *w, int channels, bool split, uint16_t *dst) {
     const int C = channels, ot_n = C / 64;
     const size_t part = (size_t)C * 32;
     for (int chunk = 0; chunk < C / 32; chunk++) {
-        uint16_t *step = dst + (size_t)chunk * 2 * part;
+        uint16_t *step = dst + (size_t)chunk * (split ? 2 : 1) * part;
         for (int wave = 0; wave < 4; wave++)
             for (int ot = 0; ot < ot_n; ot++)
                 for (int lane = 0; lane < 64; lane++)
@@ -1363,7 +1378,7 @@ void tower_split_pack_conv_heads(const float *w, int channels, uint16_t *dst) {
                         __builtin_memcpy(&lb, &lo, 2);
                         const size_t e = (((size_t)wave * ot_n + ot) * 64 + lane) * 8 + j;
                         step[e] = hb;
-                        step[part + e] = lb;
+                        if (split) step[part + e] = lb;
                     }
     }
 }
@@ -1395,7 +1410,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
     const int grid = (t.batch + d.nb - 1) / d.nb;
-    if (split && t.heads.on) {  // (the engine asked tower_split_heads_supported)
+    if (t.heads.on && (split || t.heads.small_w)) {  // (the engine asked tower_split_[conv_]heads_supported)
         const Tower32Args::Heads &hd = t.heads;
         d.sh_w0 = hd.sh_w0; d.sh_b0 = hd.sh_b0; d.sh_w1 = hd.sh_w1; d.sh_b1 = hd.sh_b1; d.sh_w2 = hd.sh_w2; d.sh_b2 = hd.sh_b2;
         d.att_idx = hd.att_idx;
@@ -1405,10 +1420,17 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
             d.hc = hd.hc; d.hs = hd.hs; d.pc = hd.pc; d.policy_len = hd.policy_len; d.zero_tail = hd.zero_tail; d.extra = hd.extra;
             d.sh_w1t = hd.sh_w1t; d.p_b1 = hd.p_b1; d.pe_bc = hd.pe_bc; d.pe_wl = hd.pe_wl; d.pe_bl = hd.pe_bl;
             d.small_w = reinterpret_cast<const f32x4 *>(hd.small_w);
-            if (t.channels == 256) launch<256, 4, true, 2>(d, grid, stream);
-            else if (nt == 7) launch<128, 7, true, 2>(d, grid, stream);
-            else if (nt == 6) launch<128, 6, true, 2>(d, grid, stream);
-            else launch<128, 4, true, 2>(d, grid, stream);
+            if (split) {
+                if (t.channels == 256) launch<256, 4, true, 2>(d, grid, stream);
+                else if (nt == 7) launch<128, 7, true, 2>(d, grid, stream);
+                else if (nt == 6) launch<128, 6, true, 2>(d, grid, stream);
+                else launch<128, 4, true, 2>(d, grid, stream);
+            } else {  // the plain-f16 launch ("tower_resident_f16g+heads")
+                if (t.channels == 256) launch<256, 4, false, 2>(d, grid, stream);
+                else if (nt == 7) launch<128, 7, false, 2>(d, grid, stream);
+                else if (nt == 6) launch<128, 6, false, 2>(d, grid, stream);
+                else launch<128, 4, false, 2>(d, grid, stream);
+            }
             return;
         }
         launch<256, 4, true, 1>(d, grid, stream);
