@@ -663,6 +663,25 @@ def test_board_conv_split16_vs_oracle(dev, game, depth, channels, batch):
     assert np.array_equal(s1, s[:1]) and np.array_equal(p1, p[:1]), "result depends on the batch size"
 
 
+def test_board_conv_split16_trained_like_scale(dev):
+    """The split board-tile path on a residual stream that grows like a trained tower's (every block's second BatchNorm
+    weight x 6, eight blocks: the stream grows by orders of magnitude, the logits reach ~10 behind the final BatchNorm): 1e-4
+    RELATIVE to the output scale against the oracle, the range check silent."""
+    blob = synth.random_model("go-19", 8, 64, "conv", seed=61, block_gain=6.0)
+    bits, scalars_in = synth.random_boards("go-19", 4, seed=62)
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    scale_p, scale_s = max(1.0, float(np.abs(p_ref).max())), max(1.0, float(np.abs(s_ref).max()))
+    assert scale_p > 5.0, f"the fixture no longer stresses the range: logit scale {scale_p}"
+    eng = capi.Engine(capi.Model(blob=blob), dev, 8, capi.KZ_DTYPE_F32_SPLIT16)
+    assert eng.tower_path == "board_conv_split16"
+    s, p = eng.eval_packed(bits, scalars_in)  # (a non-finite activation would raise here)
+    rel_p, rel_s = float(np.abs(p - p_ref).max()) / scale_p, float(np.abs(s - s_ref).max()) / scale_s
+    print(f"go-19 8x64 gain 6: logit scale {scale_p:.0f}, split16 rel err policy {rel_p:.2e}, scalars {rel_s:.2e}")
+    assert rel_p <= 1e-4 and rel_s <= 1e-4
+
+
 def test_go19_40x256_split16_at_executor_batch_512(dev):
     """The G8 network at its executor batch in the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity):
     82 per-layer launches in split arithmetic.  All 512 boards: finite, deterministic, batch-size invariant; 1e-4
