@@ -578,7 +578,12 @@ def main():
     blob, bits, scalars_in = w.blob, w.bits, w.scalars_in
     w.close()
     if world == 1 and args.is_default_line and not args.no_others:
-        out["others"] = [sub_record(capi, synth, n, d, device, args.other_seconds, args.prewarm) for n, d in OTHERS]
+        out["others"] = []
+        for n, d in OTHERS:  # (a sub-record that fails says so in its place: it must not take the headline line with it)
+            try:
+                out["others"].append(sub_record(capi, synth, n, d, device, args.other_seconds, args.prewarm))
+            except Exception as ex:  # noqa: BLE001
+                out["others"].append({"workload": n, "dtype": d, "error": f"{type(ex).__name__}: {ex}"[:300]})
     if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
         out["seam"] = seam_record(blob, args.seam_seconds)
     if world > 1:

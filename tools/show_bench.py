@@ -7,5 +7,8 @@ print("value", r["value"], "chip_frac", r["roofline"]["chip_frac"], "launch_ms",
 if "pcie_inclusive" in r:
     h = r["pcie_inclusive"]; print("pcie_inclusive", h["value"], "of_resident", h["of_resident"], "engines", h.get("engines_per_gpu"))
 for o in r.get("others", []):
+    if "error" in o:
+        print(" ", o["workload"], o["dtype"], "ERROR", o["error"])
+        continue
     print(" ", o["workload"], o["dtype"], o["value"], "chip_frac", o["roofline"]["chip_frac"], "launch_ms", o["roofline"]["avg_launch_ms"], o["tower_path"])
 if "cpu_baseline" in r: print("cpu", r["cpu_baseline"]["value"], "cores", r["cpu_baseline"]["cores"])
