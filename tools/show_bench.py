@@ -11,4 +11,4 @@ for o in r.get("others", []):
         print(" ", o["workload"], o["dtype"], "ERROR", o["error"])
         continue
     print(" ", o["workload"], o["dtype"], o["value"], "chip_frac", o["roofline"]["chip_frac"], "launch_ms", o["roofline"]["avg_launch_ms"], o["tower_path"])
-if "cpu_baseline" in r: print("cpu", r["cpu_baseline"]["value"], "cores", r["cpu_baseline"]["cores"])
+if "cpu_baseline" in r: print("cpu", r["cpu_baseline"]["value"], "cores", r["cpu_baseline"]["cores"], r["cpu_baseline"].get("error", ""))
