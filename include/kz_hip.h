@@ -94,6 +94,16 @@ void kz_engine_destroy(kz_engine *engine);
  * see above), negative on a null/unknown argument.  Lets a host pick "the fastest path with <= 1e-4 parity":
  * KZ_DTYPE_F32_SPLIT16 where supported, else KZ_DTYPE_F32. */
 int kz_model_supports_dtype(const kz_model *model, int dtype);
+/* What kz_engine_create(model, any device, max_batch, dtype) WOULD choose, without touching a GPU: the tower path (the
+ * names kz_engine_tower_path documents) and the kernel launches one packed-input batch takes.  Pure host logic over the
+ * kernels' support predicates — DESIGN.md §5.0 prints its path table from it and a CPU test holds it to a committed
+ * copy.  Fails (non-zero, kz_last_error) exactly when kz_engine_create would refuse the dtype for this model. */
+typedef struct kz_path_plan {
+    char tower_path[48];
+    int32_t launches_per_batch;
+    int32_t reserved[3];
+} kz_path_plan;
+int kz_model_plan(const kz_model *model, int max_batch, int dtype, kz_path_plan *out);
 int kz_engine_max_batch(const kz_engine *engine); /* Network::max_batch_size, network/mod.rs:53 */
 
 /* ---- synchronous evaluation: replaces CudaNetwork::evaluate_batch's encode + executor.evaluate (cudnn.rs:55-82) ----

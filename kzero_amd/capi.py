@@ -23,6 +23,10 @@ class KzError(RuntimeError):
     pass
 
 
+class PathPlan(C.Structure):
+    _fields_ = [("tower_path", C.c_char * 48), ("launches_per_batch", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
 class ModelInfo(C.Structure):
     _fields_ = [
         ("input_channels", C.c_int32), ("board_h", C.c_int32), ("board_w", C.c_int32),
@@ -46,6 +50,7 @@ SIGNATURES = {
     "kz_engine_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kz_engine_destroy": (None, [C.c_void_p]),
     "kz_model_supports_dtype": (C.c_int, [C.c_void_p, C.c_int]),
+    "kz_model_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "kz_engine_max_batch": (C.c_int, [C.c_void_p]),
     "kz_engine_eval_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kz_engine_eval_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
@@ -129,6 +134,12 @@ class Model:
         info = ModelInfo()
         check(load().kz_model_get_info(self._h, C.byref(info)))
         self.info = info
+
+    def plan(self, max_batch: int, dtype: int):
+        """(tower path, launches per batch) kz_engine_create would choose — host logic, no GPU needed."""
+        out = PathPlan()
+        check(load().kz_model_plan(self._h, max_batch, dtype, C.byref(out)))
+        return out.tower_path.decode(), out.launches_per_batch
 
     def supports_dtype(self, dtype: int) -> bool:
         return load().kz_model_supports_dtype(self._h, dtype) == 1

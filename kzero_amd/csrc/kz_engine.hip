@@ -240,14 +240,14 @@ struct DeviceWeights {
         if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
 
         if ((split16 && !use_board_split) || pairs16) {
-            // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 stem k-steps, then 9*C/32 per convolution
+            // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 * ceil(c_in / 32) stem k-steps, then 9*C/32 per convolution
             // (+ the attention heads' five passes and bias rows when the split launch carries the heads)
             const bool conv_heads = (split16 && fused_split && m.policy_kind != kz::POLICY_ATTENTION) || (pairs16 && fused_pairs);  // (Ataxx, Go 9x9)
             const bool heads = split16 && fused_split && !conv_heads;
-            const size_t tower_elems = kz::tower_split_weight_elems(C, m.depth, split16);
+            const size_t tower_elems = kz::tower_split_weight_elems(C, m.depth, m.c_in, split16);
             std::vector<uint16_t> packed(tower_elems + (heads ? kz::tower_split_heads_weight_elems() : 0) +
                                          (conv_heads ? kz::tower_split_conv_heads_weight_elems(C, split16) : 0));
-            const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = 9 * step_elems,
+            const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = kz::tower_split_stem_elems(C, m.c_in, split16),
                          layer_elems = (size_t)9 * (C / 32) * step_elems;
             kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, hw, true, split16, packed.data());
             for (int l = 0; l < 2 * m.depth; l++)
@@ -453,16 +453,165 @@ struct Prof {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// Which kernels run a network: pure host logic over the kernels' support predicates (no HIP call), shared by
+// kz_engine_create and kz_model_plan — DESIGN.md §5.0 prints its table from it and tests/test_path_table.py holds it to
+// tests/golden/path_table.json without a GPU.
+//
+//   dtype f16:         8x8, 256 channels, <= 224 planes          -> tower_resident_f16 [+heads: attention head, Q = 256]
+//                      else a shape of kz_tower_split.hip        -> tower_resident_f16g [+heads: conv heads at 128 / 256]
+//                      else channels % 64 == 0, >= 160 workgroups -> board_conv_f16          (one launch per layer)
+//                      else                                       -> conv_igemm_f16          (one launch per layer)
+//   dtype f32:         128 / 256 channels on a small board        -> tower_resident_f32 [+heads: conv heads]
+//                      else                                       -> conv_igemm_f32
+//   dtype f32split16:  a shape of kz_tower_split.hip (split)      -> tower_resident_split16 [+heads]
+//                      else channels % 64 == 0                    -> board_conv_split16      (one launch per layer)
+//                      else                                       -> refused (kz_model_supports_dtype says 0)
+// ------------------------------------------------------------------------------------------------
+struct PathPlan {
+    bool resident = false, fused_heads = false, resident32 = false, split16 = false, bsplit = false, pairs16 = false;
+    bool fused32 = false, fused_split = false, fused_pairs = false, board_conv = false, keep = false;
+    std::string path;
+    int launches = 0;  // kernel launches per batch through the packed-input entry points
+};
+
+bool env_on(const char *name) {
+    const char *v = getenv(name);
+    return v && v[0] == '1';
+}
+
+// launches of run_heads for a network whose tower output is materialised (head convolutions with cout_p = round_up(cout, 32))
+int head_launches(const Model &m, int dtype, bool split16, int cp) {
+    int n = 1;  // kz_scalar_head
+    const bool f16_heads = split16 || dtype == KZ_DTYPE_F16;  // 1x1 head convolutions through kz_conv1x1_split where it fits
+    switch (m.policy_kind) {
+        case kz::POLICY_ATAXX_CONV:
+        case kz::POLICY_CONV: {
+            const int c0_in = round_up(m.p_conv0.cin, 32), c0_out = round_up(m.p_conv0.cout, 32);
+            const bool one = m.policy_kind == kz::POLICY_CONV && f16_heads && kz::conv1x1_split_supported(c0_in, c0_out) && cp >= c0_in &&
+                             kz::conv1x1_policy_epilogue_supported(c0_in, c0_out, m.p_conv0.cout, m.policy_conv_channels);
+            n += one ? 1 : 2;
+            if (m.policy_kind == kz::POLICY_CONV && m.policy_extra_moves) {
+                const bool in_scalar_head = m.sh_conv.cout == 4 && m.p_extra_conv.cout == 1 && m.p_extra_conv.cin == m.sh_conv.cin &&
+                                            kz::scalar_head_takes_extra(dtype == KZ_DTYPE_F32 || split16 ? 0 : 1, cp, m.sh_conv.cout);
+                n += in_scalar_head ? 0 : 1;
+            }
+            break;
+        }
+        case kz::POLICY_ATTENTION: n += 3; break;
+        case kz::POLICY_DENSE: n += (m.dense_hidden_channels ? 1 : 0) + (m.dense_hidden_size ? 2 : 1); break;
+    }
+    return n;
+}
+
+// dtype_in: KZ_DTYPE_F32 / KZ_DTYPE_F16 / KZ_DTYPE_F32_SPLIT16.  false + why: kz_engine_create refuses.
+bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::string &why) {
+    const bool split16 = dtype_in == KZ_DTYPE_F32_SPLIT16;
+    const int dtype = split16 ? KZ_DTYPE_F32 : dtype_in;  // KZ_DTYPE_F32_SPLIT16 is the f32 engine with one kernel exchanged
+    const int cp = round_up(m.channels, 32);
+    const bool force = env_on("KZ_FORCE_GENERIC"), nofuse = env_on("KZ_NO_FUSED_HEADS"), noboard = env_on("KZ_NO_BOARD_CONV");
+    p = PathPlan();
+    p.resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth, m.c_in) && !force;
+    p.fused_heads = p.resident && !nofuse &&
+                    kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout, m.sh_fc0.out);
+    // the board-tile kernel needs enough workgroups to fill the chip (two per CU when it is busy)
+    const bool board_conv_ok = !p.resident && !noboard && m.depth >= 1 &&
+                               kz::board_conv_supported(dtype, m.h, m.w, m.channels, m.channels) &&
+                               kz::board_conv_workgroups(max_batch, m.h, m.w, m.channels) >= 160 &&
+                               (size_t)max_batch * m.h * m.w * m.channels * 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
+    p.keep = env_on("KZ_KEEP_ACTIVATIONS") && !p.resident;
+    // exact-f32 resident launch (the per-layer activation taps of KZ_KEEP_ACTIVATIONS need the per-layer path)
+    p.resident32 = kz::tower32_supported(dtype, m.h, m.w, m.channels, m.depth) && !force && !p.keep;
+    // split arithmetic per layer for boards the resident split launch cannot hold (Go 19x19)
+    const bool split_resident = kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true);
+    const bool board_split_ok = split16 && !split_resident && m.depth >= 1 && !p.keep &&
+                                kz::board_conv_split_supported(m.h, m.w, m.channels, m.channels) && m.channels % 32 == 0 &&
+                                (size_t)max_batch * m.h * m.w * m.channels * 4 < ((size_t)1 << 31);
+    if (board_split_ok) {
+        p.split16 = p.bsplit = true;
+        p.resident32 = false;  // (a shape the exact-f32 launch takes too stays per layer here)
+    } else if (split16) {
+        if (!split_resident) {
+            why = "KZ_DTYPE_F32_SPLIT16 needs a shape of the one-launch split tower (256 tower channels on a board of at most 64 "
+                  "squares, 192 on at most 64, 64 / 128 channels on at most 96 squares, and no more input planes than tower "
+                  "channels); or, per layer, tower channels a multiple of 64, at least one block and max_batch * squares * "
+                  "channels * 4 bytes < 2 GiB";
+            return false;
+        }
+        p.split16 = p.resident32 = true;  // same tensors in and out as the exact-f32 resident launch
+    }
+    // plain-f16 board-resident tower for the shapes the chess launch (kz_tower.hip) does not take: the split kernel
+    // without its lo halves
+    p.pairs16 = dtype == KZ_DTYPE_F16 && !p.resident && !force && !p.keep && !env_on("KZ_NO_RESIDENT_F16G") &&
+                kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
+    p.board_conv = board_conv_ok && !p.pairs16 && !p.bsplit;
+    p.fused_pairs = p.pairs16 && !nofuse &&
+                    kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
+                                                         m.channels, m.sh_conv.cout, m.sh_fc0.out, false);
+    p.fused32 = p.resident32 && !p.split16 && !nofuse &&
+                kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w, m.channels,
+                                            m.sh_conv.cout, m.sh_fc0.out);
+    p.fused_split = p.split16 && !p.bsplit && !nofuse &&
+                    (kz::tower_split_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.h, m.w, m.channels,
+                                                     m.sh_conv.cout, m.sh_fc0.out) ||
+                     kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
+                                                          m.channels, m.sh_conv.cout, m.sh_fc0.out, true));
+    p.path = p.fused_heads   ? "tower_resident_f16+heads"
+             : p.resident    ? "tower_resident_f16"
+             : p.bsplit      ? "board_conv_split16"
+             : p.fused_split ? "tower_resident_split16+heads"
+             : p.split16     ? "tower_resident_split16"
+             : p.fused32     ? "tower_resident_f32+heads"
+             : p.resident32  ? "tower_resident_f32"
+             : p.fused_pairs ? "tower_resident_f16g+heads"
+             : p.pairs16     ? "tower_resident_f16g"
+             : p.board_conv  ? "board_conv_f16"
+                             : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
+    const bool fused = p.fused_heads || p.fused32 || p.fused_split || p.fused_pairs;
+    const bool one_launch_tower = p.resident || p.resident32 || p.pairs16;  // (board encode inside)
+    p.launches = fused ? 1
+                 : (one_launch_tower ? 1 : p.bsplit ? 3 + 2 * m.depth : 2 + 2 * m.depth) + head_launches(m, dtype, p.split16, cp);
+    return true;
+}
+
 }  // namespace
 
 struct kz_model {
     std::shared_ptr<Model> m;
+    // the tower widened to a multiple of 64 channels by zero filters (kz::pad_channels), built at first use; null when the
+    // channel count is one already
+    mutable std::mutex widened_mutex;
+    mutable std::shared_ptr<Model> widened;
+    mutable bool widened_tried = false;
+    explicit kz_model(std::shared_ptr<Model> model) : m(std::move(model)) {}
 };
+
+namespace {
+// The network the kernels of `dtype` run: the model itself, or — f16 / split arithmetic, a tower of 48, 96, 160 ...
+// channels — the same network widened to the next multiple of 64 channels: zero filters cost (Cpad / C)^2 of the
+// multiply-adds and buy the one-launch and board-tile kernels instead of the generic implicit GEMM (chess x 96 channels,
+// f16: 0.53M -> 1.0M evals/s; x 160: 0.24M -> 0.6M).  Exact f32 keeps its implicit GEMM (the f32 one-launch tower exists
+// for 128 / 256 channels only and the f32 matrix rate makes the zero work expensive).
+std::shared_ptr<Model> effective_model(const kz_model *model, int dtype_in) {
+    const Model &m = *model->m;
+    if (dtype_in == KZ_DTYPE_F32 || m.channels % 64 == 0 || m.channels > 512 || m.depth < 1 || env_on("KZ_FORCE_GENERIC") ||
+        env_on("KZ_KEEP_ACTIVATIONS"))
+        return model->m;
+    std::lock_guard<std::mutex> lock(model->widened_mutex);
+    if (!model->widened_tried) {
+        model->widened_tried = true;
+        model->widened.reset(kz::pad_channels(m, round_up(m.channels, 64)));
+    }
+    return model->widened ? model->widened : model->m;
+}
+}  // namespace
 
 struct kz_engine {
     std::shared_ptr<Model> model;
     std::shared_ptr<DeviceWeights> wts;
     int device = 0, dtype = 0, max_batch = 0;
+    int out_channels = 0;  // the network's own tower channels (model->channels may be widened: effective_model)
     size_t esz = 4;
     hipStream_t stream = nullptr;          // the stream the forward pass is currently enqueued on
     // [0] = the main stream.  On the fused path (one launch per batch, which touches nothing but its slot's buffers) slots
@@ -986,7 +1135,7 @@ KZ_API int kz_model_load_onnx_memory(const void *blob, size_t len, int input_sca
     std::string err;
     Model *m = kz::parse_onnx(blob, len, input_scalar_channels, err);
     if (!m) return fail("kz_model_load_onnx: " + err);
-    *out = new kz_model{std::shared_ptr<Model>(m)};
+    *out = new kz_model(std::shared_ptr<Model>(m));
     return 0;
 }
 
@@ -996,7 +1145,7 @@ KZ_API int kz_model_load_memory(const void *blob, size_t len, kz_model **out) {
     std::string err;
     Model *m = kz::parse_model(blob, len, err);
     if (!m) return fail("kz_model_load: " + err);
-    *out = new kz_model{std::shared_ptr<Model>(m)};
+    *out = new kz_model(std::shared_ptr<Model>(m));
     return 0;
 }
 
@@ -1078,84 +1227,48 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
                     " visible)");
     HIP_TRY(hipSetDevice(device));
 
-    const Model &m = *model->m;
     std::unique_ptr<kz_engine, void (*)(kz_engine *)> e(new kz_engine(), kz_engine_destroy);
-    e->model = model->m;
+    e->model = effective_model(model, split16 ? KZ_DTYPE_F32_SPLIT16 : dtype);
+    e->out_channels = model->m->channels;
+    const Model &m = *e->model;
     e->device = device;
     e->dtype = dtype;
     e->max_batch = max_batch;
     e->esz = dtype == KZ_DTYPE_F32 ? 4 : 2;
     e->cin_p = round_up(m.c_in, 32);
     e->cp = round_up(m.channels, 32);
-    const char *force = getenv("KZ_FORCE_GENERIC");
-    e->resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth) && e->cin_p == 32 &&
-                  !(force && force[0] == '1');
+    // which kernels run this network: plan_path (above) — the table of DESIGN.md §5.0 is printed from it
+    PathPlan plan;
+    {
+        std::string why;
+        if (!plan_path(m, max_batch, split16 ? KZ_DTYPE_F32_SPLIT16 : dtype, plan, why)) return fail("kz_engine_create: " + why);
+    }
+    e->resident = plan.resident;
+    e->fused_heads = plan.fused_heads;
+    e->keep = plan.keep;
+    e->resident32 = plan.resident32;
+    e->split16 = plan.split16;
+    e->bsplit = plan.bsplit;
+    e->pairs16 = plan.pairs16;
+    e->fused_pairs = plan.fused_pairs;
+    e->fused32 = plan.fused32;
+    e->fused_split = plan.fused_split;
+    e->path = plan.path;
+    const bool board_conv = plan.board_conv;
 #ifdef KZ_EXPERIMENTS
     const char *notower = getenv("KZ_NO_TOWER_F16");  // (chess f16 through the generic one-launch f16 tower)
-    if (notower && notower[0] == '1') e->resident = false;
-#endif
-    const char *nofuse = getenv("KZ_NO_FUSED_HEADS");
-    e->fused_heads = e->resident && !(nofuse && nofuse[0] == '1') &&
-                     kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout,
-                                               m.sh_fc0.out);
-#ifdef KZ_EXPERIMENTS
-    const char *nb_env = getenv("KZ_TOWER_NB");
-    e->nb4 = e->resident && nb_env && atoi(nb_env) == 4;
-    if (e->nb4) e->fused_heads = false;  // (the four-board launch has no fused heads yet)
-#endif
-    const char *noboard = getenv("KZ_NO_BOARD_CONV");
-    // the board-tile kernel needs enough workgroups to fill the chip (two per CU when it is busy)
-    const bool board_conv_ok = !e->resident && !(noboard && noboard[0] == '1') && m.depth >= 1 &&
-                            kz::board_conv_supported(dtype, m.h, m.w, m.channels, m.channels) &&
-                            kz::board_conv_workgroups(max_batch, m.h, m.w, m.channels) >= 160 &&
-                            (size_t)max_batch * m.h * m.w * m.channels * 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
-    const char *keep = getenv("KZ_KEEP_ACTIVATIONS");
-    e->keep = keep && keep[0] == '1' && !e->resident;
-    // exact-f32 resident launch (the per-layer activation taps of KZ_KEEP_ACTIVATIONS need the per-layer path)
-    e->resident32 = kz::tower32_supported(dtype, m.h, m.w, m.channels, m.depth) && m.c_in <= e->cin_p &&
-                    !(force && force[0] == '1') && !e->keep;
-    // split arithmetic per layer for boards the resident split launch cannot hold (Go 19x19)
-    const bool board_split_ok = split16 && !(kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) && e->cin_p == 32) &&
-                                m.depth >= 1 && !e->keep && kz::board_conv_split_supported(m.h, m.w, m.channels, m.channels) &&
-                                m.channels % 32 == 0 && (size_t)max_batch * m.h * m.w * m.channels * 4 < ((size_t)1 << 31);
-    if (board_split_ok) {
-        e->split16 = e->bsplit = true;
-    } else if (split16) {
-        if (!kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) || e->cin_p != 32)
-            return fail("kz_engine_create: KZ_DTYPE_F32_SPLIT16 needs 256 tower channels on a board of at most 64 squares or "
-                        "64 / 128 channels on at most 96 squares, and at most 32 input planes; or, per layer, tower channels a "
-                        "multiple of 64, at least one block and max_batch * squares * channels * 4 bytes < 2 GiB");
-        e->split16 = e->resident32 = true;  // same tensors in and out as the exact-f32 resident launch
+    if (notower && notower[0] == '1' && e->resident) {
+        e->resident = e->fused_heads = false;
+        e->pairs16 = kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
+        e->path = e->pairs16 ? "tower_resident_f16g" : "conv_igemm_f16";
     }
-    // plain-f16 board-resident tower for the shapes the chess launch (kz_tower.hip) does not take: the split kernel
-    // without its lo halves
-    const char *nopairs = getenv("KZ_NO_RESIDENT_F16G");
-    e->pairs16 = dtype == KZ_DTYPE_F16 && !e->resident && !(force && force[0] == '1') && !e->keep &&
-                 !(nopairs && nopairs[0] == '1') && e->cin_p == 32 &&
-                 kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
-    const bool board_conv = board_conv_ok && !e->pairs16 && !e->bsplit;
-    e->fused_pairs = e->pairs16 && !(nofuse && nofuse[0] == '1') &&
-                     kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h,
-                                                          m.w, m.channels, m.sh_conv.cout, m.sh_fc0.out, false);
-    e->fused32 = e->resident32 && !e->split16 && !(nofuse && nofuse[0] == '1') &&
-                 kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
-                                             m.channels, m.sh_conv.cout, m.sh_fc0.out);
-    e->fused_split = e->split16 && !e->bsplit && !(nofuse && nofuse[0] == '1') &&
-                     (kz::tower_split_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.h, m.w,
-                                                      m.channels, m.sh_conv.cout, m.sh_fc0.out) ||
-                      kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h,
-                                                           m.w, m.channels, m.sh_conv.cout, m.sh_fc0.out, true));
-    e->path = e->fused_heads ? "tower_resident_f16+heads"
-              : e->resident  ? "tower_resident_f16"
-              : e->bsplit    ? "board_conv_split16"
-              : e->fused_split ? "tower_resident_split16+heads"
-              : e->split16   ? "tower_resident_split16"
-              : e->fused32   ? "tower_resident_f32+heads"
-              : e->resident32 ? "tower_resident_f32"
-              : e->fused_pairs ? "tower_resident_f16g+heads"
-              : e->pairs16   ? "tower_resident_f16g"
-              : board_conv   ? "board_conv_f16"
-                             : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
+    const char *nb_env = getenv("KZ_TOWER_NB");
+    e->nb4 = e->resident && nb_env && atoi(nb_env) == 4 && e->cin_p == 32;
+    if (e->nb4) {  // (the four-board launch has no fused heads yet)
+        e->fused_heads = false;
+        e->path = "tower_resident_f16";
+    }
+#endif
 
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -1164,7 +1277,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         const char *c2 = getenv("KZ_BOARD_CONV2");  // (the opt-in board-conv organisation has its own weight packing)
         variant = c2 && c2[0] == '1' ? 400 : 0;
 #endif
-        auto key = std::make_tuple(model->m.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + variant,
+        auto key = std::make_tuple(e->model.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + variant,
                                    e->resident || e->resident32,
                                    e->fused_heads || e->fused_split || e->fused_pairs, board_conv);
         auto it = g_cache.find(key);
@@ -1251,14 +1364,25 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 
 KZ_API int kz_model_supports_dtype(const kz_model *model, int dtype) {
     if (!model) return -1;
-    const Model &m = *model->m;
-    if (dtype == KZ_DTYPE_F32 || dtype == KZ_DTYPE_F16) return 1;
-    if (dtype == KZ_DTYPE_F32_SPLIT16) {
-        if (kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true) && round_up(m.c_in, 32) == 32) return 1;
-        // larger boards: per layer (the engine additionally needs max_batch * h * w * channels * 4 bytes < 2 GiB)
-        return m.depth >= 1 && m.channels % 32 == 0 && kz::board_conv_split_supported(m.h, m.w, m.channels, m.channels) ? 1 : 0;
-    }
-    return -1;
+    if (dtype != KZ_DTYPE_F32 && dtype != KZ_DTYPE_F16 && dtype != KZ_DTYPE_F32_SPLIT16) return -1;
+    // (larger boards in split arithmetic run per layer: the engine additionally needs max_batch * h * w * channels * 4 bytes
+    // < 2 GiB, asked here for one board)
+    PathPlan plan;
+    std::string why;
+    return plan_path(*effective_model(model, dtype), 1, dtype, plan, why) ? 1 : 0;
+}
+
+KZ_API int kz_model_plan(const kz_model *model, int max_batch, int dtype, kz_path_plan *out) {
+    if (!model || !out) return fail("kz_model_plan: null argument");
+    if (max_batch <= 0) return fail("kz_model_plan: max_batch must be positive");
+    if (dtype != KZ_DTYPE_F32 && dtype != KZ_DTYPE_F16 && dtype != KZ_DTYPE_F32_SPLIT16) return fail("kz_model_plan: unknown dtype");
+    PathPlan plan;
+    std::string why;
+    if (!plan_path(*effective_model(model, dtype), max_batch, dtype, plan, why)) return fail("kz_model_plan: " + why);
+    memset(out, 0, sizeof *out);
+    snprintf(out->tower_path, sizeof out->tower_path, "%s", plan.path.c_str());
+    out->launches_per_batch = plan.launches;
+    return 0;
 }
 
 KZ_API int kz_engine_max_batch(const kz_engine *e) { return e ? e->max_batch : 0; }
@@ -1270,7 +1394,7 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     if ((batch < 0 || batch > e->max_batch ? fail("kz_engine_launch_geometry: batch out of range") : 0)) return 1;
     const Model &m = *e->model;
     int per = 0, wgs = 0;
-    if (e->resident) per = e->nb4 ? 4 : kz::tower_resident_boards_per_workgroup();
+    if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
     else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
     else if (e->resident32) per = kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
@@ -1653,7 +1777,7 @@ KZ_API int kz_engine_read_activation(kz_engine *e, const char *name, int batch, 
     const void *src_act = tower_out ? e->act[e->tower_out] : it->second;
     if (check_batch(e, batch, "kz_engine_read_activation")) return 1;
     const Model &m = *e->model;
-    const int hw = m.h * m.w, C = m.channels, cp = e->cp;
+    const int hw = m.h * m.w, C = e->out_channels, cp = e->cp;
     HIP_TRY(hipSetDevice(e->device));
     if (e->sync_all()) return 1;
     std::vector<uint8_t> raw((size_t)batch * hw * cp * e->esz);

@@ -196,6 +196,8 @@ struct Tower32Args {
 bool tower32_supported(int dtype, int h, int w, int channels, int depth);
 // conv / ataxx_conv policy head + a scalar head whose activations fit the launch's spare LDS
 bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs);
+// the same question for any launch that ends in kz_conv_heads.hpp with nt tiles of 16 pixel rows per workgroup
+bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs);
 size_t tower32_small_weight_elems(int channels);
 void tower32_pack_small_weights(const float *sh_w0, int hc, const float *pe_wc /* or null */, const float *p_w1, int pc,
                                 int channels, float *dst);
@@ -208,11 +210,13 @@ void tower32_pack_weights(const float *oihw, int cout, int cin, bool stem, float
 void launch_tower32(const Tower32Args &a, hipStream_t stream);
 
 // ---- the same tower with f32-equivalent results on the f16 matrix cores (kz_tower_split.hip): activations and weights
-// as (hi, lo) f16 pairs, three MFMAs per product.  Shapes of the exact-f32 launch with c_in <= 32; same Tower32Args
-// (f32 in/out), `weights` = tower_split_pack_weights stream: 9 stem k-steps, then 9*C/32 per tower convolution ----
+// as (hi, lo) f16 pairs, three MFMAs per product.  Shapes of the exact-f32 launch with c_in <= channels; same Tower32Args
+// (f32 in/out), `weights` = tower_split_pack_weights stream: 9 * ceil(c_in / 32) stem k-steps, then 9*C/32 per tower
+// convolution ----
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split);
 int tower_split_boards_per_workgroup(int h, int w, int channels, bool split);
-size_t tower_split_weight_elems(int channels, int depth, bool split = true);  // f16 elements
+size_t tower_split_stem_elems(int channels, int c_in, bool split);              // f16 elements of the 9 * ceil(c_in / 32) stem k-steps
+size_t tower_split_weight_elems(int channels, int depth, int c_in, bool split);  // f16 elements: stem + 2 * depth layers
 void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool stem, bool split, uint16_t *dst);
 void launch_tower_split(const Tower32Args &a, hipStream_t stream);
 // the chess attention network's heads inside that launch (a.heads.on; scalars and policy are then its only output)
@@ -256,10 +260,10 @@ void conv1x1_split_pack_weights(const float *w, int cout, int cin, int cout_p, i
 void launch_conv1x1_split(const Conv1x1SplitArgs &a, hipStream_t stream);
 
 // ---- board-resident tower (kz_tower.hip): the whole ResTower in ONE launch, activations never leave LDS ----
-// Requirements: f16, h*w <= 64, channels == 256 (cp), any depth >= 1.
+// Requirements: f16, 8x8, channels == 256 (cp), any depth >= 1, at most 224 input planes.
 struct TowerArgs {
     const void *x0;       // encoded input [batch*hw][cin_p] f16 (used when bits == nullptr)
-    int cin_p;            // 32
+    int cin_p;            // input planes padded to a multiple of 32 (<= 224)
     // fused board encode: packed boards straight into the launch (bits == nullptr: read x0 instead)
     const uint8_t *bits;
     size_t bits_stride;
@@ -279,7 +283,7 @@ struct TowerArgs {
     int *nonfinite_flag;  // fused heads only: see ScalarHeadArgs
     int epoch;
 };
-bool tower_resident_supported(int dtype, int h, int w, int channels, int depth);
+bool tower_resident_supported(int dtype, int h, int w, int channels, int depth, int c_in);
 int tower_resident_boards_per_workgroup();  // 2 (1 with KZ_TOWER_NB=1)
 bool tower_heads_supported(int policy_kind, int query_channels, int policy_len, int sh_channels, int sh_size);
 size_t tower_packed_weight_elems(int cin_p, int depth);

@@ -414,4 +414,67 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
     return m.release();
 }
 
+// ---- the same network with its tower widened to `cpad` channels by all-zero filters ----
+namespace {
+// [cout][cin][k][k] -> [cout_p][cin_p][k][k], new rows / columns zero (bias too)
+Conv widen(const Conv &c, int cout_p, int cin_p) {
+    Conv o;
+    o.cout = cout_p;
+    o.cin = cin_p;
+    o.k = c.k;
+    const int taps = c.k * c.k;
+    o.w.assign((size_t)cout_p * cin_p * taps, 0.0f);
+    o.b.assign((size_t)cout_p, 0.0f);
+    for (int oc = 0; oc < c.cout; oc++) {
+        for (int ic = 0; ic < c.cin; ic++)
+            for (int t = 0; t < taps; t++) o.w[((size_t)oc * cin_p + ic) * taps + t] = c.w[((size_t)oc * c.cin + ic) * taps + t];
+        o.b[oc] = c.b[oc];
+    }
+    return o;
+}
+// nn.Linear over a channel-major flatten of [ch][hw]: the new channels' inputs are appended (index c * hw + p)
+Linear widen_flat(const Linear &l, int in_p) {
+    Linear o;
+    o.out = l.out;
+    o.in = in_p;
+    o.w.assign((size_t)l.out * in_p, 0.0f);
+    o.b = l.b;
+    for (int r = 0; r < l.out; r++) memcpy(&o.w[(size_t)r * in_p], &l.w[(size_t)r * l.in], (size_t)l.in * 4);
+    return o;
+}
+}  // namespace
+
+Model *pad_channels(const Model &m, int cpad) {
+    if (cpad <= m.channels) return nullptr;
+    std::unique_ptr<Model> o(new Model(m));
+    const int C = m.channels, hw = m.h * m.w;
+    o->channels = cpad;
+    // a widened channel carries 0 through the whole tower: zero filters and bias in the stem, relu(0) in conv A,
+    // relu(0) + 0 in conv B, and 1 * 0 + 0 through the final BatchNorm
+    o->tower[0] = widen(m.tower[0], cpad, m.tower[0].cin);
+    for (size_t i = 1; i < m.tower.size(); i++) o->tower[i] = widen(m.tower[i], cpad, cpad);
+    o->final_scale.resize(cpad, 1.0f);
+    o->final_shift.resize(cpad, 0.0f);
+    o->sh_conv = widen(m.sh_conv, m.sh_conv.cout, cpad);
+    switch (m.policy_kind) {
+        case POLICY_ATAXX_CONV:
+        case POLICY_CONV:
+            o->p_conv0 = widen(m.p_conv0, cpad, cpad);  // (its hidden layer has the tower's width: relu(0) = 0 in the new channels)
+            o->p_conv1 = widen(m.p_conv1, m.p_conv1.cout, cpad);
+            if (m.policy_extra_moves) o->p_extra_conv = widen(m.p_extra_conv, m.p_extra_conv.cout, cpad);
+            break;
+        case POLICY_ATTENTION:
+            o->p_bulk = widen(m.p_bulk, m.p_bulk.cout, cpad);
+            o->p_under = widen(m.p_under, m.p_under.cout, cpad);
+            break;
+        case POLICY_DENSE:
+            if (m.dense_hidden_channels) o->p_conv0 = widen(m.p_conv0, m.p_conv0.cout, cpad);
+            else if (m.dense_hidden_size) o->p_fc0 = widen_flat(m.p_fc0, cpad * hw);
+            else o->p_fc1 = widen_flat(m.p_fc1, cpad * hw);
+            break;
+    }
+    (void)C;
+    return o.release();
+}
+
 }  // namespace kz

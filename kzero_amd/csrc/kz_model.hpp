@@ -57,6 +57,12 @@ struct Model {
 // Returns nullptr and sets `err` on failure.
 Model *parse_model(const void *blob, size_t len, std::string &err);
 
+// The same network with its tower widened to `cpad` channels by all-zero filters (same outputs: the new channels carry
+// zeros from the stem to the heads).  param_count and flops_per_eval stay the original network's.  The engine widens a
+// tower whose channel count is not a multiple of 64 (48, 96, 160 ...) to the next one, so that it runs on the one-launch
+// and board-tile kernels instead of the generic implicit GEMM.  nullptr when cpad <= channels.
+Model *pad_channels(const Model &m, int cpad);
+
 // ONNX as exported by the trainer (python/lib/save_onnx.py:60-122), kz_onnx.cpp.  n_scalar = how many of the input
 // planes are broadcast scalars (InputMapper::input_scalar_count, rust/kz-core/src/mapping/mod.rs:21) — the graph does
 // not carry that split; pass -1 when unknown (then only the dense-input entry points work).

@@ -103,7 +103,9 @@ constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 // PF = weight prefetch distance in k-steps (register ring stages, a power of two <= 8); PF * 16 KB are in flight per
 // CU.  Measured at one board per workgroup: PF = 8 is SLOWER than PF = 4 (0.665 vs 0.611 ms per batch) — that
 // configuration is bound by L2->CU bandwidth (~80 GB/s per CU), not by latency.
-template <int NB, bool HEADS, int PF>
+// WIDE: more than 32 input planes (the instance for up to 32 keeps its compile-time stem: a same-box A/B of a run-time
+// chunk count in the benchmark's instance cost 0.3 %)
+template <int NB, bool HEADS, int PF, bool WIDE = false>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
     using L = Layout<NB>;
     constexpr int M = L::M, MT = L::MT;
@@ -141,11 +143,15 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
 #endif
     };
 
-    // ---- zero rows and stem input ----
+    // ---- zero rows and stem input.  Up to 32 input planes the stem input has its own rows of 64 B behind the zero rows;
+    // more (ChessHistoryMapper, chess.rs:32-39: 34 / 47 / 60 planes; sc chunks of 32) are staged in the Y image, which
+    // nothing touches before the first block's epilogue ----
+    const int sc = WIDE ? a.cin_p >> 5 : 1;
+    const int stem_off = WIDE ? L::Y_OFF : L::S_OFF, srow = 64 * sc, spieces = 4 * sc;
     for (int id = tid; id < 16 * RS / 16; id += 256)
         *reinterpret_cast<uint4 *>(lds + L::Z_OFF + id * 16) = make_uint4(0, 0, 0, 0);
-    for (int id = tid; id < M * 4; id += 256) {
-        const int row = id >> 2, c = id & 3;
+    for (int id = tid; id < M * spieces; id += 256) {
+        const int row = WIDE ? id / spieces : id >> 2, c = id - row * spieces;
         const int board = board0 + (row >> 6);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (board < a.batch) {
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 v = *reinterpret_cast<const uint4 *>(a.x0 + ((size_t)board0 * 64 + row) * a.cin_p + c * 8);
             }
         }
-        *reinterpret_cast<uint4 *>(lds + L::S_OFF + row * 64 + c * 16) = v;
+        *reinterpret_cast<uint4 *>(lds + stem_off + row * srow + c * 16) = v;
     }
     __syncthreads();
 
@@ -251,23 +257,24 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
         else return !(kill_x || ((mt & 3) == 0 && dy < 0 && yo_is0) || ((mt & 3) == 3 && dy > 0 && yo_is1));
     };
 
-    // ---- stem: 9 k-steps over the 32 (padded) input channels; conv + bias, no activation (post_act.py:205) ----
+    // ---- stem: 9 sc k-steps over the 32 sc (padded) input channels; conv + bias, no activation (post_act.py:205) ----
     fetch_bias(0);
     init_acc();
     fetch_bias(1);
-    for (int tap = 0; tap < 9; tap++) {
+    for (int ks = 0; ks < 9 * sc; ks++) {
+        const int tap = WIDE ? ks / sc : ks, chunk = ks - tap * sc;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         h16x8 af[4];
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
-            const uint4 t = a.w_stem[((tap * 4 + wave) * 4 + nt) * 64 + lane];
+            const uint4 t = a.w_stem[((ks * 4 + wave) * 4 + nt) * 64 + lane];
             af[nt] = *reinterpret_cast<const h16x8 *>(&t);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const bool ok = tap_ok(mt, dy, dx);
             const int p = L::LINE_TILES ? (fr >> 3) * 64 + mt * 8 + (fr & 7) : mt * 16 + fr;  // row of the stem input
-            const int off = ok ? L::S_OFF + (p + dy * 8 + dx) * 64 + kq * 16 : L::Z_OFF + kq * 16;  // stem: natural k
+            const int off = ok ? stem_off + (p + dy * 8 + dx) * srow + chunk * 64 + kq * 16 : L::Z_OFF + kq * 16;  // stem: natural k
             const h16x8 bf = *reinterpret_cast<const h16x8 *>(lds + off);
 #pragma unroll
             for (int nt = 0; nt < 4; nt++)
@@ -606,8 +613,10 @@ void pack_1x1(const float *w, uint16_t *dst) {
 
 int tower_resident_boards_per_workgroup() { return boards_per_wg(); }
 
-bool tower_resident_supported(int dtype, int h, int w, int channels, int depth) {
-    return dtype == 1 && h == 8 && w == 8 && channels == C && depth >= 1;
+// (input planes in chunks of 32; beyond one chunk they are staged in the Y image: 64 B per chunk and row; 7 chunks at
+// most — tower_pack_weights tells a tower layer from a stem by cin_p == 256)
+bool tower_resident_supported(int dtype, int h, int w, int channels, int depth, int c_in) {
+    return dtype == 1 && h == 8 && w == 8 && channels == C && depth >= 1 && c_in >= 1 && c_in <= 224;
 }
 
 bool tower_heads_supported(int policy_kind, int query_channels, int policy_len, int sh_channels, int sh_size) {
@@ -623,7 +632,7 @@ size_t tower_heads_weight_elems() { return (size_t)HEAD_KSTEPS * 16 * 1024 / 2; 
 // OIHW f32 -> [tap 9][chunk cin_p/32][wave 4][nt 4][lane 64][8] f16: element j of lane (fr, kq) of (wave, nt) is
 // W[oc = 64*wave + 16*nt + fr][channel][tap] — the A fragment of v_mfma_f32_16x16x32_f16 — where the k-step's channel
 // assignment is the kernel's: cin_p == 256: channel = 8*chunk + {0,128,64,192}[kq] + j (bank-conflict-free LDS reads);
-// stem (cin_p == 32): channel = 8*kq + j.
+// stem (cin_p a multiple of 32 below 256: ceil(c_in / 32) chunks): channel = 32*chunk + 8*kq + j.
 void tower_pack_weights(const float *oihw, int cout, int cin, int cin_p, uint16_t *dst) {
     const int nchunk = cin_p / 32;
     static const int kq_base[4] = {0, 128, 64, 192};
@@ -699,7 +708,11 @@ void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
         }
         kernel<<<grid, 256, bytes, stream>>>(d);
     };
-    if (boards_per_wg() == 1) {
+    if (t.cin_p > 32) {  // (ChessHistoryMapper: 34 / 47 / 60 planes; always two boards per workgroup)
+        const int grid = (t.batch + 1) / 2;
+        if (heads) launch(kz_tower_resident<2, true, PF_NB2, true>, grid, Layout<2>::BYTES);
+        else launch(kz_tower_resident<2, false, PF_NB2, true>, grid, Layout<2>::BYTES);
+    } else if (boards_per_wg() == 1) {
         if (heads) launch(kz_tower_resident<1, true, PF_NB1>, t.batch, Layout<1>::BYTES);
         else launch(kz_tower_resident<1, false, PF_NB1>, t.batch, Layout<1>::BYTES);
     } else {

@@ -390,8 +390,13 @@ bool tower32_supported(int dtype, int h, int w, int channels, int depth) {
 }
 
 bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs) {
-    const int nt = tiles_for(h * w, channels), hw = h * w;
-    if (!nt || (policy_kind != 0 && policy_kind != 1) || extra_moves < 0 || hc < 1 || hs < 1 || hs > 256) return false;
+    return conv_heads_fit(tiles_for(h * w, channels), policy_kind, extra_moves, pc, h, w, channels, hc, hs);
+}
+
+// kz_conv_heads.hpp on a launch of nt tiles of 16 rows: at most 8 tiles (two per wave) and four boards
+bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs) {
+    const int hw = h * w;
+    if (!nt || nt > 8 || (policy_kind != 0 && policy_kind != 1) || extra_moves < 0 || hc < 1 || hs < 1 || hs > 256) return false;
     if (policy_kind == 0 && extra_moves) return false;
     if (pc < 1 || pc > 32 || hc + (extra_moves ? 1 : 0) > 32) return false;  // two 16-channel tiles per small conv
     const int nb = nt * 16 / hw, nseg = 256 / hs;

@@ -50,13 +50,16 @@ struct Geo {
     static constexpr int XH = 0, YH = IMG, ZH = 2 * IMG;
     static constexpr int DELTA = (2 * IMG + 16 * RS + 255) / 256 * 256;
     static constexpr int PARTS = SPLIT ? 2 : 1;
-    static constexpr int SH = PARTS * DELTA, SL = SH + ROWS * 64;  // stem input, rows of 64 B (32 channels)
-    static constexpr int LDS_BYTES = SH + PARTS * ROWS * 64;
+    // (the stem input — rows of 64 B per chunk of 32 input planes — is staged in the Y image, which nothing else touches
+    // before the first block's epilogue)
+    static constexpr int LDS_BYTES = PARTS * DELTA;
+    static constexpr int SH = PARTS * DELTA, SL = SH + ROWS * 64, LDS_BYTES_OWN_STEM = SH + PARTS * ROWS * 64;  // (the experiment build's 32x32x16 variant keeps its own stem rows)
     static constexpr int OT = C / 64;   // 16-channel output tiles per wave
     static constexpr int G = C / 32;    // k-steps per tap
     static constexpr int STEP = PARTS * 4 * OT * 64;  // uint4 per k-step: [hi | lo][wave 4][ot][lane 64]
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static constexpr int PF = G >= 4 ? 4 : 2;  // weight ring depth in k-steps
+    static_assert(C % 64 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
+    // weight ring depth in k-steps (a divisor of G; five stages of 320 channels next to six pixel tiles do not fit the registers)
+    static constexpr int PF = G % 4 == 0 ? 4 : G % 3 == 0 ? 3 : (G % 5 == 0 && NT < 6) ? 5 : 2;
     static_assert(G % PF == 0, "ring stage of a k-step must not depend on the tap");
 };
 
@@ -67,6 +70,7 @@ struct SplitDev {
     const float *post_scale, *post_shift;
     void *y;            // tower output [batch*hw][ldy]: f32 (SPLIT) or f16
     int ldx0, ldy, batch, depth, h, w_, hw, nb;
+    int stem_chunks;    // 32-channel chunks of the (padded) input planes: 9 * stem_chunks stem k-steps
     unsigned inv_w, inv_hw;  // ceil(65536 / w), ceil(65536 / hw): exact quotients for values < 512
     // fused encode (F0): packed boards; when bits == nullptr the stem input comes from x0
     const uint8_t *bits;
@@ -114,13 +118,14 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     const int boards = min(a.nb, a.batch - board0);
     const int rows_valid = boards * a.hw;
     const int layers = 2 * a.depth;
-    // of the ring: the 9 stem k-steps in front of them are read directly; the heads' passes follow the tower's
+    // of the ring: the 9 * stem_chunks stem k-steps in front of them are read directly; the heads' passes follow the tower's
     const int total_ksteps = layers * 9 * G + (HEADS == 1 ? HEAD_PASSES * G : HEADS == 2 ? G : 0);
     const int bias_rows = layers + (HEADS == 1 ? HEAD_PASSES : HEADS == 2 ? 1 : 0);
 
     // ---- weight stream: prime PF stages (stage s = k-step g % PF) ----
     const uint4 *wp_stem = a.w + wave * OT * 64 + lane;
-    const uint4 *wp = wp_stem + (size_t)9 * L::STEP;
+    const int sc = a.stem_chunks;
+    const uint4 *wp = wp_stem + (size_t)9 * sc * L::STEP;
     auto wload = [&](int gk, int part, int ot) __attribute__((always_inline)) {
         return wp[(size_t)gk * L::STEP + part * (4 * OT * 64) + ot * 64];
     };
@@ -145,13 +150,17 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             for (int ot = 0; ot < OT; ot++) wreg[stage][part][ot] = wload(gn, part, ot);
     };
 
-    // ---- zero rows and the stem input (f32 -> hi/lo, 32 channels per square; rows beyond the batch are zero) ----
+    // ---- zero rows and the stem input (f32 -> hi/lo, 32 sc channels per square; rows beyond the batch are zero), staged
+    // in the Y image: rows of 64 B per chunk of 32 input planes (ChessStdMapper 21 planes: one chunk; ChessHistoryMapper,
+    // chess.rs:32-39, 34 / 47 / 60 planes: two) ----
+    constexpr int stem_h = YH, stem_l = YH + DELTA;
+    const int srow = 64 * sc, spieces = 8 * sc;
     for (int id = tid; id < 16 * RS / 16; id += 256) {
         *reinterpret_cast<uint4 *>(lds + ZH + id * 16) = make_uint4(0, 0, 0, 0);
         if constexpr (SPLIT) *reinterpret_cast<uint4 *>(lds + ZH + DELTA + id * 16) = make_uint4(0, 0, 0, 0);
     }
-    for (int id = tid; id < L::ROWS * 8; id += 256) {  // (row, 4-channel piece)
-        const int row = id >> 3, c4 = id & 7;
+    for (int id = tid; id < L::ROWS * spieces; id += 256) {  // (row, 4-channel piece)
+        const int row = id / spieces, c4 = id - row * spieces;
         const bool have = row < rows_valid && c4 * 4 < a.ldx0;
         if (a.bits) {
             // encode_input_full (rust/kz-core/src/mapping/mod.rs:40-63) for 4 channels of one square: scalar planes first,
@@ -173,19 +182,19 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             }
             h16x4 hi, lo;
             split4(v, hi, lo);
-            *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = hi;
-            if constexpr (SPLIT) *reinterpret_cast<h16x4 *>(lds + L::SL + row * 64 + c4 * 8) = lo;
+            *reinterpret_cast<h16x4 *>(lds + stem_h + row * srow + c4 * 8) = hi;
+            if constexpr (SPLIT) *reinterpret_cast<h16x4 *>(lds + stem_l + row * srow + c4 * 8) = lo;
         } else if constexpr (SPLIT) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (have) v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(a.x0) + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
             h16x4 hi, lo;
             split4(v, hi, lo);
-            *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = hi;
-            *reinterpret_cast<h16x4 *>(lds + L::SL + row * 64 + c4 * 8) = lo;
+            *reinterpret_cast<h16x4 *>(lds + stem_h + row * srow + c4 * 8) = hi;
+            *reinterpret_cast<h16x4 *>(lds + stem_l + row * srow + c4 * 8) = lo;
         } else {
             h16x4 v = h16x4{};
             if (have) v = *reinterpret_cast<const h16x4 *>(static_cast<const h16 *>(a.x0) + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
-            *reinterpret_cast<h16x4 *>(lds + L::SH + row * 64 + c4 * 8) = v;
+            *reinterpret_cast<h16x4 *>(lds + stem_h + row * srow + c4 * 8) = v;
         }
     }
 
@@ -239,30 +248,31 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                : tap == 4 ? okmask[4] : tap == 5 ? okmask[5] : tap == 6 ? okmask[6] : tap == 7 ? okmask[7] : okmask[8];
     };
 
-    // ---- stem: 9 k-steps over the 32 (padded) input channels; conv + bias, no activation (post_act.py:205) ----
+    // ---- stem: 9 sc k-steps over the 32 sc (padded) input channels; conv + bias, no activation (post_act.py:205) ----
     fetch_bias(0);
     init_acc();
     fetch_bias(1);
 #pragma nounroll
-    for (int tap = 0; tap < 9; tap++) {
+    for (int ks = 0; ks < 9 * sc; ks++) {
+        const int tap = sc == 1 ? ks : ks / sc, chunk = ks - tap * sc;
         const int shift = (tap / 3 - 1) * a.w_ + (tap % 3 - 1);
         const unsigned ok = ok_of(tap);
         h16x8 ah[OT], al[OT], bh[NT], bl[NT];
 #pragma unroll
         for (int ot = 0; ot < OT; ot++) {
-            const uint4 th = wp_stem[(size_t)tap * L::STEP + ot * 64];
+            const uint4 th = wp_stem[(size_t)ks * L::STEP + ot * 64];
             ah[ot] = *reinterpret_cast<const h16x8 *>(&th);
             if constexpr (SPLIT) {
-                const uint4 tl = wp_stem[(size_t)tap * L::STEP + 4 * OT * 64 + ot * 64];
+                const uint4 tl = wp_stem[(size_t)ks * L::STEP + 4 * OT * 64 + ot * 64];
                 al[ot] = *reinterpret_cast<const h16x8 *>(&tl);
             }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            const int off = (nt * 16 + fr + shift) * 64 + kq * 16;  // stem: natural k (channel = 8 kq + j)
+            const int off = (nt * 16 + fr + shift) * srow + chunk * 64 + kq * 16;  // stem: natural k (channel = 32 chunk + 8 kq + j)
             const bool valid = (ok >> nt) & 1;
-            bh[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + L::SH + off) : h16x8{};
-            if constexpr (SPLIT) bl[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + L::SL + off) : h16x8{};
+            bh[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + stem_h + off) : h16x8{};
+            if constexpr (SPLIT) bl[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + stem_l + off) : h16x8{};
         }
         mfma3(ah, al, bh, bl);
     }
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             tap_rows(tap + 1 < 9 ? tap + 1 : tap, src_h, Tn);
 #pragma unroll
             for (int ch = 0; ch < G; ch++) {
-                const int stage = ch & (PF - 1), cur = ch & 1, nxt = cur ^ 1;
+                const int stage = ch % PF, cur = ch & 1, nxt = cur ^ 1;
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     bh[nxt][nt] = ch < G - 1 ? rd(T[nt], (ch + 1) * 16) : rd(Tn[nt], 0);
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                 bh[nt] = *reinterpret_cast<const h16x8 *>(lds + t);
                 if constexpr (SPLIT) bl[nt] = *reinterpret_cast<const h16x8 *>(lds + t + DELTA);
             }
-            ring_take(ch & (PF - 1), ah, al);
+            ring_take(ch % PF, ah, al);
             mfma3(ah, al, bh, bl);
             g++;
         }
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                     bh[nt] = *reinterpret_cast<const h16x8 *>(lds + t);
                     bl[nt] = *reinterpret_cast<const h16x8 *>(lds + t + DELTA);
                 }
-                ring_take(ch & (PF - 1), ah, al);
+                ring_take(ch % PF, ah, al);
                 if (tiles == 1) {
 #pragma unroll
                     for (int ot = 0; ot < OT; ot++) {
@@ -1022,16 +1032,26 @@ void launch32(const SplitDev &d, int grid, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_tower_resident_split32<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Geo<256, 4, SPLIT>::LDS_BYTES);
+                                  Geo<256, 4, SPLIT>::LDS_BYTES_OWN_STEM);
         done_mask |= 1ull << (dev & 63);
     }
-    kz_tower_resident_split32<SPLIT><<<grid, 256, Geo<256, 4, SPLIT>::LDS_BYTES, stream>>>(d);
+    kz_tower_resident_split32<SPLIT><<<grid, 256, Geo<256, 4, SPLIT>::LDS_BYTES_OWN_STEM, stream>>>(d);
 }
 #endif  // KZ_EXPERIMENTS
 
+// Tiles of 16 pixel rows per workgroup (0: no instance): as many whole boards as the LDS images and the accumulators
+// hold.  The weight stream is read once per workgroup and layer, so more boards per workgroup = fewer L2 bytes per board.
 int split_tiles_for(int hw, int channels, bool split) {
-    // (the plain-f16 launch has half the LDS footprint: 256 channels fit up to 96 squares — Go 9x9)
-    if (channels == 256) return hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
+    // (the plain-f16 launch has half the LDS footprint: 256 / 320 channels fit up to 96 squares — Go 9x9)
+    if (channels == 256 || channels == 320) return channels == 320 && split ? 0 : hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
+    if (channels == 384 || channels == 512) return !split && hw <= 64 ? 4 : 0;
+#ifdef KZ_192_NT4
+    if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
+#else
+    if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 8 : hw <= 96 ? 6 : 0;
+#endif
+    // (two 8x8 boards in eight tiles were measured at 64 / 128 channels: 0.29 against 0.32 of the peak with two engines —
+    // half as many workgroups, one per CU instead of two)
     if (channels == 128 || channels == 64) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
     return 0;
 }
@@ -1219,8 +1239,14 @@ __global__ __launch_bounds__(256) void kz_conv1x1_split(Conv1x1SplitDev a) {
 
 }  // namespace
 
+// (the stem takes the input planes in chunks of 32; beyond one chunk they are staged in the Y image: rows of 64 B per
+// chunk must fit a row of 2 C + 16 B)
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split) {
-    return depth >= 1 && c_in <= 32 && h >= 2 && w >= 2 && w <= 32 && split_tiles_for(h * w, channels, split) != 0;
+    const int nt = split_tiles_for(h * w, channels, split);
+#ifdef KZ_EXPERIMENTS
+    if (c_in > 32 && split_uses_32x32(channels, nt, split)) return false;  // (the 32x32x16 variant has the one-chunk stem)
+#endif
+    return depth >= 1 && c_in >= 1 && (c_in + 31) / 32 <= channels / 32 && h >= 2 && w >= 2 && w <= 32 && nt != 0;
 }
 
 int tower_split_boards_per_workgroup(int h, int w, int channels, bool split) {
@@ -1228,17 +1254,22 @@ int tower_split_boards_per_workgroup(int h, int w, int channels, bool split) {
     return nt ? nt * 16 / (h * w) : 0;
 }
 
-size_t tower_split_weight_elems(int channels, int depth, bool split) {  // f16 elements
+size_t tower_split_stem_elems(int channels, int c_in, bool split) {  // f16 elements of the stem's k-steps
+    return (size_t)9 * ((c_in + 31) / 32) * (split ? 2 : 1) * channels * 32;
+}
+
+size_t tower_split_weight_elems(int channels, int depth, int c_in, bool split) {  // f16 elements
     const size_t step = (size_t)(split ? 2 : 1) * channels * 32;  // [hi | lo][channels][32]
-    return ((size_t)9 + (size_t)2 * depth * 9 * (channels / 32)) * step;
+    return tower_split_stem_elems(channels, c_in, split) + (size_t)2 * depth * 9 * (channels / 32) * step;
 }
 
 // OIHW f32 (BN folded) -> k-steps of [hi | lo][wave 4][ot C/64][lane 64][8] f16; element j of lane (fr, kq) of (wave, ot)
 // is W[oc = 16*(wave*C/64 + ot) + fr][channel][tap], channel = 8*chunk + {0, C/2, C/4, 3C/4}[kq] + j for a tower layer (one
-// k-step per tap and chunk of 32 channels) and 8*kq + j for the stem (one k-step per tap, 32 padded input channels).
+// k-step per tap and chunk of 32 channels) and 32*chunk + 8*kq + j for the stem (one k-step per tap and chunk of 32 padded
+// input channels).
 void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool stem, bool split, uint16_t *dst) {
     const int kq_base[4] = {0, cout / 2, cout / 4, 3 * cout / 4};  // tower layers: cin == cout
-    const int nchunk = stem ? 1 : cin / 32, ot_n = cout / 64;
+    const int nchunk = stem ? (cin + 31) / 32 : cin / 32, ot_n = cout / 64;
     const size_t part = (size_t)cout * 32;  // f16 elements of the hi (or lo) half of a k-step
     (void)hw;
 #ifdef KZ_EXPERIMENTS
@@ -1278,7 +1309,7 @@ void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool
                         for (int j = 0; j < 8; j++) {
                             const int oc = 16 * (wave * ot_n + ot) + (lane & 15);
                             const int kq = lane >> 4;
-                            const int ch = stem ? 8 * kq + j : 8 * chunk + kq_base[kq] + j;
+                            const int ch = stem ? 32 * chunk + 8 * kq + j : 8 * chunk + kq_base[kq] + j;
                             float v = 0.0f;
                             if (oc < cout && ch < cin) v = oihw[((size_t)oc * cin + ch) * 9 + tap];
                             const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
@@ -1351,8 +1382,9 @@ bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, 
                                       bool split) {
     if (channels != 128 && channels != 256) return false;
     const int nt = split_tiles_for(h * w, channels, split);
-    return nt != 0 && nt * 16 / (h * w) == tower32_boards_per_workgroup(h, w, channels) &&
-           tower32_heads_supported(policy_kind, extra_moves, pc, h, w, channels, hc, hs);
+    // (instances: <256, 4> and <128, 4 / 6 / 7>; the f32 row images of the tail must fit the LDS next to nothing else)
+    if (nt == 0 || (channels == 256 && nt != 4) || (size_t)(16 + 2 * nt * 16) * (channels * 4 + 16) > (size_t)160 * 1024) return false;
+    return conv_heads_fit(nt, policy_kind, extra_moves, pc, h, w, channels, hc, hs);
 }
 
 size_t tower_split_conv_heads_weight_elems(int channels, bool split) { return (size_t)(channels / 32) * (split ? 2 : 1) * channels * 32; }  // one pass
@@ -1405,6 +1437,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     d.h = t.h;
     d.w_ = t.w;
     d.hw = t.h * t.w;
+    d.stem_chunks = (t.c_in + 31) / 32;
     const int nt = split_tiles_for(d.hw, t.channels, split);
     d.nb = nt * 16 / d.hw;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
@@ -1422,14 +1455,14 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
             d.small_w = reinterpret_cast<const f32x4 *>(hd.small_w);
             if (split) {
                 if (t.channels == 256) launch<256, 4, true, 2>(d, grid, stream);
+                else if (nt == 4) launch<128, 4, true, 2>(d, grid, stream);
                 else if (nt == 7) launch<128, 7, true, 2>(d, grid, stream);
-                else if (nt == 6) launch<128, 6, true, 2>(d, grid, stream);
-                else launch<128, 4, true, 2>(d, grid, stream);
+                else launch<128, 6, true, 2>(d, grid, stream);
             } else {  // the plain-f16 launch ("tower_resident_f16g+heads")
                 if (t.channels == 256) launch<256, 4, false, 2>(d, grid, stream);
+                else if (nt == 4) launch<128, 4, false, 2>(d, grid, stream);
                 else if (nt == 7) launch<128, 7, false, 2>(d, grid, stream);
-                else if (nt == 6) launch<128, 6, false, 2>(d, grid, stream);
-                else launch<128, 4, false, 2>(d, grid, stream);
+                else launch<128, 6, false, 2>(d, grid, stream);
             }
             return;
         }
@@ -1442,25 +1475,34 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else
 #endif
         if (t.channels == 256) launch<256, 4, true>(d, grid, stream);
+        else if (t.channels == 192) launch<192, 4, true>(d, grid, stream);
+        else if (t.channels == 128 && nt == 4) launch<128, 4, true>(d, grid, stream);
         else if (t.channels == 128 && nt == 7) launch<128, 7, true>(d, grid, stream);
-        else if (t.channels == 128 && nt == 6) launch<128, 6, true>(d, grid, stream);
-        else if (t.channels == 128) launch<128, 4, true>(d, grid, stream);
+        else if (t.channels == 128) launch<128, 6, true>(d, grid, stream);
+        else if (nt == 4) launch<64, 4, true>(d, grid, stream);
         else if (nt == 7) launch<64, 7, true>(d, grid, stream);
-        else if (nt == 6) launch<64, 6, true>(d, grid, stream);
-        else launch<64, 4, true>(d, grid, stream);
+        else launch<64, 6, true>(d, grid, stream);
     } else {
 #ifdef KZ_EXPERIMENTS
         if (split_uses_32x32(t.channels, nt, false)) launch32<false>(d, grid, stream);
         else
 #endif
-        if (t.channels == 256 && nt == 6) launch<256, 6, false>(d, grid, stream);
+        if (t.channels == 512) launch<512, 4, false>(d, grid, stream);
+        else if (t.channels == 384) launch<384, 4, false>(d, grid, stream);
+        else if (t.channels == 320 && nt == 6) launch<320, 6, false>(d, grid, stream);
+        else if (t.channels == 320) launch<320, 4, false>(d, grid, stream);
+        else if (t.channels == 256 && nt == 6) launch<256, 6, false>(d, grid, stream);
         else if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
+        else if (t.channels == 192 && nt == 8) launch<192, 8, false>(d, grid, stream);
+        else if (t.channels == 192 && nt == 4) launch<192, 4, false>(d, grid, stream);
+        else if (t.channels == 192 && nt == 7) launch<192, 7, false>(d, grid, stream);
+        else if (t.channels == 192) launch<192, 6, false>(d, grid, stream);
+        else if (t.channels == 128 && nt == 4) launch<128, 4, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 7) launch<128, 7, false>(d, grid, stream);
-        else if (t.channels == 128 && nt == 6) launch<128, 6, false>(d, grid, stream);
-        else if (t.channels == 128) launch<128, 4, false>(d, grid, stream);
+        else if (t.channels == 128) launch<128, 6, false>(d, grid, stream);
+        else if (nt == 4) launch<64, 4, false>(d, grid, stream);
         else if (nt == 7) launch<64, 7, false>(d, grid, stream);
-        else if (nt == 6) launch<64, 6, false>(d, grid, stream);
-        else launch<64, 4, false>(d, grid, stream);
+        else launch<64, 6, false>(d, grid, stream);
     }
 }
 

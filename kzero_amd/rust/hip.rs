@@ -42,6 +42,15 @@ pub struct KzModelInfo {
     pub flops_per_eval: f64,
 }
 
+/// What `kz_engine_create` would choose for a model (kz_model_plan): host logic, no GPU touched
+#[repr(C)]
+#[derive(Debug, Copy, Clone)]
+pub struct KzPathPlan {
+    pub tower_path: [c_char; 48],
+    pub launches_per_batch: i32,
+    pub reserved: [i32; 3],
+}
+
 pub const KZ_DTYPE_F32: c_int = 0;
 pub const KZ_DTYPE_F16: c_int = 1;
 /// f32 tensors and the same <= 1e-4 parity as KZ_DTYPE_F32, the tower's products as three f16 MFMAs on (hi, lo) pairs
@@ -65,6 +74,7 @@ extern "C" {
     fn kz_engine_create(model: *const c_void, device: c_int, max_batch: c_int, dtype: c_int, out: *mut *mut c_void) -> c_int;
     fn kz_engine_destroy(engine: *mut c_void);
     fn kz_model_supports_dtype(model: *const c_void, dtype: c_int) -> c_int;
+    fn kz_model_plan(model: *const c_void, max_batch: c_int, dtype: c_int, out: *mut KzPathPlan) -> c_int;
     fn kz_engine_max_batch(engine: *const c_void) -> c_int;
     fn kz_engine_eval_dense(engine: *mut c_void, input_nchw: *const f32, batch: c_int, scalars_out: *mut f32, policy_out: *mut f32) -> c_int;
     fn kz_engine_eval_packed(engine: *mut c_void, bits: *const u8, bits_stride: usize, scalars_in: *const f32, batch: c_int, scalars_out: *mut f32, policy_out: *mut f32) -> c_int;

@@ -26,6 +26,26 @@ GAMES = {
     "go-9": dict(size=9, n_scalar=6, n_bool=7, policy_len=1 + 81, p_bool=0.25),
 }
 
+
+def game_spec(game: str) -> dict:
+    """The table above, plus every other size / mapper the reference's server accepts (rust/kz-selfplay/src/server/
+    server.rs:170-200): `ataxx-N` (N 2..8), `go-N`, `go-N-noterr` (GoStdMapper without the territory planes: 4 bool + 6
+    scalar = 10 input planes), `chess-hist-L` (ChessHistoryMapper, chess.rs:32-39: 8 + L scalars, 1 + 12 (L + 1) bools)."""
+    if game in GAMES:
+        return GAMES[game]
+    if game.startswith("chess-hist-"):
+        length = int(game[len("chess-hist-"):])
+        return dict(size=8, n_scalar=7 + (length + 1), n_bool=1 + 12 * (length + 1), policy_len=1880, p_bool=0.04)
+    if game.startswith("ataxx-"):
+        n = int(game[6:])
+        return dict(size=n, n_scalar=1, n_bool=3, policy_len=17 * n * n + 1, p_bool=0.3)
+    if game.startswith("go-"):
+        noterr = game.endswith("-noterr")
+        n = int(game[3:-7] if noterr else game[3:])
+        return dict(size=n, n_scalar=6, n_bool=4 if noterr else 7, policy_len=1 + n * n, p_bool=0.25)
+    raise KeyError(game)
+
+
 _GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -59,10 +79,11 @@ def _bn(rng, t, prefix, c):
 
 
 def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0, query_channels: int = None,
-                 n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0) -> bytes:
+                 n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0,
+                 dense_hidden_channels: int = None, dense_hidden_size: int = None) -> bytes:
     """`block_gain` > 1 scales every block's second BatchNorm weight: the residual stream then grows from block to block
     the way a trained network's does (a random-init tower keeps it within a few tens)."""
-    g = GAMES[game]
+    g = game_spec(game)
     size, n_scalar = g["size"], g["n_scalar"]
     n_bool = g["n_bool"] if n_bool is None else n_bool
     hw, C = size * size, channels
@@ -81,6 +102,9 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
         # scales them down, an untrained one would let them dominate every activation
         t["common.tower.0.weight"][:, 6] *= 0.5
         t["common.tower.0.weight"][:, 7] *= 0.01
+    elif game.startswith("chess-hist-"):
+        t["common.tower.0.weight"][:, 6] *= 0.01  # the 50-move counter (chess.rs:54)
+        t["common.tower.0.weight"][:, 7:n_scalar] *= 0.5  # 1 + repetitions per board (chess.rs:86-87)
     for i in range(1, depth + 1):
         _conv(rng, t, f"common.tower.{i}.seq.0", C, C, 3)
         _bn(rng, t, f"common.tower.{i}.seq.1", C)
@@ -109,6 +133,21 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
         _conv(rng, t, "policy_head.conv_bulk", 2 * q, C, 1)
         _conv(rng, t, "policy_head.conv_under", 3 * q, C, 1)
         t["policy_head.FLAT_TO_ATT"] = chess_flat_to_att()
+    elif head == "dense":
+        # DensePolicyHead(game, channels, hidden_channels, hidden_size) (post_act.py:26-51): nn.Sequential indices shift
+        # with the optional layers — [Conv2d, ReLU,] Flatten, [Linear, ReLU,] Linear
+        idx, ch = 0, C
+        if dense_hidden_channels:
+            meta["policy_dense_hidden_channels"] = dense_hidden_channels
+            _conv(rng, t, "policy_head.seq.0", dense_hidden_channels, C, 1)
+            ch, idx = dense_hidden_channels, 2
+        idx += 1
+        size_in = ch * hw
+        if dense_hidden_size:
+            meta["policy_dense_hidden_size"] = dense_hidden_size
+            _linear(rng, t, f"policy_head.seq.{idx}", dense_hidden_size, size_in)
+            size_in, idx = dense_hidden_size, idx + 2
+        _linear(rng, t, f"policy_head.seq.{idx}", g["policy_len"], size_in)
     else:
         raise ValueError(f"unsupported synthetic head '{head}'")
     return write_model(meta, t)
@@ -116,7 +155,7 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
 
 def random_boards(game: str, batch: int, seed: int = 0, n_bool: int = None) -> Tuple[np.ndarray, np.ndarray]:
     """Returns (bits [batch, ceil(n_bool*hw/8)] u8, scalars [batch, n_scalar] f32)."""
-    g = GAMES[game]
+    g = game_spec(game)
     size, n_scalar = g["size"], g["n_scalar"]
     n_bool = g["n_bool"] if n_bool is None else n_bool
     rng = np.random.default_rng(seed)
@@ -127,6 +166,12 @@ def random_boards(game: str, batch: int, seed: int = 0, n_bool: int = None) -> T
         white = rng.integers(0, 2, size=batch)
         scalars = np.stack([white, 1 - white, *(rng.integers(0, 2, size=batch) for _ in range(4)),
                             rng.integers(0, 3, size=batch), rng.integers(0, 100, size=batch)], axis=1)
+    elif game.startswith("chess-hist-"):
+        # [pov==White, pov==Black, castling x4, 50-move counter, then 1 + repetitions per board] (chess.rs:41-75)
+        white = rng.integers(0, 2, size=batch)
+        scalars = np.stack([white, 1 - white, *(rng.integers(0, 2, size=batch) for _ in range(4)),
+                            rng.integers(0, 100, size=batch),
+                            *(1 + rng.integers(0, 3, size=batch) for _ in range(n_scalar - 7))], axis=1)
     elif game.startswith("ataxx"):
         scalars = rng.uniform(0, 1, size=(batch, 1))  # moves_since_last_copy / MAX (ataxx.rs:107-109)
     else:

@@ -57,12 +57,16 @@ def test_flops_match_baseline_md():
 
 def test_which_models_the_parity_arithmetic_takes():
     """kz_model_supports_dtype needs no GPU: it is what the Rust binding's default (`KZ_HIP_DTYPE=parity`, hip.rs) asks before
-    it creates an engine.  KZ_DTYPE_F32_SPLIT16: the one-launch shapes, and since round 3 Go-size boards per layer."""
+    it creates an engine.  KZ_DTYPE_F32_SPLIT16: the one-launch shapes, since round 3 Go-size boards per layer, and since
+    round 4 towers of any channel count up to 512 (widened to the next multiple of 64 by zero filters); not: a tower
+    without blocks, or a channel count beyond 512 that is no multiple of 64."""
     S = capi.KZ_DTYPE_F32_SPLIT16
     for game, depth, ch, head, want in [("chess", 20, 256, "attention", True), ("ataxx-7", 8, 128, "ataxx_conv", True),
                                         ("go-9", 4, 128, "conv", True), ("go-19", 40, 256, "conv", True),
                                         ("go-19", 2, 64, "conv", True), ("go-9", 2, 256, "conv", True),
-                                        ("chess", 2, 32, "attention", False), ("go-19", 2, 96, "conv", False)]:
+                                        ("chess", 2, 32, "attention", True), ("go-19", 2, 96, "conv", True),
+                                        ("chess", 2, 192, "attention", True), ("chess-hist-2", 2, 256, "attention", True),
+                                        ("chess", 0, 64, "attention", False), ("go-19", 1, 520, "conv", False)]:
         model = capi.Model(blob=synth.random_model(game, depth, ch, head))
         assert model.supports_dtype(capi.KZ_DTYPE_F32) and model.supports_dtype(capi.KZ_DTYPE_F16)
         assert model.supports_dtype(S) == want, (game, depth, ch)

@@ -18,7 +18,7 @@ C_TO_RUST = {
     "kz_model **": "*mut *mut c_void", "const kz_model *": "*const c_void", "kz_model *": "*mut c_void",
     "kz_engine **": "*mut *mut c_void", "const kz_engine *": "*const c_void", "kz_engine *": "*mut c_void",
     "const void *": "*const c_void", "void *": "*mut c_void", "void **": "*mut *mut c_void",
-    "kz_model_info *": "*mut KzModelInfo",
+    "kz_model_info *": "*mut KzModelInfo", "kz_path_plan *": "*mut KzPathPlan",
 }
 C_RET = {"int": "c_int", "void": None, "const char *": "*const c_char"}
 
