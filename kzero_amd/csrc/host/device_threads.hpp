@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+#include <time.h>
+
 #include "executor.hpp"
 #include "hip_network.hpp"
 
@@ -43,7 +45,17 @@ struct DeviceSizing {
 // Evals::new(real, potential, cached) (protocol.rs:52-72); `real`/s is the north-star metric (collector.rs:172-191)
 struct EvalCounters {
     std::atomic<uint64_t> real{0}, potential{0};
+    // measurement only: CPU time (CLOCK_THREAD_CPUTIME_ID, ns) each executor thread of the device has used so far, read
+    // after every batch — what tells whether one executor thread keeps up with its GPU
+    static constexpr size_t MAX_EXECUTORS = 16;
+    std::atomic<uint64_t> executor_cpu_ns[MAX_EXECUTORS] = {};
 };
+
+inline uint64_t thread_cpu_ns() {
+    timespec ts{};
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 
 // Net: the network an executor thread builds from a graph, `Net(mapper, graph, max_batch, device, dtype)` with
 // evaluate_batch / submit_batch / wait_batch / set_device_decode / max_in_flight (HipNetwork<B, M>; the tests put a fake
@@ -93,6 +105,7 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
                 if (counters) {
                     counters->real += n;  // ExpandEvals(real = x.len(), potential = gpu_batch_size) (:113-115)
                     counters->potential += gpu_batch_size;
+                    if (local_id < EvalCounters::MAX_EXECUTORS) counters->executor_cpu_ns[local_id] = thread_cpu_ns();
                 }
             };
             const RunCondition cond = RunCondition::job_count(sizing.eval_job_count);

@@ -6,12 +6,21 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 #include "../../../include/kz_hip.h"
 #include "mapping.hpp"
 #include "network.hpp"
 
 namespace kz::host {
+
+// A board type may carry the policy indices of its available moves, computed where the board was made (a generator
+// thread): `const std::vector<int32_t> *policy_indices() const`, null when it does not.  The executor thread then
+// neither generates the moves nor looks them up for the device-side decode.
+template <class T, class = void>
+struct has_policy_indices : std::false_type {};
+template <class T>
+struct has_policy_indices<T, std::void_t<decltype(std::declval<const T &>().policy_indices())>> : std::true_type {};
 
 inline void kz_check(int rc) {
     if (rc != 0) throw std::runtime_error(std::string("kzhip: ") + kz_last_error());  // the reference panics
@@ -60,6 +69,15 @@ class HipNetwork : public Network<B> {
         offsets.assign(1, 0);
         move_indices_.clear();
         for (size_t bi = 0; bi < n; bi++) {
+            if constexpr (has_policy_indices<B>::value) {
+                if (const std::vector<int32_t> *idx = boards[bi].policy_indices()) {
+                    for (int32_t index : *idx)
+                        if (index < 0 || (size_t)index >= policy_len) throw std::out_of_range("policy index out of range");
+                    move_indices_.insert(move_indices_.end(), idx->begin(), idx->end());
+                    offsets.push_back((int64_t)move_indices_.size());
+                    continue;
+                }
+            }
             auto moves = boards[bi].available_moves();
             if (moves)
                 for (const auto &mv : *moves) {

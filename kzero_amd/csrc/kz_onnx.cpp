@@ -9,7 +9,10 @@
 // (stem conv, [conv (BN) relu conv (BN) relu add]*, final BatchNormalization, scalar head, one of the four policy
 // heads); anything else is rejected with a message.  The exporter has already folded the in-block Conv+BN pairs
 // (eval mode); a BatchNormalization that does follow a Conv is folded here.
+#include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -235,6 +238,499 @@ OGraph read_model(const void *blob, size_t len) {
     return g;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Normalising pass in front of the architecture matcher.  Exporters of other versions and settings write the same
+// network with other nodes: `Reshape(x, [0, -1])` or `Reshape(x, Concat(Unsqueeze(Gather(Shape(x), 0)), [-1]))` for
+// Flatten, `MatMul` + `Add` for Gemm, Gemm with transB = 0, `Constant` nodes instead of initializers (or both: initializers
+// listed as graph inputs), `Identity` / `Dropout` / `Cast` no-ops, un-folded Conv -> BatchNormalization pairs (folded by
+// the matcher), `Unsqueeze` / `Squeeze` / `Slice` with their parameters as attributes (opset < 10 / 13) or as inputs.
+// The pass brings all of them to ONE form — the one python/lib/save_onnx.py:107-119 gives with torch 2.x at opset 10 —
+// by (1) turning Constant nodes into initializers, (2) bypassing no-ops, (3) folding the integer "shape arithmetic"
+// (Shape / Gather / Unsqueeze / Squeeze / Concat / Slice / Cast chains) with a small shape inference in which the batch
+// axis stays symbolic, (4) rewriting Reshape-as-flatten to Flatten, identity reshapes to nothing and MatMul + Add to
+// Gemm.  What the matcher then rejects is a different architecture, not a different spelling.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int64_t BATCH = INT64_MIN + 1;  // the symbolic batch size inside folded integer tensors
+
+struct Normalizer {
+    OGraph &g;
+    std::map<std::string, std::vector<int64_t>> shape;  // data tensors: -1 = the batch (or another dynamic) axis
+    std::map<std::string, std::vector<int64_t>> ints;   // folded INT64 tensors (1-D or scalar): BATCH = symbolic
+    std::set<std::string> int_scalar;                   // ... of rank 0
+
+    bool is_output(const std::string &name) const {
+        for (auto &o : g.outputs) if (o == name) return true;
+        return false;
+    }
+    // every use of `from` (node inputs) now reads `to`
+    void replace_uses(const std::string &from, const std::string &to) {
+        for (auto &n : g.nodes)
+            for (auto &in : n.in) if (in == from) in = to;
+    }
+    // node i computes out[0] = in[0]: remove it
+    void bypass(size_t i) {
+        const std::string out = g.nodes[i].out[0], in = g.nodes[i].in[0];
+        g.nodes.erase(g.nodes.begin() + (long)i);
+        if (!is_output(out)) {
+            replace_uses(out, in);
+            return;
+        }
+        // a graph output: its name must survive — the producer of `in` writes `out` instead
+        bool renamed = false;
+        for (auto &n : g.nodes)
+            for (auto &o : n.out) if (o == in) { o = out; renamed = true; }
+        if (!renamed) fail("graph output '" + out + "' is a constant or the graph input");
+        replace_uses(in, out);
+    }
+    const OTensor *init(const std::string &name) const {
+        auto it = g.init.find(name);
+        return it == g.init.end() ? nullptr : &it->second;
+    }
+    // INT64 initializer or folded tensor -> values
+    bool get_ints(const std::string &name, std::vector<int64_t> &out) const {
+        auto it = ints.find(name);
+        if (it != ints.end()) { out = it->second; return true; }
+        if (const OTensor *t = init(name)) {
+            if (t->dtype == 7) { out = t->i; return true; }
+        }
+        return false;
+    }
+    bool is_scalar(const std::string &name) const {
+        if (int_scalar.count(name)) return true;
+        const OTensor *t = init(name);
+        return t && t->dims.empty();
+    }
+    const std::vector<int64_t> *get_shape(const std::string &name) const {
+        auto it = shape.find(name);
+        return it == shape.end() ? nullptr : &it->second;
+    }
+    // parameters that are attributes in old opsets and inputs in new ones
+    bool param_ints(const ONode &n, const char *attr, size_t input, std::vector<int64_t> &out) const {
+        auto a = n.attr.find(attr);
+        if (a != n.attr.end()) { out = a->second.ints; return true; }
+        return input < n.in.size() && !n.in[input].empty() && get_ints(n.in[input], out);
+    }
+
+    void absorb_constants() {
+        for (size_t i = 0; i < g.nodes.size();) {
+            ONode &n = g.nodes[i];
+            if (n.op != "Constant" || n.out.empty()) { i++; continue; }
+            OTensor t;
+            auto a = n.attr.find("value");
+            if (a != n.attr.end() && a->second.t) t = *a->second.t;
+            else if ((a = n.attr.find("value_int")) != n.attr.end()) { t.dtype = 7; t.i = {a->second.i}; }
+            else if ((a = n.attr.find("value_ints")) != n.attr.end()) { t.dtype = 7; t.i = a->second.ints; t.dims = {(int64_t)t.i.size()}; }
+            else if ((a = n.attr.find("value_float")) != n.attr.end()) { t.dtype = 1; t.f = {a->second.f}; }
+            else fail("Constant node without a value");
+            t.name = n.out[0];
+            g.init[t.name] = std::move(t);
+            g.nodes.erase(g.nodes.begin() + (long)i);
+        }
+    }
+
+    void bypass_noops() {
+        for (size_t i = 0; i < g.nodes.size();) {
+            ONode &n = g.nodes[i];
+            const bool noop = n.op == "Identity" || n.op == "Dropout" || n.op == "Cast";
+            if (!noop || n.in.empty() || n.out.empty()) { i++; continue; }
+            if (const OTensor *t = init(n.in[0])) {  // of a constant: an alias (Cast: converted)
+                OTensor c = *t;
+                if (n.op == "Cast") {
+                    const int64_t to = n.attr_i("to", 1);
+                    if (to == 1 && c.dtype == 7) { c.f.assign(c.i.begin(), c.i.end()); c.i.clear(); c.dtype = 1; }
+                    else if (to == 7 && c.dtype == 1) { c.i.clear(); for (float f : c.f) c.i.push_back((int64_t)f); c.f.clear(); c.dtype = 7; }
+                    else if (!((to == 1 && c.dtype == 1) || (to == 7 && c.dtype == 7))) fail("Cast of a constant to data type " + std::to_string(to));
+                }
+                c.name = n.out[0];
+                if (is_output(c.name)) fail("graph output '" + c.name + "' is a constant");
+                g.init[c.name] = std::move(c);
+                g.nodes.erase(g.nodes.begin() + (long)i);
+                continue;
+            }
+            if (n.op == "Cast") {
+                const int64_t to = n.attr_i("to", 1);
+                if (to == 7 || to == 6) { i++; continue; }  // integer arithmetic on shapes: folded below
+                if (to != 1) fail("Cast of an activation to data type " + std::to_string(to) + " (only FLOAT)");
+            }
+            bypass(i);
+        }
+    }
+
+    static int64_t prod(const std::vector<int64_t> &d, size_t lo, size_t hi) {
+        int64_t p = 1;
+        for (size_t k = lo; k < hi; k++) {
+            if (d[k] < 0) return -1;
+            p *= d[k];
+        }
+        return p;
+    }
+
+    // one pass over the (topologically ordered) nodes: shapes of data tensors and values of integer tensors, where known
+    void infer() {
+        shape.clear();
+        ints.clear();
+        int_scalar.clear();
+        for (auto &in : g.inputs)
+            if (!g.init.count(in.first)) shape[in.first] = in.second;
+        for (auto &n : g.nodes) {
+            if (n.out.empty()) continue;
+            const std::string &o = n.out[0];
+            const std::vector<int64_t> *a = n.in.empty() ? nullptr : get_shape(n.in[0]);
+            std::vector<int64_t> v, w;
+            if (n.op == "Shape") {
+                if (a) {
+                    v = *a;
+                    for (auto &d : v) if (d < 0) d = BATCH;
+                    ints[o] = v;
+                }
+            } else if (n.op == "Gather") {
+                const int64_t axis = n.attr_i("axis", 0);
+                if (get_ints(n.in[0], v) && get_ints(n.in[1], w) && axis == 0) {  // integer tensor, constant indices
+                    std::vector<int64_t> r;
+                    for (int64_t k : w) {
+                        if (k < 0) k += (int64_t)v.size();
+                        if (k < 0 || k >= (int64_t)v.size()) fail("Gather index out of range in shape arithmetic");
+                        r.push_back(v[(size_t)k]);
+                    }
+                    ints[o] = r;
+                    if (is_scalar(n.in[1])) int_scalar.insert(o);
+                } else if (a && get_ints(n.in[1], w)) {  // data tensor
+                    std::vector<int64_t> r = *a;
+                    const int64_t ax = axis < 0 ? axis + (int64_t)r.size() : axis;
+                    if (ax >= 0 && ax < (int64_t)r.size()) {
+                        if (is_scalar(n.in[1])) r.erase(r.begin() + ax);
+                        else r[(size_t)ax] = (int64_t)w.size();
+                        shape[o] = r;
+                    }
+                }
+            } else if (n.op == "Unsqueeze" || n.op == "Squeeze") {
+                if (get_ints(n.in[0], v)) {  // integer tensors stay lists here (rank 0 <-> rank 1)
+                    ints[o] = v;
+                    if (n.op == "Squeeze" && v.size() == 1) int_scalar.insert(o);
+                } else if (a && param_ints(n, "axes", 1, w)) {
+                    std::vector<int64_t> r = *a;
+                    if (n.op == "Unsqueeze") {
+                        std::vector<int64_t> ax = w;
+                        for (auto &x : ax) if (x < 0) x += (int64_t)(r.size() + ax.size());
+                        std::sort(ax.begin(), ax.end());
+                        for (int64_t x : ax) if (x >= 0 && x <= (int64_t)r.size()) r.insert(r.begin() + x, 1);
+                    } else {
+                        std::vector<int64_t> ax = w;
+                        for (auto &x : ax) if (x < 0) x += (int64_t)r.size();
+                        std::sort(ax.rbegin(), ax.rend());
+                        for (int64_t x : ax) if (x >= 0 && x < (int64_t)r.size()) r.erase(r.begin() + x);
+                    }
+                    shape[o] = r;
+                }
+            } else if (n.op == "Cast") {
+                if (get_ints(n.in[0], v)) { ints[o] = v; if (is_scalar(n.in[0])) int_scalar.insert(o); }
+            } else if (n.op == "Concat") {
+                bool all_ints = !n.in.empty();
+                std::vector<int64_t> r;
+                for (auto &in : n.in) {
+                    if (!get_ints(in, v)) { all_ints = false; break; }
+                    r.insert(r.end(), v.begin(), v.end());
+                }
+                if (all_ints) ints[o] = r;
+                else if (a) {
+                    std::vector<int64_t> s = *a;
+                    int64_t axis = n.attr_i("axis", 0);
+                    if (axis < 0) axis += (int64_t)s.size();
+                    bool ok = axis >= 0 && axis < (int64_t)s.size();
+                    for (size_t k = 1; k < n.in.size() && ok; k++) {
+                        const std::vector<int64_t> *b = get_shape(n.in[k]);
+                        if (!b || b->size() != s.size()) { ok = false; break; }
+                        s[(size_t)axis] = s[(size_t)axis] < 0 || (*b)[(size_t)axis] < 0 ? -1 : s[(size_t)axis] + (*b)[(size_t)axis];
+                    }
+                    if (ok) shape[o] = s;
+                }
+            } else if (n.op == "Slice") {
+                std::vector<int64_t> starts, ends, axes, steps;
+                const bool have = param_ints(n, "starts", 1, starts) && param_ints(n, "ends", 2, ends);
+                const bool have_axes = param_ints(n, "axes", 3, axes);
+                param_ints(n, "steps", 4, steps);
+                if (have && get_ints(n.in[0], v)) {  // a slice of an integer tensor (1-D)
+                    if (starts.size() == 1 && (!have_axes || (axes.size() == 1 && axes[0] == 0)) && (steps.empty() || steps[0] == 1)) {
+                        const int64_t len = (int64_t)v.size();
+                        int64_t lo = starts[0] < 0 ? starts[0] + len : starts[0], hi = ends[0] < 0 ? ends[0] + len : ends[0];
+                        lo = std::max<int64_t>(0, std::min(lo, len));
+                        hi = std::max<int64_t>(0, std::min(hi, len));
+                        ints[o] = std::vector<int64_t>(v.begin() + lo, v.begin() + std::max(lo, hi));
+                    }
+                } else if (have && a) {
+                    std::vector<int64_t> r = *a;
+                    bool ok = true;
+                    for (size_t k = 0; k < starts.size() && ok; k++) {
+                        int64_t ax = have_axes ? axes[k] : (int64_t)k;
+                        if (ax < 0) ax += (int64_t)r.size();
+                        const int64_t step = k < steps.size() ? steps[k] : 1;
+                        if (ax < 0 || ax >= (int64_t)r.size() || step != 1) { ok = false; break; }
+                        const int64_t len = r[(size_t)ax];
+                        if (len < 0) continue;  // a slice of the batch axis stays symbolic
+                        int64_t lo = starts[k] < 0 ? starts[k] + len : starts[k], hi = ends[k] < 0 ? ends[k] + len : ends[k];
+                        lo = std::max<int64_t>(0, std::min(lo, len));
+                        hi = std::max<int64_t>(0, std::min(hi, len));
+                        r[(size_t)ax] = std::max<int64_t>(0, hi - lo);
+                    }
+                    if (ok) shape[o] = r;
+                }
+            } else if (n.op == "Conv") {
+                const OTensor *wt = n.in.size() > 1 ? init(n.in[1]) : nullptr;
+                if (a && a->size() == 4 && wt && wt->dims.size() == 4) shape[o] = {(*a)[0], wt->dims[0], (*a)[2], (*a)[3]};
+            } else if (n.op == "Relu" || n.op == "BatchNormalization" || n.op == "Div" || n.op == "Mul" || n.op == "Sub" ||
+                       n.op == "Sigmoid" || n.op == "Tanh" || n.op == "Softmax" || n.op == "Identity" || n.op == "Dropout") {
+                if (a) shape[o] = *a;
+            } else if (n.op == "Add") {
+                const std::vector<int64_t> *b = n.in.size() > 1 ? get_shape(n.in[1]) : nullptr;
+                if (a && (!b || a->size() >= b->size())) shape[o] = *a;
+                else if (b) shape[o] = *b;
+            } else if (n.op == "Flatten") {
+                if (a) {
+                    int64_t axis = n.attr_i("axis", 1);
+                    if (axis < 0) axis += (int64_t)a->size();
+                    if (axis >= 0 && axis <= (int64_t)a->size()) shape[o] = {prod(*a, 0, (size_t)axis), prod(*a, (size_t)axis, a->size())};
+                }
+            } else if (n.op == "Gemm") {
+                const OTensor *wt = n.in.size() > 1 ? init(n.in[1]) : nullptr;
+                if (a && a->size() == 2 && wt && wt->dims.size() == 2) shape[o] = {(*a)[0], wt->dims[n.attr_i("transB", 0) ? 0 : 1]};
+            } else if (n.op == "MatMul") {
+                const OTensor *wt = n.in.size() > 1 ? init(n.in[1]) : nullptr;
+                const std::vector<int64_t> *b = n.in.size() > 1 ? get_shape(n.in[1]) : nullptr;
+                if (a && !a->empty() && wt && wt->dims.size() == 2) { v = *a; v.back() = wt->dims[1]; shape[o] = v; }
+                else if (a && b && a->size() >= 2 && b->size() >= 2) { v = *a; v.back() = b->back(); shape[o] = v; }
+            } else if (n.op == "Transpose") {
+                std::vector<int64_t> perm = n.attr_ints("perm");
+                if (a && perm.size() == a->size()) {
+                    for (int64_t pz : perm) v.push_back(pz >= 0 && pz < (int64_t)a->size() ? (*a)[(size_t)pz] : -1);
+                    shape[o] = v;
+                }
+            } else if (n.op == "Reshape") {
+                if (n.in.size() > 1 && get_ints(n.in[1], w)) {
+                    std::vector<int64_t> r;
+                    int64_t known = 1;
+                    int infer_at = -1;
+                    for (size_t k = 0; k < w.size(); k++) {
+                        int64_t d = w[k];
+                        if (d == 0) d = a && k < a->size() ? (*a)[k] : -1;
+                        else if (d == BATCH) d = -1;
+                        else if (d == -1) { infer_at = (int)k; d = -2; }
+                        r.push_back(d);
+                        if (d > 0) known *= d;
+                    }
+                    if (infer_at >= 0) {
+                        const bool batch_in = a && std::count(a->begin(), a->end(), (int64_t)-1) == 1;
+                        const bool batch_out = std::count(r.begin(), r.end(), (int64_t)-1) == 1;
+                        const int64_t total = a ? prod(*a, 0, a->size()) : -1;
+                        if (a && total > 0 && !batch_out) r[(size_t)infer_at] = total / known;
+                        else if (a && batch_in && batch_out) {  // both carry the batch: the rest must match
+                            int64_t rest = 1;
+                            for (int64_t d : *a) if (d > 0) rest *= d;
+                            r[(size_t)infer_at] = rest / known;
+                        } else r[(size_t)infer_at] = -1;  // the inferred axis is the batch (or unknown)
+                    }
+                    shape[o] = r;
+                }
+            }
+        }
+    }
+
+    // Reshape that flattens everything behind the batch axis -> Flatten(axis = 1); a reshape (or flatten) of a tensor
+    // that has that shape already -> nothing.  Returns true when the graph changed.
+    bool rewrite_reshapes() {
+        for (size_t i = 0; i < g.nodes.size(); i++) {
+            ONode &n = g.nodes[i];
+            if (n.op != "Reshape" && n.op != "Flatten") continue;
+            const std::vector<int64_t> *a = get_shape(n.in[0]);
+            if (n.op == "Flatten") {
+                if (a && a->size() == 2 && n.attr_i("axis", 1) == 1) { bypass(i); return true; }
+                continue;
+            }
+            std::vector<int64_t> t;
+            if (n.in.size() < 2 || !get_ints(n.in[1], t)) continue;
+            const std::vector<int64_t> *o = get_shape(n.out[0]);
+            if (a && o && *a == *o) { bypass(i); return true; }  // e.g. DensePolicyHead's .view(-1, *policy_shape), post_act.py:51
+            if (t.size() != 2) continue;
+            const bool batch_first = t[0] == BATCH || t[0] == 0 || (t[0] == -1 && t[1] > 0);
+            if (!batch_first || (a && (a->size() < 2 || (*a)[0] >= 0))) continue;
+            if (t[1] != -1 && a) {  // an explicit size must be the product of the flattened axes
+                const int64_t rest = prod(*a, 1, a->size());
+                if (rest > 0 && rest != t[1]) continue;
+            }
+            n.op = "Flatten";
+            n.in.resize(1);
+            n.attr.clear();
+            OAttr axis;
+            axis.i = 1;
+            n.attr["axis"] = axis;
+            return true;
+        }
+        return false;
+    }
+
+    // MatMul(x, W [in, out] constant) -> Add(., b [out] constant)  =>  Gemm(x, W, b), transB = 0
+    bool rewrite_matmul_add() {
+        for (size_t i = 0; i < g.nodes.size(); i++) {
+            ONode &mm = g.nodes[i];
+            if (mm.op != "MatMul" || mm.in.size() != 2) continue;
+            const OTensor *w = init(mm.in[1]);
+            if (!w || w->dtype != 1 || w->dims.size() != 2) continue;
+            int users = 0, add_at = -1;
+            for (size_t k = 0; k < g.nodes.size(); k++)
+                for (auto &in : g.nodes[k].in)
+                    if (in == mm.out[0]) { users++; if (g.nodes[k].op == "Add") add_at = (int)k; }
+            if (users != 1 || add_at < 0 || is_output(mm.out[0])) continue;
+            ONode &add = g.nodes[(size_t)add_at];
+            const std::string &other = add.in[0] == mm.out[0] ? add.in[1] : add.in[0];
+            const OTensor *b = init(other);
+            if (!b || b->dtype != 1 || (int64_t)b->f.size() != w->dims[1]) continue;
+            ONode gemm;
+            gemm.op = "Gemm";
+            gemm.in.push_back(mm.in[0]);
+            gemm.in.push_back(mm.in[1]);
+            gemm.in.push_back(other);
+            gemm.out = add.out;
+            g.nodes[(size_t)add_at] = gemm;  // (transB absent = 0; alpha = beta = 1)
+            g.nodes.erase(g.nodes.begin() + (long)i);
+            return true;
+        }
+        return false;
+    }
+
+    // The older output form (value [B], wdl [B, 3], policy) that check_graph_shapes and decode_output still accept
+    // (rust/kz-core/src/network/common.rs:42-49, 186-190) -> the (scalars [B, 5], policy) form: the rows of the scalar
+    // head's last Linear that value and wdl select become rows 0..3 of a [5, hidden] Linear whose fifth row yields NaN —
+    // decode_output's `moves_left = NaN` for such graphs (common.rs:44).  Outputs are taken by position, like the
+    // reference does.
+    void legacy_outputs() {
+        if (g.outputs.size() != 3) return;
+        auto producer_of = [&](const std::string &name) -> ONode * {
+            for (auto &n : g.nodes)
+                for (auto &o : n.out) if (o == name) return &n;
+            return nullptr;
+        };
+        // rows of a Gemm's output a name selects: walks through shape-only nodes to Gather / Slice on axis 1
+        struct Pick { ONode *gemm; std::vector<int64_t> rows; };
+        auto pick = [&](std::string name, size_t want) -> Pick {
+            std::vector<int64_t> rows;
+            bool selected = false;
+            for (int hop = 0; hop < 8; hop++) {
+                ONode *n = producer_of(name);
+                if (!n) break;
+                if (n->op == "Squeeze" || n->op == "Flatten" || n->op == "Reshape" || n->op == "Unsqueeze") { name = n->in[0]; continue; }
+                if (n->op == "Gather" && !selected) {
+                    std::vector<int64_t> idx;
+                    if (n->attr_i("axis", 0) != 1 || !get_ints(n->in[1], idx)) break;
+                    rows = idx;
+                    selected = true;
+                    name = n->in[0];
+                    continue;
+                }
+                if (n->op == "Slice" && !selected) {
+                    std::vector<int64_t> starts, ends, axes, steps;
+                    if (!param_ints(*n, "starts", 1, starts) || !param_ints(*n, "ends", 2, ends) || starts.size() != 1) break;
+                    if (param_ints(*n, "axes", 3, axes) && (axes.size() != 1 || axes[0] != 1)) break;
+                    if (param_ints(*n, "steps", 4, steps) && (steps.size() != 1 || steps[0] != 1)) break;
+                    if (axes.empty()) break;  // (without axes a one-element slice would cut the batch axis)
+                    for (int64_t r = starts[0]; r < std::min<int64_t>(ends[0], starts[0] + 64); r++) rows.push_back(r);
+                    selected = true;
+                    name = n->in[0];
+                    continue;
+                }
+                if (n->op == "Gemm") {
+                    const OTensor *w = n->in.size() > 1 ? init(n->in[1]) : nullptr;
+                    if (!w || w->dims.size() != 2) break;
+                    const int64_t outs = w->dims[n->attr_i("transB", 0) ? 0 : 1];
+                    if (!selected) for (int64_t r = 0; r < outs; r++) rows.push_back(r);
+                    for (auto &r : rows) if (r < 0) r += outs;
+                    for (int64_t r : rows) if (r < 0 || r >= outs) fail("legacy outputs: selected row out of range");
+                    if (rows.size() != want) break;
+                    return Pick{n, rows};
+                }
+                break;
+            }
+            fail("legacy (value, wdl, policy) outputs: '" + name + "' is not " + std::to_string(want) + " row(s) of the scalar head's last Linear");
+        };
+        const Pick value = pick(g.outputs[0], 1), wdl = pick(g.outputs[1], 3);
+        if (value.gemm->in[0] != wdl.gemm->in[0]) fail("legacy outputs: value and wdl do not read the same hidden layer");
+        // [5, hidden] rows: value, wdl x 3, moves_left = NaN
+        Linear rows[2];
+        int hidden = -1;
+        OTensor w5, b5;
+        w5.dtype = b5.dtype = 1;
+        for (const Pick *pk : {&value, &wdl}) {
+            const OTensor *w = init(pk->gemm->in[1]), *b = pk->gemm->in.size() > 2 ? init(pk->gemm->in[2]) : nullptr;
+            if (!w || !b || w->dtype != 1 || b->dtype != 1) fail("legacy outputs: Gemm without constant weights and bias");
+            const bool tb = pk->gemm->attr_i("transB", 0) == 1;
+            const int64_t outs = w->dims[tb ? 0 : 1], in = w->dims[tb ? 1 : 0];
+            if (hidden < 0) hidden = (int)in;
+            if (in != hidden || (int64_t)b->f.size() != outs) fail("legacy outputs: Linear shapes");
+            for (int64_t r : pk->rows) {
+                for (int64_t i = 0; i < in; i++) w5.f.push_back(tb ? w->f[(size_t)(r * in + i)] : w->f[(size_t)(i * outs + r)]);
+                b5.f.push_back(b->f[(size_t)r]);
+            }
+        }
+        w5.f.insert(w5.f.end(), (size_t)hidden, 0.0f);
+        b5.f.push_back(std::nanf(""));
+        w5.dims = {5, hidden};
+        b5.dims = {5};
+        w5.name = "kz.legacy.scalars.weight";
+        b5.name = "kz.legacy.scalars.bias";
+        ONode gemm;
+        gemm.op = "Gemm";
+        gemm.in.push_back(value.gemm->in[0]);
+        gemm.in.push_back(w5.name);
+        gemm.in.push_back(b5.name);
+        gemm.out.push_back("scalars");
+        OAttr one;
+        one.i = 1;
+        gemm.attr["transB"] = one;
+        g.init[w5.name] = std::move(w5);
+        g.init[b5.name] = std::move(b5);
+        g.nodes.push_back(gemm);
+        const std::string policy = g.outputs[2];
+        if (policy != "policy") {
+            ONode *pp = producer_of(policy);
+            if (!pp) fail("legacy outputs: nothing produces the policy");
+            for (auto &o : pp->out) if (o == policy) o = "policy";
+            replace_uses(policy, "policy");
+        }
+        g.outputs = {"scalars", "policy"};
+    }
+
+    void rebuild_index() {
+        g.producer.clear();
+        g.consumers.clear();
+        for (size_t i = 0; i < g.nodes.size(); i++) {
+            for (auto &o : g.nodes[i].out) g.producer[o] = (int)i;
+            for (auto &in : g.nodes[i].in) g.consumers[in].push_back((int)i);
+        }
+    }
+
+    void run() {
+        absorb_constants();
+        bypass_noops();
+        for (int guard = 0; guard < 10000; guard++) {
+            infer();
+            if (!rewrite_reshapes() && !rewrite_matmul_add()) break;
+        }
+        legacy_outputs();
+        // the folded integer tensors are constants from here on (e.g. the shape ConstantOfShape reads)
+        for (auto &kv : ints) {
+            if (g.init.count(kv.first)) continue;
+            bool symbolic = false;
+            for (int64_t v : kv.second) symbolic |= v == BATCH;
+            if (symbolic) continue;
+            OTensor t;
+            t.name = kv.first;
+            t.dtype = 7;
+            t.i = kv.second;
+            if (!int_scalar.count(kv.first)) t.dims = {(int64_t)t.i.size()};
+            g.init[t.name] = std::move(t);
+        }
+        rebuild_index();
+    }
+};
+
 struct Matcher {
     const OGraph &g;
 
@@ -326,14 +822,22 @@ struct Matcher {
     }
     Linear gemm(const ONode &n) const {
         if (n.op != "Gemm" || n.in.size() != 3) fail("expected Gemm with bias");
-        if (n.attr_i("transB", 0) != 1 || n.attr_i("transA", 0) != 0 || n.attr_f("alpha", 1.f) != 1.f || n.attr_f("beta", 1.f) != 1.f)
-            fail("Gemm must be x * W^T + b");
+        if (n.attr_i("transA", 0) != 0 || n.attr_f("alpha", 1.f) != 1.f || n.attr_f("beta", 1.f) != 1.f)
+            fail("Gemm must be x * W^T + b (or x * W + b)");
         const OTensor &w = constant(n.in[1]);
         if (w.dtype != 1 || w.dims.size() != 2) fail("Gemm weight must be 2-D");
         Linear l;
-        l.out = (int)w.dims[0];
-        l.in = (int)w.dims[1];
-        l.w = w.f;
+        if (n.attr_i("transB", 0) == 1) {  // nn.Linear's own layout [out, in]
+            l.out = (int)w.dims[0];
+            l.in = (int)w.dims[1];
+            l.w = w.f;
+        } else {  // [in, out]: MatMul + Add, or an exporter that transposes the weight
+            l.in = (int)w.dims[0];
+            l.out = (int)w.dims[1];
+            l.w.resize(w.f.size());
+            for (int o = 0; o < l.out; o++)
+                for (int i = 0; i < l.in; i++) l.w[(size_t)o * l.in + i] = w.f[(size_t)i * l.out + o];
+        }
         l.b = floats(n.in[2], (size_t)l.out);
         return l;
     }
@@ -360,6 +864,7 @@ bool looks_like_onnx(const void *blob, size_t len) {
 Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err) {
     try {
         OGraph g = read_model(blob, len);
+        Normalizer{g}.run();
         Matcher M{g};
         std::unique_ptr<Model> m(new Model());
 
@@ -377,8 +882,8 @@ Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err) 
         m->n_bool = n_scalar < 0 ? -1 : m->c_in - n_scalar;
         bool has_scalars = false, has_policy = false;
         for (auto &o : g.outputs) { has_scalars |= o == "scalars"; has_policy |= o == "policy"; }
-        if (g.outputs.size() != 2 || !has_scalars || !has_policy) fail("outputs must be 'scalars' and 'policy' (legacy (value, wdl, policy) graphs, network/common.rs:36-45, "
-                                                                        "are not taken: re-export with save_onnx.py)");
+        if (g.outputs.size() != 2 || !has_scalars || !has_policy)
+            fail("outputs must be ('scalars', 'policy'), or three outputs (value, wdl, policy) in that order (network/common.rs:36-49)");
         const int hw = m->h * m->w;
 
         // ---- ResTower (post_act.py:201-228) ----

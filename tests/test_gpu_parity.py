@@ -99,6 +99,38 @@ def test_packed_input(dev, name, dtype):
         assert np.abs(softmax(p) - softmax(p_gold)).max() < 5e-3
 
 
+import json as _json
+
+ONNX_VARIANTS = _json.load(open(os.path.join(O.GOLDEN, "onnx_variants", "manifest.json")))
+
+
+@pytest.mark.parametrize("entry", ONNX_VARIANTS, ids=lambda m: f"{m['net']}.{m['variant']}")
+def test_onnx_variants_match_golden(dev, entry):
+    """N1 beyond one exporter (oracle/gen_onnx_variants.py: other opsets and export settings, rewritten graphs): every
+    variant of a golden network gives the reference PyTorch outputs (<= 1e-4, f32).  The legacy (value, wdl, policy) output
+    form (rust/kz-core/src/network/common.rs:42-49) comes back as scalars [B, 5] with moves_left = NaN — what decode_output
+    makes of such a graph — here and through the device-side decode."""
+    name = entry["net"]
+    net = O.OracleNet(O.load_blob(name))
+    _, s_gold, p_gold = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
+    bits, scalars_in = O.read_packed(name, net.n_bool, net.n_scalar, net.h, net.w)
+    path = os.path.join(O.GOLDEN, "onnx_variants", entry["file"])
+    eng = capi.Engine(capi.Model(path=path, onnx_scalar_channels=entry["scalar_planes"]), dev, 4, capi.KZ_DTYPE_F32)
+    s, p = eng.eval_packed(bits, scalars_in)
+    assert_f32(p, p_gold, "policy")
+    if entry["variant"] != "legacy3":
+        assert_f32(s, s_gold, "scalars")
+        return
+    assert_f32(s[:, :4], s_gold[:, :4], "value and wdl logits")
+    assert np.isnan(s[:, 4]).all(), "legacy graphs have no moves_left: NaN (common.rs:44)"
+    moves = [list(range(0, net.policy_len, 7)) for _ in range(len(bits))]
+    values, probs = eng.eval_packed_decoded(bits, scalars_in, moves)
+    v_ref, p_ref = O.decode_output(s_gold, p_gold, moves)
+    assert np.abs(values[:, :4] - v_ref[:, :4]).max() < 1e-5 and np.isnan(values[:, 4]).all()
+    for a, b in zip(probs, p_ref):
+        assert np.abs(a - b).max() < 1e-5
+
+
 @pytest.mark.parametrize("name,n_scalar", [("ataxx7_2x16", 1), ("chess_2x32_att", 8), ("chess_2x32_dense_h", 8),
                                            ("go9_2x16_conv_terr", 6)])
 def test_onnx_models_match_golden(dev, name, n_scalar):

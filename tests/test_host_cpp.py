@@ -35,6 +35,19 @@ def test_host_mirror_cpu_thread_sanitizer():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_bench_executor_chess_helpers():
+    """The stand-ins bench_executor uses for the host work of a chess evaluation (pseudo-legal move generation, the
+    SipHash-keyed move map of chess.rs:202-210): every generated move is one of the 1880 flat moves and both lookups agree."""
+    exe = _build("test_bench_chess.cpp", "test_bench_chess_asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0 and "bench chess tests ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_executor_compiles_against_the_c_abi():
+    lib = os.path.join(REPO, "kzero_amd")
+    _build("bench_executor.cpp", "bench_executor_check", [f"-L{lib}", "-lkzhip", f"-Wl,-rpath,{lib}"])
+
+
 def test_hip_network_test_compiles_against_the_c_abi():
     """The GPU test links only against libkzhip.so's C ABI (include/kz_hip.h): no torch, no HIP headers."""
     _build("test_hip_network.cpp", "test_hip_network",

@@ -131,5 +131,5 @@ def test_integration_md_lists_every_edited_reference_line():
     text = open(os.path.join(REPO, "INTEGRATION.md")).read()
     for cite in ("server_alphazero.rs:39-123", "load_network", "server.rs:16", "server.rs:47-53", "server.rs:105", "server.rs:207", "server.rs:249", "server.rs:293",
                  "server.rs:306", "server_alphazero.rs:7", "server_alphazero.rs:35", "server_muzero.rs:26",
-                 "type Device", "KZ_HIP_DTYPE", "Legacy three-output graphs are rejected"):
+                 "type Device", "KZ_HIP_DTYPE", "Legacy three-output graphs are taken"):
         assert cite in text, f"INTEGRATION.md does not mention {cite}"
