@@ -171,8 +171,14 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
     """The CPU restatement (oracle, kind 'port') timed on this box's host cores, on a bounded sample of the same
     boards.  Reported beside the GPU number; never the thing measured as `value`."""
     from tests import oracle_lib as O
+    if hasattr(os, "sched_setaffinity") and FULL_AFFINITY:
+        try:
+            os.sched_setaffinity(0, FULL_AFFINITY)  # (this process bound itself to its GPU's NUMA node for the timed regions)
+        except OSError:
+            pass
     net = O.OracleNet(blob)
     cores = usable_cores()
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
     t0 = time.perf_counter()
     net.forward(dense[:1], threads=1)
@@ -185,8 +191,9 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 3), "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{n} boards of the same synthetic batch, oracle/kz_oracle.c f32 NCHW direct conv, "
-                      f"OpenMP over boards on {cores} threads (of {os.cpu_count()} the machine reports), {dt:.1f} s; "
-                      f"single-thread {1.0 / one:.3f} evals/s"}
+                      f"OpenMP over boards on {cores} threads = the container's CPU quota (cgroup cpu.max; the affinity mask "
+                      f"allows {affinity}, the machine reports {os.cpu_count()}: a whole socket is not this process's to "
+                      f"use), {dt:.1f} s; single-thread {1.0 / one:.3f} evals/s"}
 
 
 def committed_traffic(kernel: str, workload: str, batch: int):
@@ -314,6 +321,26 @@ class Workload:
             return 2.0 * hw * 9 * C * C * B  # one launch per 3x3 tower convolution (split16: algorithmic FLOP, a third of the executed)
         return info.flops_per_eval * B / max(launches_per_step, 1)  # per-layer launches: average over the step
 
+    def algorithmic_bytes_per_launch(self):
+        """What one launch of the dominant kernel must move at least: its weights once, its inputs and its outputs
+        (DESIGN.md §8).  One-launch paths: the weight stream + packed boards in + (scalars, policy) out.  Per-layer board
+        paths: the activation tensor in and out, the residual on every other layer, one layer's weights."""
+        info, B = self.info, self.B
+        hw, C = info.board_h * info.board_w, info.tower_channels
+        wbytes = {"f16": 2, "f32": 4, "f32split16": 4}[self.dtype_name]  # (split16: a (hi, lo) f16 pair per weight)
+        p = self.tower_path
+        io = B * (self.stride + 4 * info.input_scalar_channels + 4 * (5 + info.policy_len))
+        if p.endswith("+heads"):
+            return int(info.param_count * wbytes + io)
+        tower_params = 9 * C * (info.input_channels + 2 * info.tower_depth * C)
+        if p.startswith("tower_resident"):
+            act = B * hw * C * (4 if self.dtype_name != "f16" else 2)  # the tower output written for the head kernels
+            return int(tower_params * wbytes + B * (self.stride + 4 * info.input_scalar_channels) + act)
+        if p in ("board_conv_f16", "board_conv_split16"):
+            act = B * hw * C * (2 if p == "board_conv_f16" else 4)
+            return int(2.5 * act + 9 * C * C * wbytes)
+        return None
+
     def roofline(self, k_ms, k_n, steps, evals_per_s_per_gpu):
         peak = 157.3 if self.dtype_name == "f32" else 2500.0  # f32split16: algorithmic FLOP against the f16 matrix cores
         avg_ms = k_ms / max(k_n, 1)
@@ -321,18 +348,24 @@ class Workload:
         achieved = fpl / (avg_ms * 1e-3) / 1e12 if k_n else 0.0
         wgs, per = self.engines[0].launch_geometry(self.B)
         traffic, source = committed_traffic(self.kernel, self.name, self.B)
-        # `achieved`/`frac` follow the contract literally: algorithmic FLOP of ONE launch / its average duration.  A
-        # resident launch covers `workgroups_per_launch` of the 256 CUs and `concurrent_launches` run side by side, so
-        # the chip-level figure is `chip_frac` (all engines' FLOP / wall time), not `frac`.
-        return {"bound": "mfma", "kernel": self.kernel, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
+        alg_bytes = self.algorithmic_bytes_per_launch()
+        # `achieved` / `frac` are the CHIP's: the algorithmic FLOP of all launches running side by side / wall time /
+        # peak — a resident launch covers `workgroups_per_launch` of the 256 CUs and `concurrent_launches` of them run
+        # at once, so one launch's own rate (`launch_achieved` = its FLOP / its average duration, `launch_frac`) is a half
+        # or a third of what the chip does.  `traffic` = HBM-side bytes of one launch from the committed PMC passes,
+        # `traffic_ratio` = traffic / the launch's algorithmic bytes (weights once + what it must read and write).
+        chip = evals_per_s_per_gpu * self.info.flops_per_eval / 1e12
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": round(chip, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(chip / peak, 4), "launch_achieved": round(achieved, 2), "launch_frac": round(achieved / peak, 4),
+                "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic_ratio": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,
                 "avg_launch_ms": round(avg_ms, 5), "launches": k_n, "flop_per_launch": fpl,
                 "launch_timing": ("HIP events around every launch of an instrumented pass behind the timed steps (per-layer path: "
                                   "events around each of its ~85 launches per batch cost 1.7 % of the rate)") if self.per_layer
                 else "HIP events around every launch of the timed steps",
                 "workgroups_per_launch": wgs, "boards_per_workgroup": per or None,
                 "concurrent_launches": len(self.engines),
-                "chip_frac": round(evals_per_s_per_gpu * self.info.flops_per_eval / 1e12 / peak, 4)}
+                "chip_frac": round(chip / peak, 4)}
 
     def close(self):
         self.sync()
@@ -382,44 +415,88 @@ def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm):
         w.close()
 
 
-def seam_record(blob, seconds, devices=(0,)):
+# The seam configurations of the default line.  `work` = what the executor thread does besides submit / wait
+# (tests/cpp/bench_executor.cpp): "real" = what kzero_amd/rust/hip.rs does — ChessStdMapper::encode_input at submit and,
+# per board, a fresh move generation and a SipHash map lookup per move (chess.rs:202-210), at submit with the softmax on
+# the GPU (device_decode 1) or at decode with the softmax on the thread (0: the reference's decode_output);
+# "pre" = the generators computed the policy indices (move generation + lookups on their threads) and the GPU decodes;
+# "packed" = pre-packed boards and move lists: the channel and PCIe alone (what rounds 1-3 reported as `seam`).
+SEAM_CONFIGS = [
+    dict(name="hip.rs default (KZ_HIP_DECODE=device): move lists built on the executor thread at submit, softmax on the GPU; "
+              "one executor thread", work="real", gpu_threads=1, depth=3, device_decode=1),
+    dict(name="KZ_HIP_DECODE=host (the reference's decode_output on the executor thread), one executor thread", work="real",
+         gpu_threads=1, depth=3, device_decode=0),
+    dict(name="KZ_HIP_DECODE=host, gpu_threads_per_device = 4", work="real", gpu_threads=4, depth=2, device_decode=0),
+    dict(name="policy indices computed by the generators and carried in the job, decode on the GPU, one executor thread",
+         work="pre", gpu_threads=1, depth=3, device_decode=1),
+    dict(name="channel and PCIe alone (pre-packed boards and move lists: what rounds 1-3 reported)", work="packed",
+         gpu_threads=1, depth=3, device_decode=0),
+]
+
+
+def bench_executor_exe():
+    exe = os.path.join(REPO, "tests", "cpp", "build", "bench_executor")
+    srcs = [os.path.join(REPO, "tests", "cpp", n) for n in ("bench_executor.cpp", "bench_chess.hpp")]
+    lib_dir = os.path.join(REPO, "kzero_amd")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(x) for x in srcs):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", srcs[0], "-o", exe, f"-L{lib_dir}", "-lkzhip",
+                               f"-Wl,-rpath,{lib_dir}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    return exe
+
+
+def seam_run(exe, model_path, seconds, cfg, dtype, devices):
+    env = dict(os.environ)
+    if len(devices) > 1:
+        env["KZ_BENCH_FULL_AFFINITY"] = "1"  # (this process bound itself to ONE GPU's NUMA node; the child drives several)
+    out = subprocess.run([exe, model_path, str(seconds), str(cfg["gpu_threads"]), "6", "256", "8", dtype, str(cfg["depth"]),
+                          str(cfg["device_decode"]), ",".join(str(d) for d in devices), cfg["work"]],
+                         capture_output=True, text=True, timeout=120, env=env)
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    return {"config": cfg["name"], "work": cfg["work"], "value": rec["evals_per_s"], "unit": "evals/s", "fill": rec["fill"],
+            "executor_threads": rec["gpu_threads"], "pipeline_depth": rec["pipeline_depth"], "device_decode": rec["device_decode"],
+            "generator_threads": rec["generator_threads"], "concurrent_games": rec["concurrent_games"],
+            "gpu_batch": rec["gpu_batch"], "search_batch": rec["search_batch"], "seconds": rec["seconds"],
+            # executor_work_util = CPU time outside kz_engine_wait* / wall (the HIP runtime polls inside the wait: an executor
+            # thread shows ~100 % CPU however little work it does)
+            "executor_work_util": rec["executor_work_util"], "executor_work_util_max": rec["executor_work_util_max"],
+            "executor_cpu_util": rec["executor_cpu_util"], "generator_cpu_util": rec["generator_cpu_util"],
+            "host_cpu_s_per_Meval": rec["host_cpu_s_per_Meval"], "executor_work_s_per_Meval": rec["executor_work_s_per_Meval"],
+            "executor_cpu_s_per_Meval": rec["executor_cpu_s_per_Meval"], "generator_cpu_s_per_Meval": rec["generator_cpu_s_per_Meval"],
+            "projection_8gpu": rec["projection_8gpu"], "devices": rec.get("devices"),
+            "per_device_evals_per_s": rec.get("per_device_evals_per_s")}
+
+
+def seam_record(blob, seconds, devices=(0,), dtype="f16", configs=None):
     """BASELINE configs[2] as the reference runs it: generator threads -> job channel -> executor loop
-    (`RunCondition::JobCount`, sizing of server_alphazero.rs:47-55) -> `HipNetwork::evaluate_batch` (host encode, the
-    engine over PCIe, host decode_output) -> replies, counted like the collector's `real` evals/s.  The host side is the
-    C++ mirror of the Rust seam (tests/cpp/bench_executor.cpp over kzero_amd/csrc/host/): one pipelined executor thread
-    with three batches in flight, search_batch 8 (the record carries the number of concurrent games the sizing rule
-    gives).  Built with g++ on first
-    use; any failure here is reported in the record, it never fails the bench."""
+    (`RunCondition::JobCount`, sizing of server_alphazero.rs:47-55) -> `HipNetwork` (host encode, the engine over PCIe,
+    decode_output) -> replies, counted like the collector's `real` evals/s, with the host work of the Rust shim ON the
+    threads that will do it (SEAM_CONFIGS) and every thread's CPU utilisation in the record.  The host side is the C++
+    mirror of the Rust seam (tests/cpp/bench_executor.cpp over kzero_amd/csrc/host/), search_batch 8 (the record carries
+    the number of concurrent games the sizing rule gives).  The first configuration is the record's own `value`, the
+    others sit in `variants`.  Built with g++ on first use; any failure here is reported in the record, it never fails
+    the bench."""
     try:
-        exe = os.path.join(REPO, "tests", "cpp", "build", "bench_executor")
-        src = os.path.join(REPO, "tests", "cpp", "bench_executor.cpp")
-        lib_dir = os.path.join(REPO, "kzero_amd")
-        if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
-            os.makedirs(os.path.dirname(exe), exist_ok=True)
-            subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", src, "-o", exe, f"-L{lib_dir}", "-lkzhip",
-                                   f"-Wl,-rpath,{lib_dir}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        exe = bench_executor_exe()
         path = os.path.join("/tmp", f"kz_bench_seam_{os.getpid()}.kzm")
         with open(path, "wb") as f:
             f.write(blob)
-        # (the child drives every listed device: it gets the affinity this process had before it bound itself to its own
-        # GPU's NUMA node)
-        def unbind():
-            if hasattr(os, "sched_setaffinity"):
-                os.sched_setaffinity(0, FULL_AFFINITY)
         try:
-            out = subprocess.run([exe, path, str(seconds), "1", "6", "256", "8", "f16", "3", "0",
-                                  ",".join(str(d) for d in devices)], capture_output=True, text=True, timeout=120,
-                                 preexec_fn=unbind if len(devices) > 1 else None)
+            runs = []
+            for cfg in (configs or SEAM_CONFIGS):
+                try:
+                    runs.append(seam_run(exe, path, seconds, cfg, dtype, devices))
+                except Exception as ex:  # noqa: BLE001
+                    runs.append({"config": cfg["name"], "error": f"{type(ex).__name__}: {ex}"[:300]})
         finally:
             os.unlink(path)
-        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-        return {"metric": "NN evals/sec through generators -> job channel -> executor loop -> PCIe -> replies",
-                "value": rec["evals_per_s"], "unit": "evals/s", "fill": rec["fill"],
-                "executor_threads": rec["gpu_threads"], "pipeline_depth": rec["pipeline_depth"],
-                "generator_threads": rec["generator_threads"], "concurrent_games": rec["concurrent_games"],
-                "gpu_batch": rec["gpu_batch"], "search_batch": rec["search_batch"], "seconds": rec["seconds"],
-                "devices": rec.get("devices"), "per_device_evals_per_s": rec.get("per_device_evals_per_s"),
-                "host": "C++ mirror of the Rust seam (kzero_amd/csrc/host), tests/cpp/bench_executor.cpp"}
+        head = dict(runs[0])
+        head["metric"] = ("NN evals/sec through generators -> job channel -> executor loop -> PCIe -> replies, host work of the "
+                          f"Rust shim on the executor thread, {dtype}")
+        head["dtype"] = dtype
+        head["variants"] = runs[1:]
+        head["host"] = "C++ mirror of the Rust seam (kzero_amd/csrc/host), tests/cpp/bench_executor.cpp"
+        return head
     except Exception as ex:  # noqa: BLE001 (diagnostic record only)
         return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
@@ -586,12 +663,21 @@ def main():
                 out["others"].append({"workload": n, "dtype": d, "error": f"{type(ex).__name__}: {ex}"[:300]})
     if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
         out["seam"] = seam_record(blob, args.seam_seconds)
+        # ... and at the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity -> split16 for this network)
+        out["seam_parity"] = seam_record(blob, args.seam_seconds, dtype="f32split16", configs=SEAM_CONFIGS[:2] + SEAM_CONFIGS[3:4])
     if world > 1:
         dist.barrier()  # every rank has closed its engines
         if args.is_default_line and not args.no_seam and not args.no_others:
             # the topology the reference and the Rust drop-in use: ONE process, a thread set per device
-            # (rust/kz-selfplay/src/server/server.rs:323-331) over every GPU this rank can see
-            out["seam_one_process"] = seam_record(blob, args.seam_seconds, devices=list(range(ndev)))
+            # (rust/kz-selfplay/src/server/server.rs:323-331) over exactly the GPUs the ranks of this run drove
+            drove = [r["device"] for r in per_rank]
+            if ndev >= world and len(set(drove)) == world:
+                rec = seam_record(blob, args.seam_seconds, devices=drove, configs=SEAM_CONFIGS[:1])
+                rec["metric"] = rec.get("metric", "seam") + f", one process over devices {drove}"
+                out["seam_one_process"] = rec
+            else:
+                out["seam_one_process"] = {"skipped": f"ranks see {ndev} GPU(s) each (masked visibility): rank 0 cannot drive "
+                                                      f"the other ranks' devices from one process"}
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(blob, bits, scalars_in, args.cpu_seconds)

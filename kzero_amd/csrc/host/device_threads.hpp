@@ -49,13 +49,15 @@ struct EvalCounters {
     // after every batch — what tells whether one executor thread keeps up with its GPU
     static constexpr size_t MAX_EXECUTORS = 16;
     std::atomic<uint64_t> executor_cpu_ns[MAX_EXECUTORS] = {};
+    // ... of which inside the engine's wait calls (the HIP runtime polls: spinning, not work)
+    std::atomic<uint64_t> executor_wait_ns[MAX_EXECUTORS] = {};
 };
 
-inline uint64_t thread_cpu_ns() {
-    timespec ts{};
-    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
-    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
-}
+// (has `wait_cpu_ns`: HipNetwork; the tests' fake networks do not)
+template <class T, class = void>
+struct has_wait_cpu_ns : std::false_type {};
+template <class T>
+struct has_wait_cpu_ns<T, std::void_t<decltype(std::declval<const T &>().wait_cpu_ns)>> : std::true_type {};
 
 // Net: the network an executor thread builds from a graph, `Net(mapper, graph, max_batch, device, dtype)` with
 // evaluate_batch / submit_batch / wait_batch / set_device_decode / max_in_flight (HipNetwork<B, M>; the tests put a fake
@@ -101,11 +103,14 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
                 net.set_device_decode(device_decode);
                 return net;
             };
-            auto count = [=](size_t n) {
+            auto count = [=](size_t n, const Net &net) {
                 if (counters) {
                     counters->real += n;  // ExpandEvals(real = x.len(), potential = gpu_batch_size) (:113-115)
                     counters->potential += gpu_batch_size;
-                    if (local_id < EvalCounters::MAX_EXECUTORS) counters->executor_cpu_ns[local_id] = thread_cpu_ns();
+                    if (local_id < EvalCounters::MAX_EXECUTORS) {
+                        counters->executor_cpu_ns[local_id] = thread_cpu_ns();
+                        if constexpr (has_wait_cpu_ns<Net>::value) counters->executor_wait_ns[local_id] = net.wait_cpu_ns;
+                    }
                 }
             };
             const RunCondition cond = RunCondition::job_count(sizing.eval_job_count);
@@ -113,7 +118,7 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
                 batched_executor_loop<Graph, Net, B, ZeroEvaluation>(
                     gpu_batch_size, cond, std::move(rx), std::move(srv), load, [=](Net &net, const B *x, size_t n) {
                         auto y = net.evaluate_batch(x, n);
-                        count(n);
+                        count(n, net);
                         return y;
                     });
             } else {
@@ -122,7 +127,7 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
                     std::move(srv), load, [](Net &net, B *x, size_t n) { net.submit_batch(x, n); },
                     [=](Net &net) {
                         auto y = net.wait_batch();
-                        count(y.size());
+                        count(y.size(), net);
                         return y;
                     });
             }

@@ -8,6 +8,8 @@
 #include <string>
 #include <type_traits>
 
+#include <time.h>
+
 #include "../../../include/kz_hip.h"
 #include "mapping.hpp"
 #include "network.hpp"
@@ -21,6 +23,14 @@ template <class T, class = void>
 struct has_policy_indices : std::false_type {};
 template <class T>
 struct has_policy_indices<T, std::void_t<decltype(std::declval<const T &>().policy_indices())>> : std::true_type {};
+
+// CPU time of the calling thread (measurement: how much of an executor thread's time is work, how much is the HIP
+// runtime spinning in kz_engine_wait*)
+inline uint64_t thread_cpu_ns() {
+    timespec ts{};
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 
 inline void kz_check(int rc) {
     if (rc != 0) throw std::runtime_error(std::string("kzhip: ") + kz_last_error());  // the reference panics
@@ -114,6 +124,9 @@ class HipNetwork : public Network<B> {
     }
 
   public:
+    // CPU time this thread has spent inside kz_engine_wait* so far: the HIP runtime polls the event, so an executor
+    // thread shows ~100 % CPU however little work it does; (thread CPU - this) is its work
+    uint64_t wait_cpu_ns = 0;
     // cudnn.rs:29-43 (check_graph_shapes: common.rs:165-198)
     HipNetwork(M mapper, std::shared_ptr<const HipModel> model, size_t max_batch_size, int device, int dtype)
         : mapper_(mapper), model_(std::move(model)), max_batch_size_(max_batch_size) {
@@ -130,7 +143,7 @@ class HipNetwork : public Network<B> {
     HipNetwork(HipNetwork &&o) noexcept
         : mapper_(o.mapper_), model_(std::move(o.model_)), engine_(o.engine_), max_batch_size_(o.max_batch_size_),
           bits_(std::move(o.bits_)), scalars_in_(std::move(o.scalars_in_)), next_slot_(o.next_slot_),
-          oldest_slot_(o.oldest_slot_), in_flight_(o.in_flight_), device_decode_(o.device_decode_) {
+          oldest_slot_(o.oldest_slot_), in_flight_(o.in_flight_), device_decode_(o.device_decode_), wait_cpu_ns(o.wait_cpu_ns) {
         for (int i = 0; i < KZ_ENGINE_SLOTS; i++) {
             pending_boards_[i] = std::move(o.pending_boards_[i]);
             move_offsets_[i] = std::move(o.move_offsets_[i]);
@@ -160,13 +173,17 @@ class HipNetwork : public Network<B> {
             const float *values = nullptr, *probs = nullptr;
             kz_check(kz_engine_submit_packed_decoded(engine_, 0, bits_.data(), bits_bytes, scalars_in_.data(), (int)n,
                                                      move_offsets_[0].data(), move_indices_.data()));
+            const uint64_t w0 = thread_cpu_ns();
             kz_check(kz_engine_wait_decoded(engine_, 0, &values, &probs));
+            wait_cpu_ns += thread_cpu_ns() - w0;
             return assemble_decoded(n, move_offsets_[0], values, probs);
         }
         // kz_engine_eval_packed without its copy into caller buffers: decode reads the pinned staging directly
         const float *scalars = nullptr, *policy = nullptr;
         kz_check(kz_engine_submit_packed(engine_, 0, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
+        const uint64_t w0 = thread_cpu_ns();
         kz_check(kz_engine_wait_view(engine_, 0, &scalars, &policy));
+        wait_cpu_ns += thread_cpu_ns() - w0;
         return decode_output(mapper_, boards, n, scalars, policy);
     }
 
@@ -202,12 +219,16 @@ class HipNetwork : public Network<B> {
         in_flight_--;
         if (device_decode_) {
             const float *values = nullptr, *probs = nullptr;
+            const uint64_t w0 = thread_cpu_ns();
             kz_check(kz_engine_wait_decoded(engine_, slot, &values, &probs));
+            wait_cpu_ns += thread_cpu_ns() - w0;
             return assemble_decoded(move_offsets_[slot].size() - 1, move_offsets_[slot], values, probs);
         }
         // decode straight from the engine's pinned staging (valid until the next submit on this slot)
         const float *scalars = nullptr, *policy = nullptr;
+        const uint64_t w0 = thread_cpu_ns();
         kz_check(kz_engine_wait_view(engine_, slot, &scalars, &policy));
+        wait_cpu_ns += thread_cpu_ns() - w0;
         const std::vector<B> &boards = pending_boards_[slot];
         return decode_output(mapper_, boards.data(), boards.size(), scalars, policy);
     }

@@ -194,7 +194,19 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // one chunk, the input have the same ld), or -1 for a padding row: 32-bit offsets on a uniform base keep the twelve
     // addresses in twelve registers.  The image rows (where a piece goes in LDS) are not kept across the k-loops — 12
     // registers the loop needs: they sit in LDS behind the image, 768 bytes, and are read back at every chunk boundary.
-    int po[12];
+    // (SPLIT: the twelve offsets do not fit the registers next to 96 accumulators, the ring and three MFMA steps' worth of
+    // fragments — the round-3 build spilled them and reloaded four of them from scratch inside every chunk's last k-steps,
+    // each reload behind an s_waitcnt vmcnt(0) that drained the weight ring.  They sit in LDS instead, one row offset per
+    // tile row behind the image-row table, read back with the LDS counter where they are needed.)
+    int po[SPLIT ? 1 : 12];
+    auto po_of = [&](int i) __attribute__((always_inline)) -> int {
+        if constexpr (SPLIT) {
+            const int base = *reinterpret_cast<const int *>(lds + a.rm_off + ROWS * 2 + ((tid >> 3) + i * 32) * 4);
+            return base < 0 ? -1 : base + piece * 16;
+        } else {
+            return po[i];
+        }
+    };
     u32x4 v0[12];  // chunk 0
     int irow0[12];
 #pragma unroll
@@ -205,9 +217,17 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
         // (SPLIT: a row is [hi 32 | lo 32] per group of 32 channels — a chunk is again 128 contiguous bytes, pieces 0..3 its
         // hi halves, 4..7 its lo halves, and the same offsets serve input, residual and output)
-        po[i] = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
+        const int po_i = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
+        if constexpr (!SPLIT) po[i] = po_i;
         v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
-        if (piece == 0) *reinterpret_cast<unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2) = (unsigned short)irow;
+        if (piece == 0) {
+            // (SPLIT: a padding row is marked in the table itself — there is no po[i] to ask)
+            *reinterpret_cast<unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2) = SPLIT && !ok ? (unsigned short)0xffff : (unsigned short)irow;
+            if constexpr (SPLIT) *reinterpret_cast<int *>(lds + a.rm_off + ROWS * 2 + ((tid >> 3) + i * 32) * 4) = po_i;  // (piece 0: the row's own offset)
+        }
+        if constexpr (SPLIT) {
+            if (!ok) irow0[i] = -1;
+        }
     }
 
 #ifndef KZ_BC_REALTIME
@@ -288,7 +308,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     KZ_STAMP(2);
 #pragma unroll
     for (int i = 0; i < 12; i++)
-        if (po[i] >= 0) *reinterpret_cast<u32x4 *>(lds + irow0[i] * PRS + ls_piece) = v0[i];
+        if (SPLIT ? irow0[i] >= 0 : po[SPLIT ? 0 : i] >= 0) *reinterpret_cast<u32x4 *>(lds + irow0[i] * PRS + ls_piece) = v0[i];
     KZ_STAMP(3);
     for (int chunk = 0; chunk < chunks; chunk++) {
         __syncthreads();  // the chunk is staged
@@ -374,7 +394,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                     static_assert(NTW == 4 && PF == 3, "12 pieces = PF stages x NTW registers");
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++)
-                        wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po[jj * 4 + nt], tsoff, 0));
+                        wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po_of(jj * 4 + nt), tsoff, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (stage_done) g++;
@@ -391,7 +411,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
             KZ_STAMP(6 + (chunk & 3) * 4);
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                if (po[i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * PRS + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
+                if (SPLIT ? erow[i] != 0xffff : po[SPLIT ? 0 : i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * PRS + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
 #pragma unroll
             for (int st = 0; st < PF; st++)
 #pragma unroll
@@ -422,23 +442,25 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 if (pass == 0) {
 #pragma unroll
                     for (int i = 0; i < 12; i++)
-                        wreg[i / NTW][i % NTW] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, po[i], nquarter * OCW * 4 + 128, 0));
+                        wreg[i / NTW][i % NTW] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, po_of(i), nquarter * OCW * 4 + 128, 0));
                 }
                 __syncthreads();
             }
-            u32x2 rh[NH][MTW], rl[NH][MTW];
-            if (with_res) {
 #pragma unroll
-                for (int n2 = 0; n2 < NH; n2++)
+            for (int n2 = 0; n2 < NH; n2++) {
+                // the residual pieces of this 16-channel tile: all six tile rows are read before the first one is rewritten
+                // (one LDS round trip per tile instead of six), but one tile at a time — both tiles' 48 registers next to
+                // the accumulators, the ring (which holds pass 1's residual by now) and the slot offsets did not fit: the
+                // round-3 build of this instance spilled 33 registers here
+                u32x2 rh[MTW], rl[MTW];
+                if (with_res) {
 #pragma unroll
                     for (int i = 0; i < MTW; i++) {
                         const unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + (n2 * 16 + kq * 4) * 2;
-                        rh[n2][i] = *reinterpret_cast<const u32x2 *>(slot);
-                        rl[n2][i] = *reinterpret_cast<const u32x2 *>(slot + 64);
+                        rh[i] = *reinterpret_cast<const u32x2 *>(slot);
+                        rl[i] = *reinterpret_cast<const u32x2 *>(slot + 64);
                     }
-            }
-#pragma unroll
-            for (int n2 = 0; n2 < NH; n2++) {
+                }
                 const int nt = pass * NH + n2;
                 const int oc = nquarter * OCW + nt * 16 + kq * 4;
                 f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -453,7 +475,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu]
                     if (with_res) {
-                        const h16x4 h = __builtin_bit_cast(h16x4, rh[n2][i]), l = __builtin_bit_cast(h16x4, rl[n2][i]);
+                        const h16x4 h = __builtin_bit_cast(h16x4, rh[i]), l = __builtin_bit_cast(h16x4, rl[i]);
 #pragma unroll
                         for (int j = 0; j < 4; j++) v[j] += (float)h[j] + (float)l[j];  // hi + lo is exact in f32; AFTER the ReLU (post_act.py:227-228)
                     }
@@ -478,7 +500,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
             // offsets po[i] serve both
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po_of(i),
                                                        nquarter * OCW * 4 + pass * 128, 0);
         }
         KZ_STAMP(19);
@@ -580,7 +602,7 @@ namespace {
 struct Geometry {
     int tpb, bpw, pitch, rpb, plane, rm_off, lds_bytes;
 };
-constexpr int RM_BYTES = ROWS * 2;
+constexpr int RM_BYTES = ROWS * 2 + ROWS * 4;  // image-row table (u16) + the split instance's row-offset table (i32)
 Geometry geometry(int h, int w) {
     Geometry g{};
     g.tpb = (h * w + 15) / 16;

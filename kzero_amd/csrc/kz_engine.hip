@@ -677,19 +677,26 @@ struct kz_engine {
     int next_epoch() {
         if (epoch >= GRAPH_EPOCH - 1) {  // start over: settle the device-resident flag first (slot flags compare for equality)
             (void)sync_all();
-            (void)check_devflag_pending();
+            check_devflag_pending();
             if (d_devflag) (void)hipMemset(d_devflag, 0, 4);
+            // the slots' own flag words too: a slot that once recorded a non-finite batch at epoch X keeps X in its header,
+            // and X is about to be issued again (everything is idle here: sync_all above)
+            for (auto &s : slots) {
+                if (s.batch >= 0) continue;  // (a finished batch nobody has waited for yet keeps its verdict)
+                if (s.d_sout) (void)hipMemset(s.d_sout, 0, 4);
+                if (s.h_sout) *reinterpret_cast<int *>(s.h_sout) = 0;
+                s.epoch = 0;
+            }
             epoch = dev_epoch_enqueued = dev_epoch_checked = 0;
         }
         return ++epoch;
     }
     bool wrap_nonfinite_pending = false;  // a non-finite batch seen while starting the epochs over: reported by the next synchronize
-    int check_devflag_pending() {
-        if (!d_devflag || dev_epoch_checked == dev_epoch_enqueued) return 0;
+    void check_devflag_pending() {
+        if (!d_devflag || dev_epoch_checked == dev_epoch_enqueued) return;
         int v = 0;
         if (hipMemcpy(&v, d_devflag, 4, hipMemcpyDeviceToHost) == hipSuccess && v != GRAPH_EPOCH && v > dev_epoch_checked)
             wrap_nonfinite_pending = true;
-        return 0;
     }
     void arm_device() {  // the forward pass enqueued next reports into the device-resident flag
         nf_flag = d_devflag;

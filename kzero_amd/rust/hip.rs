@@ -7,7 +7,15 @@
 //! Differences from `CudaNetwork`, all invisible to callers:
 //!  * the mapper's *packed* output (`InputMapper::encode_input`: BitBuffer + scalars, mapping/mod.rs:37) is handed
 //!    over as is; the dense f32 expansion (`encode_input_full`, mapping/mod.rs:40-63) happens on the GPU;
-//!  * no NaN padding to `max_batch_size` (cudnn.rs:65) and no input clone (cudnn.rs:70): only `batch` rows exist.
+//!  * no NaN padding to `max_batch_size` (cudnn.rs:65) and no input clone (cudnn.rs:70): only `batch` rows exist;
+//!  * `decode_output`'s gather + softmax (common.rs:60-86) runs on the GPU by default (`KZ_HIP_DECODE=device`): the
+//!    executor thread builds the `move_to_index` list of every board when it submits the batch, the GPU returns
+//!    tanh(value), softmax(wdl) and the per-move probabilities — 0.2 KB instead of 7.5 KB per chess evaluation over
+//!    PCIe and no softmax on this thread.  Measured with the C++ mirror of this file (tests/cpp/bench_executor.cpp,
+//!    chess 20x256 f16, ONE executor thread, move generation + a SipHash lookup per move on it): host decode 290k
+//!    evals/s (the thread is the bottleneck: 3.4 CPU-s per million evaluations), device decode 461k, the GPU alone
+//!    502k.  `KZ_HIP_DECODE=host` keeps the reference's own `decode_output` call (bit-identical softmax; set
+//!    gpu_threads_per_device >= 4 with it for a 256-channel chess network in f16).
 //!
 //! NOT compiled in this repository's CI (no cargo in the build image); written against the cited signatures.
 
@@ -19,11 +27,16 @@ use std::marker::PhantomData;
 use std::sync::Arc;
 
 use board_game::board::Board;
+use internal_iterator::InternalIterator;
 
 use crate::mapping::bit_buffer::BitBuffer;
 use crate::mapping::BoardMapper;
 use crate::network::common::decode_output;
 use crate::network::{Network, ZeroEvaluation};
+use crate::zero::values::ZeroValuesPov;
+use board_game::pov::ScalarPov;
+use board_game::wdl::WDL;
+use std::borrow::Cow;
 
 #[repr(C)]
 #[derive(Debug, Default, Copy, Clone)]
@@ -211,9 +224,14 @@ pub struct HipNetwork<B: Board, M: BoardMapper<B>> {
     scalars_in: Vec<f32>,
     scalars_out: Vec<f32>,
     policy_out: Vec<f32>,
-    /// boards of the batches in flight, oldest first (decode_output needs their available moves)
-    pending: VecDeque<(usize, Vec<B>)>,
+    /// boards of the batches in flight, oldest first (decode_output needs their available moves); with the
+    /// device-side decode the boards are dropped at submit and the CSR offsets of their move lists are kept instead
+    pending: VecDeque<(usize, Vec<B>, Vec<i64>)>,
     next_slot: usize,
+    /// `KZ_HIP_DECODE` (default "device"): decode_output's gather + softmax on the GPU
+    device_decode: bool,
+    move_offsets: Vec<i64>,
+    move_indices: Vec<i32>,
     ph: PhantomData<B>,
 }
 
@@ -249,8 +267,55 @@ impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
             _model: model,
             pending: VecDeque::new(),
             next_slot: 0,
+            device_decode: match std::env::var("KZ_HIP_DECODE").as_deref() {
+                Err(_) | Ok("device") => true,
+                Ok("host") => false,
+                Ok(other) => panic!("KZ_HIP_DECODE must be device or host, got '{}'", other),
+            },
+            move_offsets: vec![],
+            move_indices: vec![],
             ph: PhantomData,
         }
+    }
+
+    /// `move_to_index` of every available move of every board, as CSR lists (what decode_output computes per board,
+    /// common.rs:77-81, hoisted in front of the evaluation): `move_offsets[b]..move_offsets[b + 1]` of `move_indices`.
+    fn build_move_lists(&mut self, boards: &[impl Borrow<B>]) {
+        let mapper = self.mapper;
+        let policy_len = mapper.policy_len();
+        let (offsets, indices) = (&mut self.move_offsets, &mut self.move_indices);
+        offsets.clear();
+        offsets.push(0);
+        indices.clear();
+        for board in boards {
+            let board = board.borrow();
+            // `available_moves()` is an InternalIterator behind a Result (Err = the game is over: no moves, an empty
+            // policy — decode_output's `map_or(vec![], ..)`, common.rs:77)
+            if let Ok(moves) = board.available_moves() {
+                moves.for_each(|mv| {
+                    let index = mapper.move_to_index(board, mv);
+                    assert!(index < policy_len);
+                    indices.push(index as i32);
+                });
+            }
+            offsets.push(indices.len() as i64);
+        }
+    }
+
+    /// values [n, 5] (tanh / softmax already applied on the device) + probabilities parallel to the move lists
+    fn assemble(offsets: &[i64], values: &[f32], probs: &[f32]) -> Vec<ZeroEvaluation<'static>> {
+        (0..offsets.len() - 1)
+            .map(|bi| {
+                let v = &values[bi * 5..bi * 5 + 5];
+                let values = ZeroValuesPov {
+                    value: ScalarPov::new(v[0]),
+                    wdl: WDL { win: v[1], draw: v[2], loss: v[3] },
+                    moves_left: v[4],
+                };
+                let policy = probs[offsets[bi] as usize..offsets[bi + 1] as usize].to_vec();
+                ZeroEvaluation { values, policy: Cow::Owned(policy) }
+            })
+            .collect()
     }
 
     /// packed encode: exactly what BinaryOutput stores per position (binary_output.rs:210-256)
@@ -276,28 +341,57 @@ impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
         assert!(self.pending.len() < KZ_ENGINE_SLOTS, "every engine slot is in flight");
         let bits_bytes = self.encode_into_staging(&boards);
         let slot = self.next_slot;
-        check(unsafe {
-            kz_engine_submit_packed(
-                self.engine,
-                slot as c_int,
-                self.bits.as_ptr(),
-                bits_bytes,
-                self.scalars_in.as_ptr(),
-                boards.len() as c_int,
-            )
-        });
-        self.pending.push_back((slot, boards));
+        if self.device_decode {
+            self.build_move_lists(&boards);
+            check(unsafe {
+                kz_engine_submit_packed_decoded(
+                    self.engine,
+                    slot as c_int,
+                    self.bits.as_ptr(),
+                    bits_bytes,
+                    self.scalars_in.as_ptr(),
+                    boards.len() as c_int,
+                    self.move_offsets.as_ptr(),
+                    self.move_indices.as_ptr(),
+                )
+            });
+            // (the engine has copied the lists to its pinned staging: only the offsets are needed to cut up the reply)
+            self.pending.push_back((slot, vec![], self.move_offsets.clone()));
+        } else {
+            check(unsafe {
+                kz_engine_submit_packed(
+                    self.engine,
+                    slot as c_int,
+                    self.bits.as_ptr(),
+                    bits_bytes,
+                    self.scalars_in.as_ptr(),
+                    boards.len() as c_int,
+                )
+            });
+            self.pending.push_back((slot, boards, vec![]));
+        }
         self.next_slot = (slot + 1) % KZ_ENGINE_SLOTS;
     }
 
     /// Results of the OLDEST submitted batch.
     pub fn wait_batch(&mut self) -> Vec<ZeroEvaluation<'static>> {
-        let (slot, boards) = self.pending.pop_front().expect("wait_batch with nothing in flight");
-        check(unsafe {
-            kz_engine_wait(self.engine, slot as c_int, self.scalars_out.as_mut_ptr(), self.policy_out.as_mut_ptr())
-        });
+        let (slot, boards, offsets) = self.pending.pop_front().expect("wait_batch with nothing in flight");
+        if self.device_decode {
+            let (mut values, mut probs) = (std::ptr::null::<f32>(), std::ptr::null::<f32>());
+            check(unsafe { kz_engine_wait_decoded(self.engine, slot as c_int, &mut values, &mut probs) });
+            let (n, total) = (offsets.len() - 1, *offsets.last().unwrap() as usize);
+            // views into the engine's pinned staging, valid until the next submit on this slot (include/kz_hip.h)
+            let values = unsafe { std::slice::from_raw_parts(values, n * 5) };
+            let probs = if total == 0 { &[][..] } else { unsafe { std::slice::from_raw_parts(probs, total) } };
+            return Self::assemble(&offsets, values, probs);
+        }
+        // decode straight from the engine's pinned staging (no copy of the 1.9 MB policy tensor into a Vec first)
+        let (mut scalars, mut policy) = (std::ptr::null::<f32>(), std::ptr::null::<f32>());
+        check(unsafe { kz_engine_wait_view(self.engine, slot as c_int, &mut scalars, &mut policy) });
         let (batch_size, policy_len) = (boards.len(), self.mapper.policy_len());
-        let outputs = [&self.scalars_out[..batch_size * 5], &self.policy_out[..batch_size * policy_len]];
+        let outputs = unsafe {
+            [std::slice::from_raw_parts(scalars, batch_size * 5), std::slice::from_raw_parts(policy, batch_size * policy_len)]
+        };
         decode_output(self.mapper, &boards, &outputs)
     }
 }
@@ -322,6 +416,28 @@ impl<B: Board, M: BoardMapper<B>> Network<B> for HipNetwork<B, M> {
 
         assert!(self.pending.is_empty(), "evaluate_batch while submitted batches are in flight");
         let bits_bytes = self.encode_into_staging(boards);
+
+        if self.device_decode {
+            self.build_move_lists(boards);
+            check(unsafe {
+                kz_engine_submit_packed_decoded(
+                    self.engine,
+                    0,
+                    self.bits.as_ptr(),
+                    bits_bytes,
+                    self.scalars_in.as_ptr(),
+                    batch_size as c_int,
+                    self.move_offsets.as_ptr(),
+                    self.move_indices.as_ptr(),
+                )
+            });
+            let (mut values, mut probs) = (std::ptr::null::<f32>(), std::ptr::null::<f32>());
+            check(unsafe { kz_engine_wait_decoded(self.engine, 0, &mut values, &mut probs) });
+            let total = *self.move_offsets.last().unwrap() as usize;
+            let values = unsafe { std::slice::from_raw_parts(values, batch_size * 5) };
+            let probs = if total == 0 { &[][..] } else { unsafe { std::slice::from_raw_parts(probs, total) } };
+            return Self::assemble(&self.move_offsets, values, probs);
+        }
 
         check(unsafe {
             kz_engine_eval_packed(

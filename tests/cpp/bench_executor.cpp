@@ -109,13 +109,21 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
                     gen_cpu[gi] = thread_cpu_ns();
                 }
             });
-    std::this_thread::sleep_for(std::chrono::milliseconds(500));  // warm-up
+    // warm-up: until every device has answered its first batches (engine creation — weight packing and upload — runs on
+    // the executor thread and must not be counted as its work), then half a second more
+    for (int spin = 0; spin < 600; spin++) {
+        bool all = true;
+        for (size_t i = 0; i < a.devices.size(); i++) all &= per_device[i].real.load() > 4 * st.gpu_batch_size;
+        if (all) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(500));
     const size_t nd = a.devices.size(), ne = std::min(st.gpu_threads_per_device, EvalCounters::MAX_EXECUTORS);
     std::vector<uint64_t> r0(nd), p0(nd), g0(n_gen);
-    std::vector<std::vector<uint64_t>> e0(nd, std::vector<uint64_t>(ne));
+    std::vector<std::vector<uint64_t>> e0(nd, std::vector<uint64_t>(ne)), w0(nd, std::vector<uint64_t>(ne));
     for (size_t i = 0; i < nd; i++) {
         r0[i] = per_device[i].real, p0[i] = per_device[i].potential;
-        for (size_t k = 0; k < ne; k++) e0[i][k] = per_device[i].executor_cpu_ns[k];
+        for (size_t k = 0; k < ne; k++) e0[i][k] = per_device[i].executor_cpu_ns[k], w0[i][k] = per_device[i].executor_wait_ns[k];
     }
     for (size_t i = 0; i < n_gen; i++) g0[i] = gen_cpu[i];
     const double cpu0 = process_cpu_s();
@@ -130,16 +138,22 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double cpu_s = process_cpu_s() - cpu0;
-    std::string exec_util, gen_util, per, devs_json;
-    double exec_cpu_total = 0, exec_max = 0, gen_cpu_total = 0;
+    std::string exec_util, exec_work, gen_util, per, devs_json;
+    double exec_cpu_total = 0, exec_max = 0, gen_cpu_total = 0, exec_work_total = 0, exec_work_max = 0;
     for (size_t i = 0; i < nd; i++)
         for (size_t k = 0; k < ne; k++) {
             const double u = (per_device[i].executor_cpu_ns[k] - e0[i][k]) * 1e-9 / dt;
+            // work = CPU time outside kz_engine_wait* (where the HIP runtime polls the event)
+            const double wk = u - (per_device[i].executor_wait_ns[k] - w0[i][k]) * 1e-9 / dt;
             exec_cpu_total += u * dt;
+            exec_work_total += wk * dt;
             exec_max = std::max(exec_max, u);
+            exec_work_max = std::max(exec_work_max, wk);
             char buf[32];
             std::snprintf(buf, sizeof buf, "%s%.3f", exec_util.empty() ? "" : ", ", u);
             exec_util += buf;
+            std::snprintf(buf, sizeof buf, "%s%.3f", exec_work.empty() ? "" : ", ", wk);
+            exec_work += buf;
         }
     for (size_t i = 0; i < n_gen; i++) {
         const double u = (gen_cpu[i] - g0[i]) * 1e-9 / dt;
@@ -167,14 +181,17 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
     std::printf("{\"evals_per_s\": %.1f, \"fill\": %.3f, \"gpu_threads\": %zu, \"generator_threads\": %d, "
                 "\"concurrent_games\": %zu, \"gpu_batch\": %zu, \"search_batch\": %zu, \"pipeline_depth\": %zu, \"device_decode\": %d, "
                 "\"seconds\": %.2f, \"devices\": [%s], \"per_device_evals_per_s\": [%s], \"work\": \"%s\", \"dtype\": \"%s\", "
-                "\"executor_cpu_util\": [%s], \"executor_cpu_util_max\": %.3f, \"generator_cpu_util\": [%s], "
-                "\"host_cpu_s_per_Meval\": %.3f, \"executor_cpu_s_per_Meval\": %.3f, \"generator_cpu_s_per_Meval\": %.3f, "
+                "\"executor_cpu_util\": [%s], \"executor_cpu_util_max\": %.3f, \"executor_work_util\": [%s], "
+                "\"executor_work_util_max\": %.3f, \"generator_cpu_util\": [%s], "
+                "\"host_cpu_s_per_Meval\": %.3f, \"executor_cpu_s_per_Meval\": %.3f, \"executor_work_s_per_Meval\": %.3f, "
+                "\"generator_cpu_s_per_Meval\": %.3f, "
                 "\"projection_8gpu\": {\"evals_per_s\": %.0f, \"cores_needed\": %.1f, \"cores_per_numa_node\": [%s], "
                 "\"pcie_GBps\": %.3f, \"pcie_GBps_per_gpu\": %.3f}}\n",
                 evals_s, (double)real / (double)(potential ? potential : 1), st.gpu_threads_per_device, a.generators,
                 sizing.concurrent_games, st.gpu_batch_size, st.search_batch_size, st.pipeline_depth, (int)st.device_decode, dt,
-                devs_json.c_str(), per.c_str(), a.work.c_str(), a.dtype_name.c_str(), exec_util.c_str(), exec_max, gen_util.c_str(),
-                cpu_s / mevals, exec_cpu_total / mevals, gen_cpu_total / mevals, 8 * per_dev_rate, 8 * cores_per_device, numa.c_str(),
+                devs_json.c_str(), per.c_str(), a.work.c_str(), a.dtype_name.c_str(), exec_util.c_str(), exec_max, exec_work.c_str(),
+                exec_work_max, gen_util.c_str(), cpu_s / mevals, exec_cpu_total / mevals, exec_work_total / mevals, gen_cpu_total / mevals,
+                8 * per_dev_rate, 8 * cores_per_device, numa.c_str(),
                 8 * per_dev_rate * (in_bytes + out_bytes) / 1e9, per_dev_rate * (in_bytes + out_bytes) / 1e9);
     std::fflush(stdout);
     // generators block in recv(); the process exit tears everything down (the reference server has no clean stop

@@ -887,15 +887,26 @@ def test_one_launch_f32_network_decode_and_range_check(dev):
     ("go-9", 3, 128, "conv", (1, 4)),
     ("ataxx-5", 2, 128, "ataxx_conv", (7,)),          # 25 pixels: four boards per workgroup
     ("ataxx-7", 4, 64, "ataxx_conv", (5,)),           # BASELINE configs[0]'s network (64 channels)
-    ("chess", 2, 32, "dense", (4,)),                  # not a shape of the kernel
+    ("chess", 2, 32, "dense", (4,)),                  # 32 channels: widened to 64 by zero filters (round 4)
+    ("chess", 0, 64, "attention", (1,)),              # no block: not a shape of the kernel
 ])
 def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     """KZ_DTYPE_F32_SPLIT16 (kz_tower_resident_split: (hi, lo) f16 pairs, three MFMAs per product): the SAME <= 1e-4
     against the oracle as the exact-f32 path, which it also agrees with; shapes it does not take are refused."""
-    if head == "dense":
-        blob = O.load_blob("chess_2x32_dense_h")  # 32 channels
+    if depth == 0:
         with pytest.raises(capi.KzError, match="SPLIT16 needs"):
-            capi.Engine(capi.Model(blob=blob), dev, 4, capi.KZ_DTYPE_F32_SPLIT16)
+            capi.Engine(capi.Model(blob=synth.random_model(game, 0, channels, head)), dev, 4, capi.KZ_DTYPE_F32_SPLIT16)
+        return
+    if head == "dense":  # the golden chess net with the dense head, 32 channels: runs as a 64-channel tower
+        blob = O.load_blob("chess_2x32_dense_h")
+        net = O.OracleNet(blob)
+        eng = capi.Engine(capi.Model(blob=blob), dev, 4, capi.KZ_DTYPE_F32_SPLIT16)
+        assert eng.tower_path == "tower_resident_split16"
+        _, s_gold, p_gold = O.read_io("chess_2x32_dense_h", "planes", net.c_in, net.h, net.w, net.policy_len)
+        bits, scalars_in = O.read_packed("chess_2x32_dense_h", net.n_bool, net.n_scalar, net.h, net.w)
+        s, p = eng.eval_packed(bits, scalars_in)
+        assert_f32(s, s_gold, "scalars vs the reference's golden outputs")
+        assert_f32(p, p_gold, "policy vs the reference's golden outputs")
         return
     blob = synth.random_model(game, depth, channels, head, seed=81 + depth)
     net = O.OracleNet(blob)
@@ -1070,7 +1081,8 @@ def test_abi_helpers_on_the_device(dev):
     blob = O.load_blob("chess_2x32_att")
     model = capi.Model(blob=blob)
     assert model.supports_dtype(capi.KZ_DTYPE_F32) and model.supports_dtype(capi.KZ_DTYPE_F16)
-    assert not model.supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)          # 32 channels: not a shape of the split launch
+    assert model.supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)              # 32 channels: widened to 64 by zero filters
+    assert not capi.Model(blob=synth.random_model("chess", 0, 64, "attention")).supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)  # no block
     big = capi.Model(blob=synth.random_model("chess", 1, 256, "attention", seed=1))
     assert big.supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)
     fused = capi.Engine(big, dev, 256, capi.KZ_DTYPE_F16)

@@ -13,7 +13,7 @@ open('/tmp/chess20x256.kzm','wb').write(random_model('chess', 20, 256, 'attentio
 GEN=${GENERATORS:-6}
 for dtype in f16 f32split16; do
   # work, gpu_threads, pipeline depth, device_decode
-  for cfg in "packed 1 3 0" "real 1 3 0" "real 2 2 0" "real 3 2 0" "real 4 2 0" "real 1 3 1" "real 2 2 1" "pre 1 3 1" "pre 2 2 1"; do
+  for cfg in "packed 1 3 0" "real 1 3 0" "real 2 2 0" "real 3 2 0" "real 4 2 0" "real 1 3 1" "real 1 2 1" "real 2 2 1" "pre 1 3 1" "pre 1 2 1" "pre 2 2 1"; do
     set -- $cfg
     tests/cpp/build/bench_executor /tmp/chess20x256.kzm $SEC $2 $GEN 256 8 $dtype $3 $4 0 $1 2>/dev/null
   done

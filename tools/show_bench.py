@@ -3,12 +3,35 @@
 import json, sys
 txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
 r = json.loads([ln for ln in txt.splitlines() if ln.startswith("{")][-1])
-print("value", r["value"], "chip_frac", r["roofline"]["chip_frac"], "launch_ms", r["roofline"]["avg_launch_ms"], "traffic", r["roofline"]["traffic"])
+
+
+def roof(x):
+    f = x["roofline"]
+    return (f"frac {f['frac']} (launch_frac {f.get('launch_frac')}, {f.get('concurrent_launches')} at once) launch_ms {f['avg_launch_ms']} "
+            f"traffic {f['traffic']} ratio {f.get('traffic_ratio')}")
+
+
+print("value", r["value"], roof(r))
 if "pcie_inclusive" in r:
     h = r["pcie_inclusive"]; print("pcie_inclusive", h["value"], "of_resident", h["of_resident"], "engines", h.get("engines_per_gpu"))
 for o in r.get("others", []):
     if "error" in o:
         print(" ", o["workload"], o["dtype"], "ERROR", o["error"])
         continue
-    print(" ", o["workload"], o["dtype"], o["value"], "chip_frac", o["roofline"]["chip_frac"], "launch_ms", o["roofline"]["avg_launch_ms"], o["tower_path"])
+    print(" ", o["workload"], o["dtype"], o["value"], o["tower_path"], roof(o))
+for key in ("seam", "seam_parity", "seam_one_process"):
+    s = r.get(key)
+    if not s:
+        continue
+    if "error" in s or "skipped" in s:
+        print(key, s)
+        continue
+    for run in [s] + s.get("variants", []):
+        if "error" in run:
+            print(" ", key, run["config"], "ERROR", run["error"])
+            continue
+        p = run["projection_8gpu"]
+        print(f"  {key} [{run['config']}] {run['value']:.0f} evals/s fill {run['fill']} executor work util {run['executor_work_util']} (cpu {run['executor_cpu_util']}) "
+              f"generators {run['generator_cpu_util']} host cpu s/Meval {run['host_cpu_s_per_Meval']} | x8: {p['cores_needed']} cores "
+              f"of {p['cores_per_numa_node']} per node, {p['pcie_GBps']} GB/s PCIe")
 if "cpu_baseline" in r: print("cpu", r["cpu_baseline"]["value"], "cores", r["cpu_baseline"]["cores"], r["cpu_baseline"].get("error", ""))
