@@ -1045,13 +1045,9 @@ int split_tiles_for(int hw, int channels, bool split) {
     // (the plain-f16 launch has half the LDS footprint: 256 / 320 channels fit up to 96 squares — Go 9x9)
     if (channels == 256 || channels == 320) return channels == 320 && split ? 0 : hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
     if (channels == 384 || channels == 512) return !split && hw <= 64 ? 4 : 0;
-#ifdef KZ_192_NT4
     if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
-#else
-    if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 8 : hw <= 96 ? 6 : 0;
-#endif
-    // (two 8x8 boards in eight tiles were measured at 64 / 128 channels: 0.29 against 0.32 of the peak with two engines —
-    // half as many workgroups, one per CU instead of two)
+    // (two 8x8 boards in eight tiles were measured at 64 / 128 / 192 channels: 0.29 against 0.32 of the peak at 128, 0.42
+    // against 0.45 at 192, two engines — half as many workgroups, one per CU instead of two)
     if (channels == 128 || channels == 64) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
     return 0;
 }
@@ -1493,7 +1489,6 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else if (t.channels == 320) launch<320, 4, false>(d, grid, stream);
         else if (t.channels == 256 && nt == 6) launch<256, 6, false>(d, grid, stream);
         else if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
-        else if (t.channels == 192 && nt == 8) launch<192, 8, false>(d, grid, stream);
         else if (t.channels == 192 && nt == 4) launch<192, 4, false>(d, grid, stream);
         else if (t.channels == 192 && nt == 7) launch<192, 7, false>(d, grid, stream);
         else if (t.channels == 192) launch<192, 6, false>(d, grid, stream);
