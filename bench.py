@@ -48,10 +48,15 @@ WORKLOADS = {
     "go19-40x256": dict(game="go-19", depth=40, channels=256, head="conv", batch=512, steps=400,
                         engines={"f16": 1, "f32": 1, "f32split16": 1},
                         label="Go 19x19 40x256 ResNet b=512"),
+    # the reference's own shipping configuration (python/main/loop_main_alpha.py:16-30,68-76): Go 9x9, 16 blocks x 128
+    # channels, ConvPolicyHead(extra_moves=1), gpu_batch_size 2048 (one launch of 2048 workgroups fills the chip eight times)
+    "go9-16x128": dict(game="go-9", depth=16, channels=128, head="conv", batch=2048, steps=1000,
+                       engines={"f16": 2, "f32": 2, "f32split16": 2},
+                       label="Go 9x9 16x128 ResNet b=2048 (loop_main_alpha.py)"),
 }
 # the other single-GPU BASELINE configs, reported as sub-records of the default line
 OTHERS = [("ataxx-8x128", "f32"), ("ataxx-8x128", "f32split16"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"),
-          ("go19-40x256", "f32split16")]
+          ("go19-40x256", "f32split16"), ("go9-16x128", "f32split16"), ("go9-16x128", "f16")]
 
 KERNEL_OF_PATH = {
     "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",

@@ -91,6 +91,8 @@ def load():
                           f"(or __graft_entry__.build()); there is no CPU fallback")
         lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
+            if "KZ_LIB_PATH" in os.environ and not hasattr(lib, name):
+                continue  # (an older build named explicitly for a same-box A/B: its missing entry points fail when called)
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes

@@ -199,7 +199,13 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // each reload behind an s_waitcnt vmcnt(0) that drained the weight ring.  They sit in LDS instead, one row offset per
     // tile row behind the image-row table, read back with the LDS counter where they are needed.)
     int po[SPLIT ? 1 : 12];
+#ifdef KZ_BCS_PO_REGS
+    int po_dbg[12];
+#endif
     auto po_of = [&](int i) __attribute__((always_inline)) -> int {
+#ifdef KZ_BCS_PO_REGS
+        if constexpr (SPLIT) return po_dbg[i];
+#endif
         if constexpr (SPLIT) {
             const int base = *reinterpret_cast<const int *>(lds + a.rm_off + ROWS * 2 + ((tid >> 3) + i * 32) * 4);
             return base < 0 ? -1 : base + piece * 16;
@@ -219,6 +225,9 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         // hi halves, 4..7 its lo halves, and the same offsets serve input, residual and output)
         const int po_i = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
         if constexpr (!SPLIT) po[i] = po_i;
+#ifdef KZ_BCS_PO_REGS
+        po_dbg[i] = po_i;
+#endif
         v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
         if (piece == 0) {
             // (SPLIT: a padding row is marked in the table itself — there is no po[i] to ask)
@@ -446,40 +455,45 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 }
                 __syncthreads();
             }
+            // One tile row at a time: the residual pieces of BOTH 16-channel tiles of the row are read before the row is
+            // rewritten.  (An f32 result row — the tower's last layer, a.y32 — covers the bytes the other tile's (hi, lo)
+            // residual occupies, so all of a row's residual reads must come first; reading all six rows' pieces up front, as
+            // the round-3 build did, took 48 registers next to the accumulators, the ring — which holds pass 1's residual
+            // by now — and the slot offsets, and that build spilled.  Six dependent LDS round trips per pass instead of
+            // one: ~1 us of a 480 us launch.)
+            f32x4 ps[NH], pt[NH];
 #pragma unroll
             for (int n2 = 0; n2 < NH; n2++) {
-                // the residual pieces of this 16-channel tile: all six tile rows are read before the first one is rewritten
-                // (one LDS round trip per tile instead of six), but one tile at a time — both tiles' 48 registers next to
-                // the accumulators, the ring (which holds pass 1's residual by now) and the slot offsets did not fit: the
-                // round-3 build of this instance spilled 33 registers here
-                u32x2 rh[MTW], rl[MTW];
+                const int oc = nquarter * OCW + (pass * NH + n2) * 16 + kq * 4;
+                ps[n2] = f32x4{1.f, 1.f, 1.f, 1.f};
+                pt[n2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.post_scale) {
+                    ps[n2] = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
+                    pt[n2] = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; i++) {
+                unsigned char *row = lds + ((wr * MTW + i) * 16 + fr) * ORS;  // this lane's 4 channels per tile of it: owned by the lane
+                u32x2 rh[NH], rl[NH];
                 if (with_res) {
 #pragma unroll
-                    for (int i = 0; i < MTW; i++) {
-                        const unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + (n2 * 16 + kq * 4) * 2;
-                        rh[i] = *reinterpret_cast<const u32x2 *>(slot);
-                        rl[i] = *reinterpret_cast<const u32x2 *>(slot + 64);
+                    for (int n2 = 0; n2 < NH; n2++) {
+                        rh[n2] = *reinterpret_cast<const u32x2 *>(row + (n2 * 16 + kq * 4) * 2);
+                        rl[n2] = *reinterpret_cast<const u32x2 *>(row + 64 + (n2 * 16 + kq * 4) * 2);
                     }
                 }
-                const int nt = pass * NH + n2;
-                const int oc = nquarter * OCW + nt * 16 + kq * 4;
-                f32x4 ps = f32x4{1.f, 1.f, 1.f, 1.f}, pt = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.post_scale) {
-                    ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-                    pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-                }
 #pragma unroll
-                for (int i = 0; i < MTW; i++) {
-                    unsigned char *row = lds + ((wr * MTW + i) * 16 + fr) * ORS;  // this lane's 4 channels of it: owned by the lane
-                    f32x4 v = acc[nt][i];
+                for (int n2 = 0; n2 < NH; n2++) {
+                    f32x4 v = acc[pass * NH + n2][i];
 #pragma unroll
                     for (int j = 0; j < 4; j++) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu]
                     if (with_res) {
-                        const h16x4 h = __builtin_bit_cast(h16x4, rh[i]), l = __builtin_bit_cast(h16x4, rl[i]);
+                        const h16x4 h = __builtin_bit_cast(h16x4, rh[n2]), l = __builtin_bit_cast(h16x4, rl[n2]);
 #pragma unroll
                         for (int j = 0; j < 4; j++) v[j] += (float)h[j] + (float)l[j];  // hi + lo is exact in f32; AFTER the ReLU (post_act.py:227-228)
                     }
-                    v = v * ps + pt;
+                    v = v * ps[n2] + pt[n2];
                     if (a.y32) {
                         *reinterpret_cast<f32x4 *>(row + (n2 * 16 + kq * 4) * 4) = v;
                     } else {

@@ -7,7 +7,7 @@
 // one workgroup per CU nothing covers a workgroup's prologue (tile-row map, halo clear, ring fill, first half-chunk:
 // ~5 us) and epilogue (~4 us) around 26 us of MFMA work, and the k-loop alone runs at ~70 % — the two co-resident
 // workgroups of kz_board_conv.hip cover each other's phases better than this single one pipelines its own.  What it
-// would take is a persistent workgroup that prefetches the next item under the current epilogue (DESIGN.md §5.2b).
+// would take is a persistent workgroup that prefetches the next item under the current epilogue (DESIGN.md §5.4).
 // In-kernel stamps (-DKZ_BC2_STAMPS, tools/board_conv2_stamps.py), cycles per workgroup of 119.5k: set-up 5.1k, first
 // half-chunk 4.3k, eight k-loops 78.7k (9.3k each against 6.9k of MFMA time: a single wave per SIMD pays ~265 cycles of
 // issue per k-step for its 12 fragment reads, 12 address adds and 4 loads — what the co-resident wave hides in
@@ -15,7 +15,7 @@
 //
 // Why: in kz_board_conv.hip a wave owns 64 output channels x 6 pixel tiles and two workgroups share a CU, so the CU's
 // eight waves pull the same 4 KB of weight fragments per k-step through L1 eight times: 53 of the 64 B/clk L1 delivers
-// (DESIGN.md §5.2b), and the two workgroups' staging / epilogue phases overlap each other's MFMAs only by chance.  Here a
+// (DESIGN.md §5.4), and the two workgroups' staging / epilogue phases overlap each other's MFMAs only by chance.  Here a
 // wave owns 64 output channels x TWELVE tiles (192 accumulators; one wave per SIMD, 512 registers), so a weight fragment
 // feeds 12 MFMAs and the CU's L1 weight traffic is 21 B/clk; the image lives in LDS as two 32-channel buffers of
 // rows x 80 B with a zero halo (a tap is a constant row offset, as before), and while the k-loop reads one buffer each

@@ -149,12 +149,23 @@ struct DeviceWeights {
     }
 
     // the same convolution for the board-tile kernel in split arithmetic
-    int upload_board_conv_split(const Conv &cv, DevConv &d) {
+    // (cin_pad: the stem's few input planes padded with zero weights to the kernel's 32-channel chunk)
+    int upload_board_conv_split(const Conv &cv, DevConv &d, int cin_pad = 0) {
         d.k = 3;
         d.cout = d.cout_p = cv.cout;
-        d.cin_p = cv.cin;
-        std::vector<uint16_t> packed(kz::board_conv_split_weight_elems(cv.cin, cv.cout));
-        kz::board_conv_split_pack_weights(cv.w.data(), cv.cout, cv.cin, packed.data());
+        const int cin = cin_pad ? cin_pad : cv.cin;
+        d.cin_p = cin;
+        std::vector<float> padded;
+        const float *w = cv.w.data();
+        if (cin != cv.cin) {
+            padded.assign((size_t)cv.cout * cin * 9, 0.0f);
+            for (int o = 0; o < cv.cout; o++)
+                for (int i = 0; i < cv.cin; i++)
+                    for (int t = 0; t < 9; t++) padded[((size_t)o * cin + i) * 9 + t] = cv.w[((size_t)o * cv.cin + i) * 9 + t];
+            w = padded.data();
+        }
+        std::vector<uint16_t> packed(kz::board_conv_split_weight_elems(cin, cv.cout));
+        kz::board_conv_split_pack_weights(w, cv.cout, cin, packed.data());
         if (upload(packed.data(), packed.size() * 2, &d.bws)) return 1;
         return upload_f32(cv.b, &d.b);
     }
@@ -218,6 +229,7 @@ struct DeviceWeights {
     bool use_board_conv = false;
     bool use_board_split = false;  // split16 on a board too large for the resident launch: per-layer board-tile kernel
     int stem_cin_p = 0;  // != 0: the stem goes through the board-tile kernel and wants encoded rows of this many channels
+    bool stem_split = false;  // split16 per layer: the stem too goes through kz_board_conv_split16 (<= 32 input planes)
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
     int *bc_rowmap = nullptr;  // (experiment build: kz_board_conv2_f16's tile-row map and halo-row list)
     unsigned short *bc_halo = nullptr;
@@ -346,7 +358,12 @@ struct DeviceWeights {
                 const bool stem64 = on && i == 0 && !conv2 && m.tower[0].cin <= 64 && m.tower[0].k == 3 &&
                                     kz::board_conv_supported(dtype, m.h, m.w, 64, m.tower[0].cout);
                 const bool board = on && kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
-                if (use_board_split && i >= 1) {  // (the stem stays an exact-f32 implicit GEMM: its inputs are f32 planes)
+                if (use_board_split && i == 0 && m.tower[0].cin <= 32 && m.tower[0].k == 3) {
+                    // the stem through the same kernel: its input planes as one 32-channel chunk of (hi, lo) rows — an
+                    // eighth of a 256-channel layer's work instead of an exact-f32 implicit GEMM and a splitting pass
+                    stem_split = true;
+                    if (upload_board_conv_split(m.tower[0], tower[0], 32)) return 1;
+                } else if (use_board_split && i >= 1) {  // (a stem of more than 32 planes stays an exact-f32 implicit GEMM)
                     if (upload_board_conv_split(m.tower[i], tower[i])) return 1;
                 } else if (stem64) {
                     stem_cin_p = 64;
@@ -951,10 +968,17 @@ struct kz_engine {
             // the stem in exact f32 (its inputs are f32 planes), its output split into (hi, lo) halves — an f32 tensor and a
             // (hi, lo) tensor of the same shape have the same size, so the three activation buffers serve both —, the
             // 2·depth tower convolutions in split arithmetic, the last one writing f32 for the heads
-            if (conv(wts->tower[0], x_in, cin_p, act[2], cp, M, 0, nullptr, false, m.h, m.w, hw, hw, 0)) return 1;
-            prof.begin("kz_split_rows", stream);
-            kz::launch_split_rows((const float *)act[2], act[0], (size_t)M, cp, stream);
-            prof.end(stream);
+            if (wts->stem_split) {  // encoded f32 planes [M][32] -> (hi, lo) rows -> the board-tile kernel, one chunk
+                prof.begin("kz_split_rows", stream);
+                kz::launch_split_rows((const float *)x_in, act[2], (size_t)M, cin_p, stream);
+                prof.end(stream);
+                if (conv(wts->tower[0], act[2], cin_p, act[0], cp, M, 0, nullptr, false, m.h, m.w, hw, hw, 0)) return 1;
+            } else {
+                if (conv(wts->tower[0], x_in, cin_p, act[2], cp, M, 0, nullptr, false, m.h, m.w, hw, hw, 0)) return 1;
+                prof.begin("kz_split_rows", stream);
+                kz::launch_split_rows((const float *)act[2], act[0], (size_t)M, cp, stream);
+                prof.end(stream);
+            }
             int cur = 0;
             for (int i = 1; i <= m.depth; i++) {
                 const int mid = (cur + 1) % 3, nxt = (cur + 2) % 3;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
     // 4*OT*NT MFMAs of 32 cycles = 0.75 us at A1: two steps of cover were less than an L2 round trip under load), the
     // activation fragments one step ahead in the other of two buffers; inside a step every fragment read and ring refill
     // is placed in the shadow of MFMAs (24 free issue cycles per f32 MFMA) instead of in a burst between two blocks of
-    // MFMAs.  Round 2, A1 at a full chip: MFMA-busy 83.7 % -> see DESIGN.md §5.2a. ----
+    // MFMAs.  Round 2, A1 at a full chip: MFMA-busy 83.7 % -> see DESIGN.md §5.3. ----
     const int koff = plane_of<C>(kq);
     constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
     static_assert(G % 4 == 0 && G % 2 == 0, "the ring stage and the fragment buffer of a step are compile-time constants");

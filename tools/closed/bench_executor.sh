@@ -3,7 +3,7 @@
 # synthetic chess 20x256 attention model and runs blocking (depth 1) and pipelined (depth 2) executor threads.
 #   tools/bench_executor.sh [seconds]
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 SEC=${1:-4}
 mkdir -p tests/cpp/build gpurun_out
 g++ -std=c++17 -O2 -pthread tests/cpp/bench_executor.cpp -o tests/cpp/build/bench_executor -Lkzero_amd -lkzhip -Wl,-rpath,$PWD/kzero_amd

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2: the seam bench with the four-slot zero-copy engine: blocking threads and ONE pipelined thread at depth 2, 3, 4
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 SEC=${1:-3}
 mkdir -p tests/cpp/build gpurun_out
 g++ -std=c++17 -O2 -pthread tests/cpp/bench_executor.cpp -o tests/cpp/build/bench_executor -Lkzero_amd -lkzhip -Wl,-rpath,$PWD/kzero_amd
