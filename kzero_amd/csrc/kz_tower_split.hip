@@ -1046,8 +1046,9 @@ int split_tiles_for(int hw, int channels, bool split) {
     if (channels == 256 || channels == 320) return channels == 320 && split ? 0 : hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
     if (channels == 384 || channels == 512) return !split && hw <= 64 ? 4 : 0;
     if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
-    // (two 8x8 boards in eight tiles were measured at 64 / 128 / 192 channels: 0.29 against 0.32 of the peak at 128, 0.42
-    // against 0.45 at 192, two engines — half as many workgroups, one per CU instead of two)
+    // (two 8x8 boards in eight tiles were measured at 64 / 128 / 192 channels: at 128, 0.29 against 0.32 of the peak with two
+    // engines, 0.37 against 0.38 with three, 0.29 against 0.32 with four; at 192, 0.42 against 0.45 — half as many
+    // workgroups, and the launch is not bound by the weight stream in the first place)
     if (channels == 128 || channels == 64) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
     return 0;
 }

@@ -354,23 +354,22 @@ def chess_full():
     return blob, bits, scalars_in
 
 
-C1_PICK = np.array([0, 1, 2, 3, 62, 63, 64, 65, 126, 127, 128, 129, 198, 199, 200, 201, 254, 255] + list(range(10, 220, 15)))
+C1_PICK = np.arange(256)  # every board of the batch (rounds 2-3: 32 of them)
 
 
 @pytest.fixture(scope="module")
 def chess_full_oracle(chess_full):
-    """The REAL oracle on 32 of the 256 boards of the full configuration (one board takes it about 0.3 s on one core; all
-    host threads are used): both boards of 16 workgroups, the half-empty edges included.  Shared by the f16, exact-f32 and
-    split-f16 tests."""
+    """The REAL oracle on ALL 256 boards of the full configuration (one board takes it about 0.3 s on one core; all host
+    threads are used: ~5 s on the GPU box's 16).  Shared by the f16, exact-f32 and split-f16 tests."""
     blob, bits, scalars_in = chess_full
-    assert len(set(C1_PICK.tolist())) == 32
+    assert len(set(C1_PICK.tolist())) == 256
     net = O.OracleNet(blob)
     dense = O.encode_input_full(bits[C1_PICK], scalars_in[C1_PICK], net.n_scalar, net.n_bool, net.h, net.w)
     return net.forward(dense, threads=os.cpu_count() or 1)
 
 
 def test_config_c1_chess_20x256_f16_vs_oracle_sample(dev, chess_full, chess_full_oracle):
-    """BASELINE.json configs[2] at full size against the oracle on 32 of the 256 boards."""
+    """BASELINE.json configs[2] at full size against the oracle on all 256 boards."""
     blob, bits, scalars_in = chess_full
     pick = C1_PICK
     s_ref, p_ref = chess_full_oracle
@@ -384,7 +383,7 @@ def test_config_c1_chess_20x256_f16_vs_oracle_sample(dev, chess_full, chess_full
 
 
 def test_config_c1_f32_vs_oracle_sample(dev, chess_full, chess_full_oracle):
-    """The two <= 1e-4 paths at the full configuration against the oracle on the same 32 boards as the f16 test."""
+    """The two <= 1e-4 paths at the full configuration against the oracle on all 256 boards."""
     blob, bits, scalars_in = chess_full
     pick = C1_PICK
     s_ref, p_ref = chess_full_oracle
@@ -425,13 +424,30 @@ def test_config_c1_f16_against_the_f32_accurate_launch_on_the_whole_batch(dev, c
     assert sm < 1e-3
 
 
-def test_config_g8_go19_40x256_at_executor_batch_512(dev):
+G8_PICK = np.arange(0, 512, 32)  # 16 boards spread over the batch (rounds 2-3: 8)
+
+
+@pytest.fixture(scope="module")
+def go19_full():
+    return synth.random_model("go-19", 40, 256, "conv", seed=33), *synth.random_boards("go-19", 512, seed=34)
+
+
+@pytest.fixture(scope="module")
+def go19_full_oracle(go19_full):
+    """The REAL oracle on 16 of the 512 boards of the G8 network (~10 s of one core per board; the boards run on separate
+    host threads).  Shared by the f16 and the split16 test."""
+    blob, bits, scalars_in = go19_full
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits[G8_PICK], scalars_in[G8_PICK], net.n_scalar, net.n_bool, net.h, net.w)
+    return net.forward(dense, threads=os.cpu_count() or 1)
+
+
+def test_config_g8_go19_40x256_at_executor_batch_512(dev, go19_full, go19_full_oracle):
     """BASELINE.json configs[4] at its stated size on one GPU: Go 19x19, 40 blocks x 256 channels, f16, executor batch
     512 through kz_board_conv_f16.  Size-independent properties on all 512 boards (determinism, permutation
     equivariance over the batch, batch-size invariance), the exact-f32 path of this library on a 64-board sample, and
-    the real oracle on 8 boards (it needs ~10 s of one core per board; the boards run on separate host threads)."""
-    blob = synth.random_model("go-19", 40, 256, "conv", seed=33)
-    bits, scalars_in = synth.random_boards("go-19", 512, seed=34)
+    the real oracle on 16 boards."""
+    blob, bits, scalars_in = go19_full
     model = capi.Model(blob=blob)
     f16 = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F16)
     assert f16.tower_path == "board_conv_f16" and f16.max_batch == 512
@@ -453,15 +469,12 @@ def test_config_g8_go19_40x256_at_executor_batch_512(dev):
     rp = assert_f16(p[sample], p_ref, "policy, 64 of 512 boards vs exact f32")
     print(f"go-19 40x256 B=512 f16 vs exact f32 on 64 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, "
           f"max |dsoftmax| {np.abs(softmax(p[sample]) - softmax(p_ref)).max():.2e}")
-    net = O.OracleNet(blob)
-    two = sample[::8]  # boards 0, 64, ..., 448
-    assert len(two) == 8
-    dense = O.encode_input_full(bits[two], scalars_in[two], net.n_scalar, net.n_bool, net.h, net.w)
-    so, po = net.forward(dense, threads=os.cpu_count() or 1)
-    assert_f32(s_ref[::8], so, "exact f32 vs oracle, scalars")
-    assert_f32(p_ref[::8], po, "exact f32 vs oracle, policy")
-    assert_f16(s[two], so, "f16 vs oracle, scalars")
-    assert_f16(p[two], po, "f16 vs oracle, policy")
+    so, po = go19_full_oracle
+    assert np.array_equal(sample[::4], G8_PICK)  # boards 0, 32, ..., 480
+    assert_f32(s_ref[::4], so, "exact f32 vs oracle, scalars")
+    assert_f32(p_ref[::4], po, "exact f32 vs oracle, policy")
+    assert_f16(s[G8_PICK], so, "f16 vs oracle, scalars")
+    assert_f16(p[G8_PICK], po, "f16 vs oracle, policy")
 
 
 def test_config_c1_trained_like_activation_scale(dev):
@@ -471,7 +484,7 @@ def test_config_c1_trained_like_activation_scale(dev):
     to the output scale, the split-f16 path inside 1e-4 relative, and the +-65504 range check must stay silent."""
     blob = synth.random_model("chess", 20, 256, "attention", seed=21, block_gain=3.0)
     bits, scalars_in = synth.random_boards("chess", 256, seed=22)
-    pick = C1_PICK[:8]
+    pick = np.array([0, 1, 62, 63, 64, 127, 200, 255])
     net = O.OracleNet(blob)
     dense = O.encode_input_full(bits[pick], scalars_in[pick], net.n_scalar, net.n_bool, net.h, net.w)
     s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
@@ -714,12 +727,12 @@ def test_board_conv_split16_trained_like_scale(dev):
     assert rel_p <= 1e-4 and rel_s <= 1e-4
 
 
-def test_go19_40x256_split16_at_executor_batch_512(dev):
+def test_go19_40x256_split16_at_executor_batch_512(dev, go19_full, go19_full_oracle):
     """The G8 network at its executor batch in the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity):
-    82 per-layer launches in split arithmetic.  All 512 boards: finite, deterministic, batch-size invariant; 1e-4
-    against the exact-f32 path of this library on a 32-board sample and against the real oracle on 8 boards."""
-    blob = synth.random_model("go-19", 40, 256, "conv", seed=33)
-    bits, scalars_in = synth.random_boards("go-19", 512, seed=34)
+    83 per-layer launches in split arithmetic (the stem included since round 4).  All 512 boards: finite, deterministic,
+    batch-size invariant; 1e-4 against the exact-f32 path of this library on a 32-board sample and against the real oracle
+    on 16 boards."""
+    blob, bits, scalars_in = go19_full
     model = capi.Model(blob=blob)
     eng = capi.Engine(model, dev, 512, capi.KZ_DTYPE_F32_SPLIT16)
     assert eng.tower_path == "board_conv_split16" and eng.max_batch == 512
@@ -738,12 +751,10 @@ def test_go19_40x256_split16_at_executor_batch_512(dev):
           f"max |d policy| {np.abs(p[sample] - p_ref).max():.2e}")
     assert_f32(s[sample], s_ref, "scalars, 32 of 512 boards vs exact f32")
     assert_f32(p[sample], p_ref, "policy, 32 of 512 boards vs exact f32")
-    net = O.OracleNet(blob)
-    eight = sample[::4]
-    dense = O.encode_input_full(bits[eight], scalars_in[eight], net.n_scalar, net.n_bool, net.h, net.w)
-    so, po = net.forward(dense, threads=os.cpu_count() or 1)
-    assert_f32(s[eight], so, "split16 vs oracle, scalars")
-    assert_f32(p[eight], po, "split16 vs oracle, policy")
+    so, po = go19_full_oracle
+    assert np.array_equal(sample[::2], G8_PICK)
+    assert_f32(s[G8_PICK], so, "split16 vs oracle, scalars")
+    assert_f32(p[G8_PICK], po, "split16 vs oracle, policy")
 
 
 @pytest.mark.parametrize("game,depth,batch", [("go-19", 2, 5), ("go-9", 2, 11), ("ataxx-7", 2, 13)])

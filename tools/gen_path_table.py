@@ -75,7 +75,7 @@ def markdown(table, rates):
             txt = f"`{p['path']}` ({p['launches']})"
             m = by.get((row["squares"], row["c_in"], row["channels"], row["head"]), {}).get(arith)
             if m and "evals_per_s" in m and m.get("rate_path") == p["path"]:
-                txt += f" **{m['evals_per_s'] / 1e3:,.0f}k** {m['frac_of_peak']:.2f}"
+                txt += f" **{m['evals_per_s'] / 1e3:,.0f}k** {m['frac_of_peak']:.2f} ({m.get('engines', 2)}e)"
             cells.append(txt)
         print(f"| {row['game']} ({row['squares']}) | {row['c_in']} | {row['channels']} | {row['head']} | " + " | ".join(cells) + " |")
 

@@ -3,7 +3,7 @@
 
 For every case and every arithmetic (f32, f16, the parity default): the tower path kz_engine_create chose, the largest
 deviation from the oracle on the case's boards, and the device-resident evals/s at batch 256 (Go 19x19: 128) over
-`--seconds` per point with `--engines` engines round-robin.  GPU box only:
+`--seconds` per point with `--engines` engines round-robin (the best of the listed counts).  GPU box only:
 
     python tools/shape_sweep.py --out gpurun_out/shape_sweep.json [--filter chess_3x192] [--no-oracle]
 """
@@ -53,7 +53,9 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--filter", default="")
     ap.add_argument("--seconds", type=float, default=0.3)
-    ap.add_argument("--engines", type=int, default=2)
+    ap.add_argument("--engines", default="2,3",
+                    help="engines (streams) per point, comma separated: the best rate is recorded with its engine count (the "
+                         "executor's gpu_threads_per_device; 128-channel towers want three, 256-channel ones two)")
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--dtypes", default="f32,f16,parity")
     ap.add_argument("--rate-depth", type=int, default=20,
@@ -93,7 +95,12 @@ def main():
                     rec["max_abs_err"] = float(max(np.abs(s - ref[0]).max(), np.abs(p - ref[1]).max()))
                     rec["logit_scale"] = scale
                 del eng
-                r, (wgs, per), rec["rate_path"] = rate(deep, dtype, case.game, batch, args.seconds, args.engines)
+                best = None
+                for n_eng in [int(x) for x in str(args.engines).split(",")]:
+                    got = rate(deep, dtype, case.game, batch, args.seconds, n_eng)
+                    if best is None or got[0] > best[0][0]:
+                        best = (got, n_eng)
+                (r, (wgs, per), rec["rate_path"]), rec["engines"] = best
                 rec["rate_depth"] = args.rate_depth
                 rec["evals_per_s"] = round(r, 1)
                 peak = 157.3e12 if dn == "f32" else 2.5e15

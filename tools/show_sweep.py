@@ -15,7 +15,7 @@ for r in rows:
     err = r.get("max_abs_err")
     if md:
         print(f"| {r['case']} | {r['c_in']} | {r['squares']} | {r['channels']} | {r['head']} | {r['arith']} ({r['dtype']}) | "
-              f"`{r.get('rate_path', r.get('path', 'ERR'))}` | {r.get('evals_per_s', 0):,.0f} | {r.get('frac_of_peak', 0):.3f} | "
+              f"`{r.get('rate_path', r.get('path', 'ERR'))}` | {r.get('evals_per_s', 0):,.0f} ({r.get('engines', '?')} engines) | {r.get('frac_of_peak', 0):.3f} | "
               f"{'' if err is None else format(err, '.1e')} |")
     else:
         print(f"{r['case']:50s} {r['arith']:7s} {r.get('rate_path', r.get('path', 'ERR')):30s} "
