@@ -32,11 +32,14 @@ extern "C" {
                           KZ_DTYPE_F32_SPLIT16 (its (hi, lo) pairs are f16 too) */
 #define KZ_DTYPE_F32_SPLIT16 2 /* f32 tensors and the same <=1e-4 parity as KZ_DTYPE_F32, but the tower's products run on
                                   the f16 matrix cores: every activation and weight as a (hi, lo) f16 pair, three MFMAs per
-                                  product, f32 accumulate.  One launch per batch for 256 tower channels on <= 64 squares
-                                  or 64 / 128 channels on <= 96 squares; one launch per layer for larger boards (Go 19x19:
-                                  channels a multiple of 64, max_batch * squares * channels * 4 bytes < 2 GiB);
-                                  kz_engine_create fails for other shapes (kz_model_supports_dtype tells).  Everything
-                                  outside the tower is the KZ_DTYPE_F32 path */
+                                  product, f32 accumulate.  One launch per batch for 192 / 256 tower channels on <= 64
+                                  squares or 64 / 128 channels on <= 96 squares, with no more input planes than tower
+                                  channels; one launch per layer otherwise (Go 19x19, wider towers: channels a multiple
+                                  of 64, max_batch * squares * channels * 4 bytes < 2 GiB).  A tower whose channel count
+                                  is no multiple of 64 (48, 96, 160 ... up to 512) runs widened to the next one by
+                                  all-zero filters (same outputs).  kz_engine_create fails for the rest — a tower without
+                                  blocks, more than 512 channels in no multiple of 64 — and kz_model_supports_dtype
+                                  tells.  Everything outside the tower is the KZ_DTYPE_F32 path */
 
 #define KZ_POLICY_ATAXX_CONV 0 /* AtaxxConvPolicyHead, python/lib/model/post_act.py:91-112 */
 #define KZ_POLICY_CONV 1       /* ConvPolicyHead,      post_act.py:54-88 */
@@ -192,8 +195,11 @@ int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_m
  * 32x32x16 tiles, hipGraph replay, ablation knobs) are NOT in this library: `KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh`
  * builds them into a separate libkzhip_exp.so for tests/test_gpu_experiments.py and tools/.
  *
- * Name of the path the engine chose.  One launch for the whole tower: "tower_resident_f16+heads" (chess attention
- * network, heads included), "tower_resident_f16", "tower_resident_f16g" (other board-resident f16 shapes),
+ * Name of the path the engine chose; DESIGN.md 5.0 has the table (shape x arithmetic -> path, launches per batch, measured
+ * rate), printed from kz_model_plan by tools/gen_path_table.py and held to the built library by tests/test_path_table.py.
+ * One launch for the whole tower: "tower_resident_f16+heads" (chess attention
+ * network — ChessStdMapper or ChessHistoryMapper input planes —, heads included), "tower_resident_f16",
+ * "tower_resident_f16g" (other board-resident f16 shapes: 64 .. 512 channels on small boards),
  * "tower_resident_f16g+heads" (the same with the conv policy head and the scalar head inside: 128 / 256 channels),
  * "tower_resident_f32+heads" (exact f32, conv policy heads: decode, tower and heads in one launch), "tower_resident_f32"
  * (exact f32, other heads), "tower_resident_split16+heads" (KZ_DTYPE_F32_SPLIT16: the chess attention network at 256
