@@ -62,13 +62,15 @@ def build():
     return {"max_batch": MAX_BATCH, "paths": paths, "lattice": lattice}
 
 
-def markdown(table, rates):
+def markdown(table, rates, games=None):
     by = {}
     for r in rates:
         by.setdefault((r["squares"], r["c_in"], r["channels"], r["head"]), {})[r["arith"]] = r
     print("| board (squares) | input planes | channels | head | f32 | f16 | parity default |")
     print("|---|---|---|---|---|---|---|")
     for row in table["lattice"]:
+        if games and row["game"] not in games:
+            continue
         cells = []
         for arith in ("f32", "f16", "parity"):
             p = row[arith]
@@ -84,10 +86,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--md", action="store_true")
     ap.add_argument("--rates", default=None)
+    ap.add_argument("--games", default=None, help="comma-separated subset of the lattice's games for --md")
     args = ap.parse_args()
     if args.md:
         rates = json.load(open(args.rates))["rows"] if args.rates else []
-        markdown(json.load(open(OUT)), rates)
+        markdown(json.load(open(OUT)), rates, args.games.split(",") if args.games else None)
     else:
         json.dump(build(), open(OUT, "w"), indent=1, sort_keys=True)
         print("wrote", OUT)
