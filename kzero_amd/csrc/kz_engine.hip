@@ -25,409 +25,8 @@
 
 namespace {
 
-thread_local std::string g_err;
-
-int fail(const std::string &msg) {
-    g_err = msg;
-    return 1;
-}
-
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return fail(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
-                        std::to_string(__LINE__) + ")");                                               \
-    } while (0)
-
-using kz::Conv;
-using kz::Linear;
-using kz::Model;
-using kz::round_up;
-
-uint16_t f32_to_f16_bits(float f) {
-    _Float16 h = (_Float16)f;  // round-to-nearest-even, same conversion the device uses
-    uint16_t b;
-    memcpy(&b, &h, 2);
-    return b;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Device weights, shared by all engines of one (model, device, dtype)
-// ------------------------------------------------------------------------------------------------
-struct DevConv {  // packed for kz_conv_igemm: [k*k][cout_p][cin_p] in T, bias f32 [cout_p]
-    void *w = nullptr;
-    float *b = nullptr;
-    int cin_p = 0, cout_p = 0, cout = 0, k = 1;
-    void *bw = nullptr;  // instead of w: packed for kz_board_conv_f16 (3x3, f16, channels % 64 == 0)
-    bool bw2 = false;    // ... packed for kz_board_conv2_f16 (two Go-size boards per workgroup)
-    void *bws = nullptr; // instead of w: (hi, lo) pairs packed for kz_board_conv_split16 (3x3, split arithmetic)
-    void *sw = nullptr;  // in addition to w: (hi, lo) f16 pairs for kz_conv1x1_split (1x1 head convolutions, split16)
-};
-
-struct DeviceWeights {
-    int device = 0, dtype = 0;
-    std::vector<void *> allocs;
-
-    std::vector<DevConv> tower;  // generic path
-    float *post_scale = nullptr, *post_shift = nullptr;
-
-    // resident tower
-    bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
-    bool fused_split = false;  // the split launch carries the heads (set before build)
-    bool fused_pairs = false;  // the plain-f16 generic launch carries the conv policy heads (set before build)
-    float *h32_small = nullptr;  // the fused f32 heads' small 1x1 convolutions (tower32_pack_small_weights)
-    void *res32_w = nullptr;  // f32 resident launch (exact f32, or split f16 pairs): one packed weight stream
-    void *res_w_stem = nullptr, *res_w_tower = nullptr;
-    float *res_bias = nullptr;
-    int32_t *att_idx = nullptr;
-
-    // scalar head
-    float *sh_w0 = nullptr, *sh_b0 = nullptr, *sh_w1 = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
-    float *sh_w1t = nullptr;  // sh_w1 transposed: [inputs][outputs]
-    float *sh_w0x = nullptr;  // [hc + 1][C]: the scalar head's 1x1 filters followed by ConvPolicyHead's extra-move filter
-    // policy
-    DevConv p_conv0;                                   // conv / ataxx_conv / dense hidden conv
-    float *p_w1 = nullptr, *p_b1 = nullptr;            // last 1x1 conv of the conv heads
-    float *pe_wc = nullptr, *pe_bc = nullptr, *pe_wl = nullptr, *pe_bl = nullptr;  // seq_extra
-    DevConv p_bulk, p_under;
-    int32_t *flat_to_att = nullptr;
-    DevConv p_fc0, p_fc1;
-
-    ~DeviceWeights() {
-        (void)hipSetDevice(device);
-        for (void *p : allocs) (void)hipFree(p);
-    }
-
-    int upload(const void *src, size_t bytes, void **dst) {
-        HIP_TRY(hipMalloc(dst, bytes ? bytes : 16));
-        allocs.push_back(*dst);
-        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-        return 0;
-    }
-    int upload_f32(const std::vector<float> &v, float **dst) { return upload(v.data(), v.size() * 4, (void **)dst); }
-
-    // values [rows][cols] f32 -> T [rows_p][cols_p], zero padded
-    int upload_matrix(const std::vector<float> &v, int rows, int cols, int rows_p, int cols_p, void **dst) {
-        if (dtype == KZ_DTYPE_F32) {
-            std::vector<float> p((size_t)rows_p * cols_p, 0.0f);
-            for (int r = 0; r < rows; r++)
-                for (int c = 0; c < cols; c++) p[(size_t)r * cols_p + c] = v[(size_t)r * cols + c];
-            return upload(p.data(), p.size() * 4, dst);
-        }
-        std::vector<uint16_t> p((size_t)rows_p * cols_p, 0);
-        for (int r = 0; r < rows; r++)
-            for (int c = 0; c < cols; c++) p[(size_t)r * cols_p + c] = f32_to_f16_bits(v[(size_t)r * cols + c]);
-        return upload(p.data(), p.size() * 2, dst);
-    }
-
-    // 3x3 tower conv for the board-tile kernel (kz_board_conv.hip)
-    // (the stem's few input planes are padded with zero weights to the kernel's 64-channel chunk: cin_pad)
-    int upload_board_conv(const Conv &cv, DevConv &d, int cin_pad = 0) {
-        d.k = 3;
-        d.cout = d.cout_p = cv.cout;
-        const int cin = cin_pad ? cin_pad : cv.cin;
-        d.cin_p = cin;
-        std::vector<float> padded;
-        const float *w = cv.w.data();
-        if (cin != cv.cin) {
-            padded.assign((size_t)cv.cout * cin * 9, 0.0f);
-            for (int o = 0; o < cv.cout; o++)
-                for (int i = 0; i < cv.cin; i++)
-                    for (int t = 0; t < 9; t++) padded[((size_t)o * cin + i) * 9 + t] = cv.w[((size_t)o * cv.cin + i) * 9 + t];
-            w = padded.data();
-        }
-        std::vector<uint16_t> packed(kz::board_conv_weight_elems(cin, cv.cout));
-#ifdef KZ_EXPERIMENTS
-        d.bw2 = conv2;
-        if (conv2) kz::board_conv2_pack_weights(w, cv.cout, cin, packed.data());
-        else
-#endif
-        kz::board_conv_pack_weights(w, cv.cout, cin, packed.data());
-        if (upload(packed.data(), packed.size() * 2, &d.bw)) return 1;
-        return upload_f32(cv.b, &d.b);
-    }
-
-    // the same convolution for the board-tile kernel in split arithmetic
-    // (cin_pad: the stem's few input planes padded with zero weights to the kernel's 32-channel chunk)
-    int upload_board_conv_split(const Conv &cv, DevConv &d, int cin_pad = 0) {
-        d.k = 3;
-        d.cout = d.cout_p = cv.cout;
-        const int cin = cin_pad ? cin_pad : cv.cin;
-        d.cin_p = cin;
-        std::vector<float> padded;
-        const float *w = cv.w.data();
-        if (cin != cv.cin) {
-            padded.assign((size_t)cv.cout * cin * 9, 0.0f);
-            for (int o = 0; o < cv.cout; o++)
-                for (int i = 0; i < cv.cin; i++)
-                    for (int t = 0; t < 9; t++) padded[((size_t)o * cin + i) * 9 + t] = cv.w[((size_t)o * cv.cin + i) * 9 + t];
-            w = padded.data();
-        }
-        std::vector<uint16_t> packed(kz::board_conv_split_weight_elems(cin, cv.cout));
-        kz::board_conv_split_pack_weights(w, cv.cout, cin, packed.data());
-        if (upload(packed.data(), packed.size() * 2, &d.bws)) return 1;
-        return upload_f32(cv.b, &d.b);
-    }
-
-    // OIHW conv -> [tap][cout_p][cin_p]; tap = ky*k + kx
-    int upload_conv(const Conv &cv, DevConv &d) {
-        d.k = cv.k;
-        d.cout = cv.cout;
-        d.cin_p = round_up(cv.cin, 32);
-        d.cout_p = round_up(cv.cout, 32);
-        const int taps = cv.k * cv.k;
-        std::vector<float> flat((size_t)taps * d.cout_p * d.cin_p, 0.0f);
-        for (int o = 0; o < cv.cout; o++)
-            for (int i = 0; i < cv.cin; i++)
-                for (int t = 0; t < taps; t++)
-                    flat[((size_t)t * d.cout_p + o) * d.cin_p + i] = cv.w[((size_t)o * cv.cin + i) * taps + t];
-        if (upload_matrix(flat, taps * d.cout_p, d.cin_p, taps * d.cout_p, d.cin_p, &d.w)) return 1;
-        // 1x1 head convolutions: the tiled GEMM of kz_tower_split.hip in split arithmetic (split16) or plain f16
-        if ((split16 || dtype == KZ_DTYPE_F16) && cv.k == 1 && kz::conv1x1_split_supported(d.cin_p, d.cout_p)) {
-            std::vector<uint16_t> packed(kz::conv1x1_split_weight_elems(d.cin_p, d.cout_p, split16));
-            kz::conv1x1_split_pack_weights(cv.w.data(), cv.cout, cv.cin, d.cout_p, d.cin_p, split16, packed.data());
-            if (upload(packed.data(), packed.size() * 2, &d.sw)) return 1;
-        }
-        std::vector<float> b(d.cout_p, 0.0f);
-        for (int o = 0; o < cv.cout; o++) b[o] = cv.b[o];
-        return upload_f32(b, &d.b);
-    }
-
-    // nn.Linear over a channel-major flatten of [ch][hw] (index c*hw + p) applied to NHWC rows [hw][ch_p]:
-    // re-index the input dimension to p*ch_p + c and run it as a 1x1 "convolution" over one row per board.
-    int upload_flat_linear(const Linear &l, int ch, int hw, int ch_p, DevConv &d) {
-        d.k = 1;
-        d.cout = l.out;
-        d.cout_p = round_up(l.out, 32);
-        d.cin_p = hw * ch_p;
-        std::vector<float> flat((size_t)d.cout_p * d.cin_p, 0.0f);
-        for (int o = 0; o < l.out; o++)
-            for (int c = 0; c < ch; c++)
-                for (int p = 0; p < hw; p++)
-                    flat[(size_t)o * d.cin_p + (size_t)p * ch_p + c] = l.w[(size_t)o * l.in + (size_t)c * hw + p];
-        if (upload_matrix(flat, d.cout_p, d.cin_p, d.cout_p, d.cin_p, &d.w)) return 1;
-        std::vector<float> b(d.cout_p, 0.0f);
-        for (int o = 0; o < l.out; o++) b[o] = l.b[o];
-        return upload_f32(b, &d.b);
-    }
-
-    int upload_linear(const Linear &l, DevConv &d) {
-        d.k = 1;
-        d.cout = l.out;
-        d.cout_p = round_up(l.out, 32);
-        d.cin_p = round_up(l.in, 32);
-        std::vector<float> flat((size_t)d.cout_p * d.cin_p, 0.0f);
-        for (int o = 0; o < l.out; o++)
-            for (int i = 0; i < l.in; i++) flat[(size_t)o * d.cin_p + i] = l.w[(size_t)o * l.in + i];
-        if (upload_matrix(flat, d.cout_p, d.cin_p, d.cout_p, d.cin_p, &d.w)) return 1;
-        std::vector<float> b(d.cout_p, 0.0f);
-        for (int o = 0; o < l.out; o++) b[o] = l.b[o];
-        return upload_f32(b, &d.b);
-    }
-
-    bool use_board_conv = false;
-    bool use_board_split = false;  // split16 on a board too large for the resident launch: per-layer board-tile kernel
-    int stem_cin_p = 0;  // != 0: the stem goes through the board-tile kernel and wants encoded rows of this many channels
-    bool stem_split = false;  // split16 per layer: the stem too goes through kz_board_conv_split16 (<= 32 input planes)
-    bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
-    int *bc_rowmap = nullptr;  // (experiment build: kz_board_conv2_f16's tile-row map and halo-row list)
-    unsigned short *bc_halo = nullptr;
-    int bc_n_halo = 0;
-    int build(const Model &m, bool want_resident, bool want_fused, bool want_resident32, bool want_split16,
-              bool want_pairs16) {
-        resident32 = want_resident32;
-        split16 = want_split16;
-        pairs16 = want_pairs16;  // kz_tower_resident_split without the lo halves: plain f16, generic shapes
-        const int C = m.channels, cp = round_up(C, 32), hw = m.h * m.w;
-        HIP_TRY(hipSetDevice(device));
-        resident = want_resident;
-        fused_heads = want_resident && want_fused;
-
-        std::vector<float> ps(cp, 1.0f), pt(cp, 0.0f);
-        for (int i = 0; i < C; i++) {
-            ps[i] = m.final_scale[i];
-            pt[i] = m.final_shift[i];
-        }
-        if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
-
-        if ((split16 && !use_board_split) || pairs16) {
-            // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 * ceil(c_in / 32) stem k-steps, then 9*C/32 per convolution
-            // (+ the attention heads' five passes and bias rows when the split launch carries the heads)
-            const bool conv_heads = (split16 && fused_split && m.policy_kind != kz::POLICY_ATTENTION) || (pairs16 && fused_pairs);  // (Ataxx, Go 9x9)
-            const bool heads = split16 && fused_split && !conv_heads;
-            const size_t tower_elems = kz::tower_split_weight_elems(C, m.depth, m.c_in, split16);
-            std::vector<uint16_t> packed(tower_elems + (heads ? kz::tower_split_heads_weight_elems() : 0) +
-                                         (conv_heads ? kz::tower_split_conv_heads_weight_elems(C, split16) : 0));
-            const size_t step_elems = (size_t)(split16 ? 2 : 1) * C * 32, stem_elems = kz::tower_split_stem_elems(C, m.c_in, split16),
-                         layer_elems = (size_t)9 * (C / 32) * step_elems;
-            kz::tower_split_pack_weights(m.tower[0].w.data(), C, m.c_in, hw, true, split16, packed.data());
-            for (int l = 0; l < 2 * m.depth; l++)
-                kz::tower_split_pack_weights(m.tower[1 + l].w.data(), C, C, hw, false, split16,
-                                             packed.data() + stem_elems + layer_elems * l);
-            std::vector<float> bias((size_t)(1 + 2 * m.depth + (heads ? 5 : conv_heads ? 1 : 0)) * C);
-            for (int l = 0; l < 1 + 2 * m.depth; l++)
-                for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
-            if (conv_heads) {  // the policy head's hidden layer as one more pass; the small convolutions as for the f32 launch
-                kz::tower_split_pack_conv_heads(m.p_conv0.w.data(), C, split16, packed.data() + tower_elems);
-                for (int o = 0; o < C; o++) bias[(size_t)(1 + 2 * m.depth) * C + o] = m.p_conv0.b[o];
-                std::vector<float> small(kz::tower32_small_weight_elems(C));
-                kz::tower32_pack_small_weights(m.sh_conv.w.data(), m.sh_conv.cout,
-                                               m.policy_extra_moves ? m.p_extra_conv.w.data() : nullptr, m.p_conv1.w.data(),
-                                               m.policy_conv_channels, C, small.data());
-                if (upload_f32(small, &h32_small)) return 1;
-            }
-            if (heads) {
-                kz::tower_split_pack_heads(m.p_bulk.w.data(), m.p_bulk.b.data(), m.p_under.w.data(), m.p_under.b.data(),
-                                           packed.data() + tower_elems, bias.data() + (size_t)(1 + 2 * m.depth) * C);
-                std::vector<int32_t> idx(m.flat_to_att.size());
-                for (size_t i = 0; i < idx.size(); i++) idx[i] = (m.flat_to_att[i] / 88) * 96 + m.flat_to_att[i] % 88;
-                if (upload(idx.data(), idx.size() * 4, (void **)&att_idx)) return 1;
-            }
-            if (upload(packed.data(), packed.size() * 2, &res32_w)) return 1;
-            if (upload_f32(bias, &res_bias)) return 1;
-        } else if (resident32) {
-            // (the conv policy head's first 1x1 conv rides at the end of the stream whenever the launch can fuse the
-            // heads; a launch without heads never reads it)
-            const bool heads32 = kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves,
-                                                             m.policy_conv_channels, m.h, m.w, C, m.sh_conv.cout, m.sh_fc0.out);
-            const size_t tower_elems = kz::tower32_weight_elems(m.c_in, C, m.depth);
-            std::vector<float> packed(tower_elems + (heads32 ? kz::tower32_heads_weight_elems(C) : 0) +
-                                      kz::tower32_weight_pad_elems(C), 0.0f);
-            const size_t stem_elems = (size_t)9 * ((m.c_in + 15) / 16) * 16 * C, layer_elems = (size_t)9 * C * C;
-            kz::tower32_pack_weights(m.tower[0].w.data(), C, m.c_in, true, packed.data());
-            for (int l = 0; l < 2 * m.depth; l++)
-                kz::tower32_pack_weights(m.tower[1 + l].w.data(), C, C, false, packed.data() + stem_elems + layer_elems * l);
-            std::vector<float> bias((size_t)(1 + 2 * m.depth + (heads32 ? 1 : 0)) * C);
-            for (int l = 0; l < 1 + 2 * m.depth; l++)
-                for (int o = 0; o < C; o++) bias[(size_t)l * C + o] = m.tower[l].b[o];
-            if (heads32) {
-                kz::tower32_pack_head_weights(m.p_conv0.w.data(), C, packed.data() + tower_elems);
-                for (int o = 0; o < C; o++) bias[(size_t)(1 + 2 * m.depth) * C + o] = m.p_conv0.b[o];
-                std::vector<float> small(kz::tower32_small_weight_elems(C));
-                kz::tower32_pack_small_weights(m.sh_conv.w.data(), m.sh_conv.cout,
-                                               m.policy_extra_moves ? m.p_extra_conv.w.data() : nullptr, m.p_conv1.w.data(),
-                                               m.policy_conv_channels, C, small.data());
-                if (upload_f32(small, &h32_small)) return 1;
-            }
-            if (upload(packed.data(), packed.size() * 4, &res32_w)) return 1;
-            if (upload_f32(bias, &res_bias)) return 1;
-        } else if (resident) {
-            const int cin_p = round_up(m.c_in, 32);
-            const size_t stem_elems = (size_t)9 * 256 * cin_p, layer_elems = (size_t)9 * 256 * 256;
-            const size_t head_elems = fused_heads ? kz::tower_heads_weight_elems() : 0;
-            std::vector<uint16_t> stem(stem_elems), rest(layer_elems * 2 * m.depth + head_elems);
-            kz::tower_pack_weights(m.tower[0].w.data(), C, m.c_in, cin_p, stem.data());
-            for (int l = 0; l < 2 * m.depth; l++)
-                kz::tower_pack_weights(m.tower[1 + l].w.data(), C, C, 256, rest.data() + layer_elems * l);
-            std::vector<float> bias((size_t)(1 + 2 * m.depth + (fused_heads ? 5 : 0)) * 256);
-            for (int l = 0; l < 1 + 2 * m.depth; l++)
-                for (int o = 0; o < 256; o++) bias[(size_t)l * 256 + o] = m.tower[l].b[o];
-            if (fused_heads) {
-                kz::tower_pack_heads(m.p_bulk.w.data(), m.p_bulk.b.data(), m.p_under.w.data(), m.p_under.b.data(),
-                                     rest.data() + layer_elems * 2 * m.depth, bias.data() + (size_t)(1 + 2 * m.depth) * 256);
-                std::vector<int32_t> idx(m.flat_to_att.size());
-                for (size_t i = 0; i < idx.size(); i++) idx[i] = (m.flat_to_att[i] / 88) * 96 + m.flat_to_att[i] % 88;
-                if (upload(idx.data(), idx.size() * 4, (void **)&att_idx)) return 1;
-            }
-            if (upload(stem.data(), stem.size() * 2, &res_w_stem)) return 1;
-            if (upload(rest.data(), rest.size() * 2, &res_w_tower)) return 1;
-            if (upload_f32(bias, &res_bias)) return 1;
-        } else {
-            tower.resize(m.tower.size());
-            const char *noboard = getenv("KZ_NO_BOARD_CONV");
-#ifdef KZ_EXPERIMENTS
-            if (use_board_conv && !(noboard && noboard[0] == '1')) {
-                const char *c2 = getenv("KZ_BOARD_CONV2");
-                // (experiment, opt-in: the second organisation measured 26.2k against 33.5k evals/s on Go-19 40x256)
-                conv2 = c2 && c2[0] == '1' && kz::board_conv2_supported(dtype, m.h, m.w, m.channels, m.channels);
-                if (conv2) {  // its tile-row map and halo-row list (the product kernel needs no tables)
-                    std::vector<int> rowmap;
-                    std::vector<unsigned short> halo;
-                    kz::board_conv2_tables(m.h, m.w, rowmap, halo);
-                    bc_n_halo = (int)halo.size();
-                    if (upload(rowmap.data(), rowmap.size() * sizeof(int), (void **)&bc_rowmap)) return 1;
-                    if (upload(halo.data(), halo.size() * sizeof(unsigned short), (void **)&bc_halo)) return 1;
-                }
-            }
-#endif
-            for (size_t i = 0; i < m.tower.size(); i++) {
-                const bool on = use_board_conv && !(noboard && noboard[0] == '1');
-                // the stem joins the board-tile family with its input planes padded to one 64-channel chunk (the encode
-                // kernel then writes 64-channel rows): a quarter of a tower layer's work instead of an implicit GEMM
-                const bool stem64 = on && i == 0 && !conv2 && m.tower[0].cin <= 64 && m.tower[0].k == 3 &&
-                                    kz::board_conv_supported(dtype, m.h, m.w, 64, m.tower[0].cout);
-                const bool board = on && kz::board_conv_supported(dtype, m.h, m.w, m.tower[i].cin, m.tower[i].cout);
-                if (use_board_split && i == 0 && m.tower[0].cin <= 32 && m.tower[0].k == 3) {
-                    // the stem through the same kernel: its input planes as one 32-channel chunk of (hi, lo) rows — an
-                    // eighth of a 256-channel layer's work instead of an exact-f32 implicit GEMM and a splitting pass
-                    stem_split = true;
-                    if (upload_board_conv_split(m.tower[0], tower[0], 32)) return 1;
-                } else if (use_board_split && i >= 1) {  // (a stem of more than 32 planes stays an exact-f32 implicit GEMM)
-                    if (upload_board_conv_split(m.tower[i], tower[i])) return 1;
-                } else if (stem64) {
-                    stem_cin_p = 64;
-                    if (upload_board_conv(m.tower[0], tower[0], 64)) return 1;
-                } else if (board ? upload_board_conv(m.tower[i], tower[i]) : upload_conv(m.tower[i], tower[i])) {
-                    return 1;
-                }
-            }
-        }
-
-        // scalar head: w0 [hc][C] is the OIHW 1x1 conv as is; w1 keeps the channel-major flatten order
-        if (upload_f32(m.sh_conv.w, &sh_w0) || upload_f32(m.sh_conv.b, &sh_b0) || upload_f32(m.sh_fc0.w, &sh_w1) ||
-            upload_f32(m.sh_fc0.b, &sh_b1) || upload_f32(m.sh_fc1.w, &sh_w2) || upload_f32(m.sh_fc1.b, &sh_b2))
-            return 1;
-        {
-            std::vector<float> wt((size_t)m.sh_fc0.in * m.sh_fc0.out);
-            for (int o = 0; o < m.sh_fc0.out; o++)
-                for (int i = 0; i < m.sh_fc0.in; i++) wt[(size_t)i * m.sh_fc0.out + o] = m.sh_fc0.w[(size_t)o * m.sh_fc0.in + i];
-            if (upload_f32(wt, &sh_w1t)) return 1;
-        }
-
-        if (fused_heads) return 0;  // the policy head lives in the tower's weight stream
-        switch (m.policy_kind) {
-            case kz::POLICY_ATAXX_CONV:
-            case kz::POLICY_CONV:
-                if (upload_conv(m.p_conv0, p_conv0)) return 1;
-                if (upload_f32(m.p_conv1.w, &p_w1) || upload_f32(m.p_conv1.b, &p_b1)) return 1;
-                if (m.policy_extra_moves) {
-                    if (upload_f32(m.p_extra_conv.w, &pe_wc) || upload_f32(m.p_extra_conv.b, &pe_bc) ||
-                        upload_f32(m.p_extra_fc.w, &pe_wl) || upload_f32(m.p_extra_fc.b, &pe_bl))
-                        return 1;
-                    if (m.sh_conv.cout == 4 && m.p_extra_conv.cout == 1 && m.p_extra_conv.cin == m.sh_conv.cin) {
-                        std::vector<float> w0x(m.sh_conv.w);  // [4][C] ...
-                        w0x.insert(w0x.end(), m.p_extra_conv.w.begin(), m.p_extra_conv.w.end());  // ... + [1][C]
-                        if (upload_f32(w0x, &sh_w0x)) return 1;
-                    }
-                }
-                break;
-            case kz::POLICY_ATTENTION:
-                if (upload_conv(m.p_bulk, p_bulk) || upload_conv(m.p_under, p_under)) return 1;
-                if (upload(m.flat_to_att.data(), m.flat_to_att.size() * 4, (void **)&flat_to_att)) return 1;
-                break;
-            case kz::POLICY_DENSE: {
-                int ch = C, ch_p = cp;
-                if (m.dense_hidden_channels) {
-                    if (upload_conv(m.p_conv0, p_conv0)) return 1;
-                    ch = m.dense_hidden_channels;
-                    ch_p = p_conv0.cout_p;
-                }
-                if (m.dense_hidden_size) {
-                    if (upload_flat_linear(m.p_fc0, ch, hw, ch_p, p_fc0)) return 1;
-                    if (upload_linear(m.p_fc1, p_fc1)) return 1;
-                } else {
-                    if (upload_flat_linear(m.p_fc1, ch, hw, ch_p, p_fc1)) return 1;
-                }
-                break;
-            }
-        }
-        return 0;
-    }
-};
-
-std::mutex g_cache_mutex;
-std::map<std::tuple<const Model *, int, int, bool, bool, bool>, std::weak_ptr<DeviceWeights>> g_cache;
+#include "kz_engine_util.hpp"     // g_err, fail, HIP_TRY
+#include "kz_device_weights.hpp"  // DevConv, DeviceWeights, the per-(model, device, dtype) cache
 
 struct Prof {
     struct Rec {
@@ -471,126 +70,7 @@ struct Prof {
 };
 
 
-// ------------------------------------------------------------------------------------------------
-// Which kernels run a network: pure host logic over the kernels' support predicates (no HIP call), shared by
-// kz_engine_create and kz_model_plan — DESIGN.md §5.0 prints its table from it and tests/test_path_table.py holds it to
-// tests/golden/path_table.json without a GPU.
-//
-//   dtype f16:         8x8, 256 channels, <= 224 planes          -> tower_resident_f16 [+heads: attention head, Q = 256]
-//                      else a shape of kz_tower_split.hip        -> tower_resident_f16g [+heads: conv heads at 128 / 256]
-//                      else channels % 64 == 0, >= 160 workgroups -> board_conv_f16          (one launch per layer)
-//                      else                                       -> conv_igemm_f16          (one launch per layer)
-//   dtype f32:         128 / 256 channels on a small board        -> tower_resident_f32 [+heads: conv heads]
-//                      else                                       -> conv_igemm_f32
-//   dtype f32split16:  a shape of kz_tower_split.hip (split)      -> tower_resident_split16 [+heads]
-//                      else channels % 64 == 0                    -> board_conv_split16      (one launch per layer)
-//                      else                                       -> refused (kz_model_supports_dtype says 0)
-// ------------------------------------------------------------------------------------------------
-struct PathPlan {
-    bool resident = false, fused_heads = false, resident32 = false, split16 = false, bsplit = false, pairs16 = false;
-    bool fused32 = false, fused_split = false, fused_pairs = false, board_conv = false, keep = false;
-    std::string path;
-    int launches = 0;  // kernel launches per batch through the packed-input entry points
-};
-
-bool env_on(const char *name) {
-    const char *v = getenv(name);
-    return v && v[0] == '1';
-}
-
-// launches of run_heads for a network whose tower output is materialised (head convolutions with cout_p = round_up(cout, 32))
-int head_launches(const Model &m, int dtype, bool split16, int cp) {
-    int n = 1;  // kz_scalar_head
-    const bool f16_heads = split16 || dtype == KZ_DTYPE_F16;  // 1x1 head convolutions through kz_conv1x1_split where it fits
-    switch (m.policy_kind) {
-        case kz::POLICY_ATAXX_CONV:
-        case kz::POLICY_CONV: {
-            const int c0_in = round_up(m.p_conv0.cin, 32), c0_out = round_up(m.p_conv0.cout, 32);
-            const bool one = m.policy_kind == kz::POLICY_CONV && f16_heads && kz::conv1x1_split_supported(c0_in, c0_out) && cp >= c0_in &&
-                             kz::conv1x1_policy_epilogue_supported(c0_in, c0_out, m.p_conv0.cout, m.policy_conv_channels);
-            n += one ? 1 : 2;
-            if (m.policy_kind == kz::POLICY_CONV && m.policy_extra_moves) {
-                const bool in_scalar_head = m.sh_conv.cout == 4 && m.p_extra_conv.cout == 1 && m.p_extra_conv.cin == m.sh_conv.cin &&
-                                            kz::scalar_head_takes_extra(dtype == KZ_DTYPE_F32 || split16 ? 0 : 1, cp, m.sh_conv.cout);
-                n += in_scalar_head ? 0 : 1;
-            }
-            break;
-        }
-        case kz::POLICY_ATTENTION: n += 3; break;
-        case kz::POLICY_DENSE: n += (m.dense_hidden_channels ? 1 : 0) + (m.dense_hidden_size ? 2 : 1); break;
-    }
-    return n;
-}
-
-// dtype_in: KZ_DTYPE_F32 / KZ_DTYPE_F16 / KZ_DTYPE_F32_SPLIT16.  false + why: kz_engine_create refuses.
-bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::string &why) {
-    const bool split16 = dtype_in == KZ_DTYPE_F32_SPLIT16;
-    const int dtype = split16 ? KZ_DTYPE_F32 : dtype_in;  // KZ_DTYPE_F32_SPLIT16 is the f32 engine with one kernel exchanged
-    const int cp = round_up(m.channels, 32);
-    const bool force = env_on("KZ_FORCE_GENERIC"), nofuse = env_on("KZ_NO_FUSED_HEADS"), noboard = env_on("KZ_NO_BOARD_CONV");
-    p = PathPlan();
-    p.resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth, m.c_in) && !force;
-    p.fused_heads = p.resident && !nofuse &&
-                    kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout, m.sh_fc0.out);
-    // the board-tile kernel needs enough workgroups to fill the chip (two per CU when it is busy)
-    const bool board_conv_ok = !p.resident && !noboard && m.depth >= 1 &&
-                               kz::board_conv_supported(dtype, m.h, m.w, m.channels, m.channels) &&
-                               kz::board_conv_workgroups(max_batch, m.h, m.w, m.channels) >= 160 &&
-                               (size_t)max_batch * m.h * m.w * m.channels * 2 < ((size_t)1 << 31);  // 32-bit buffer offsets
-    p.keep = env_on("KZ_KEEP_ACTIVATIONS") && !p.resident;
-    // exact-f32 resident launch (the per-layer activation taps of KZ_KEEP_ACTIVATIONS need the per-layer path)
-    p.resident32 = kz::tower32_supported(dtype, m.h, m.w, m.channels, m.depth) && !force && !p.keep;
-    // split arithmetic per layer for boards the resident split launch cannot hold (Go 19x19)
-    const bool split_resident = kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, true);
-    const bool board_split_ok = split16 && !split_resident && m.depth >= 1 && !p.keep &&
-                                kz::board_conv_split_supported(m.h, m.w, m.channels, m.channels) && m.channels % 32 == 0 &&
-                                (size_t)max_batch * m.h * m.w * m.channels * 4 < ((size_t)1 << 31);
-    if (board_split_ok) {
-        p.split16 = p.bsplit = true;
-        p.resident32 = false;  // (a shape the exact-f32 launch takes too stays per layer here)
-    } else if (split16) {
-        if (!split_resident) {
-            why = "KZ_DTYPE_F32_SPLIT16 needs a shape of the one-launch split tower (256 tower channels on a board of at most 64 "
-                  "squares, 192 on at most 64, 64 / 128 channels on at most 96 squares, and no more input planes than tower "
-                  "channels); or, per layer, tower channels a multiple of 64, at least one block and max_batch * squares * "
-                  "channels * 4 bytes < 2 GiB";
-            return false;
-        }
-        p.split16 = p.resident32 = true;  // same tensors in and out as the exact-f32 resident launch
-    }
-    // plain-f16 board-resident tower for the shapes the chess launch (kz_tower.hip) does not take: the split kernel
-    // without its lo halves
-    p.pairs16 = dtype == KZ_DTYPE_F16 && !p.resident && !force && !p.keep && !env_on("KZ_NO_RESIDENT_F16G") &&
-                kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
-    p.board_conv = board_conv_ok && !p.pairs16 && !p.bsplit;
-    p.fused_pairs = p.pairs16 && !nofuse &&
-                    kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
-                                                         m.channels, m.sh_conv.cout, m.sh_fc0.out, false);
-    p.fused32 = p.resident32 && !p.split16 && !nofuse &&
-                kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w, m.channels,
-                                            m.sh_conv.cout, m.sh_fc0.out);
-    p.fused_split = p.split16 && !p.bsplit && !nofuse &&
-                    (kz::tower_split_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.h, m.w, m.channels,
-                                                     m.sh_conv.cout, m.sh_fc0.out) ||
-                     kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
-                                                          m.channels, m.sh_conv.cout, m.sh_fc0.out, true));
-    p.path = p.fused_heads   ? "tower_resident_f16+heads"
-             : p.resident    ? "tower_resident_f16"
-             : p.bsplit      ? "board_conv_split16"
-             : p.fused_split ? "tower_resident_split16+heads"
-             : p.split16     ? "tower_resident_split16"
-             : p.fused32     ? "tower_resident_f32+heads"
-             : p.resident32  ? "tower_resident_f32"
-             : p.fused_pairs ? "tower_resident_f16g+heads"
-             : p.pairs16     ? "tower_resident_f16g"
-             : p.board_conv  ? "board_conv_f16"
-                             : (dtype == KZ_DTYPE_F32 ? "conv_igemm_f32" : "conv_igemm_f16");
-    const bool fused = p.fused_heads || p.fused32 || p.fused_split || p.fused_pairs;
-    const bool one_launch_tower = p.resident || p.resident32 || p.pairs16;  // (board encode inside)
-    p.launches = fused ? 1
-                 : (one_launch_tower ? 1 : p.bsplit ? 3 + 2 * m.depth : 2 + 2 * m.depth) + head_launches(m, dtype, p.split16, cp);
-    return true;
-}
+#include "kz_plan.hpp"  // PathPlan, plan_path: which kernels run a network
 
 }  // namespace
 

@@ -1,5 +1,5 @@
 """Which path a network takes: the committed table equals what the built library's selector chooses.
-`kz_model_plan` is the host logic `kz_engine_create` runs (kzero_amd/csrc/kz_engine.hip: plan_path) — no GPU needed."""
+`kz_model_plan` is the host logic `kz_engine_create` runs (kzero_amd/csrc/kz_plan.hpp: plan_path) — no GPU needed."""
 import json
 import os
 import sys
