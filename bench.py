@@ -303,9 +303,14 @@ class Workload:
         so that a short --steps/--warmup run measures the same steady state as a long one."""
         t_end = time.perf_counter() + seconds
         i = 0
+        burst = 4 * len(self.engines)
         while time.perf_counter() < t_end:
             step(i)
             i += 1
+            if i % burst == 0:
+                # (back-pressure: launches are enqueued far faster than a slow network executes them — a 7.6 ms launch
+                # enqueued for a quarter of a second is a minute of queued work that the sync below would then wait for)
+                self.sync()
         self.sync()
         return i
 
