@@ -80,7 +80,8 @@ def _bn(rng, t, prefix, c):
 
 def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0, query_channels: int = None,
                  n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0,
-                 dense_hidden_channels: int = None, dense_hidden_size: int = None) -> bytes:
+                 dense_hidden_channels: int = None, dense_hidden_size: int = None, scalar_hidden_channels: int = 4,
+                 final_affine: bool = True) -> bytes:
     """`block_gain` > 1 scales every block's second BatchNorm weight: the residual stream then grows from block to block
     the way a trained network's does (a random-init tower keeps it within a few tens)."""
     g = game_spec(game)
@@ -92,8 +93,8 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
     meta = {
         "game": game, "board_h": size, "board_w": size,
         "input_scalar_channels": n_scalar, "input_bool_channels": n_bool,
-        "tower_depth": depth, "tower_channels": C, "tower_final_affine": 1,
-        "scalar_hidden_channels": 4, "scalar_hidden_size": scalar_hidden_size,
+        "tower_depth": depth, "tower_channels": C, "tower_final_affine": 1 if final_affine else 0,
+        "scalar_hidden_channels": scalar_hidden_channels, "scalar_hidden_size": scalar_hidden_size,
         "policy_kind": head, "policy_len": g["policy_len"], "bn_eps": 1e-5,
     }
     _conv(rng, t, "common.tower.0", C, n_scalar + n_bool, 3)
@@ -113,8 +114,10 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
         if block_gain != 1.0:
             t[f"common.tower.{i}.seq.4.weight"] *= np.float32(block_gain)
     _bn(rng, t, f"common.tower.{depth + 1}", C)
-    _conv(rng, t, "scalar_head.seq.0", 4, C, 1)
-    _linear(rng, t, "scalar_head.seq.3", scalar_hidden_size, 4 * hw)
+    if not final_affine:  # ResTower(..., final_affine=False) (post_act.py:207; the MuZero towers of loop_main_mu.py:78): no weight / bias
+        del t[f"common.tower.{depth + 1}.weight"], t[f"common.tower.{depth + 1}.bias"]
+    _conv(rng, t, "scalar_head.seq.0", scalar_hidden_channels, C, 1)
+    _linear(rng, t, "scalar_head.seq.3", scalar_hidden_size, scalar_hidden_channels * hw)
     _linear(rng, t, "scalar_head.seq.5", 5, scalar_hidden_size)
     if head == "ataxx_conv":
         meta["policy_conv_channels"] = 17

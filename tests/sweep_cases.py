@@ -60,6 +60,12 @@ CASES = [
     _c("chess", 3, 128, "attention"),
     _c("chess", 3, 64, "attention"),
     _c("chess", 3, 256, "attention", scalar_hidden_size=64),
+    # the other head sizes the reference's main scripts build: ScalarHead(board, channels, 8, 128) with
+    # DensePolicyHead(game, channels, 32, None) (python/main/supervised_main_mu.py:80-81) and a tower whose final BatchNorm
+    # has no affine (ResTower(..., final_affine=False), python/main/loop_main_mu.py:78)
+    _c("chess", 3, 256, "dense", dense_hidden_channels=32, scalar_hidden_channels=8, scalar_hidden_size=128),
+    _c("go-9", 3, 128, "conv", scalar_hidden_channels=8, scalar_hidden_size=128),
+    _c("ataxx-7", 3, 128, "ataxx_conv", final_affine=False),
 ]
 
 # the reference's own shipping configuration (python/main/loop_main_alpha.py:16-30,68-76): Go 9x9, 16 blocks x 128
