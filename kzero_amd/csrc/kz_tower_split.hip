@@ -43,12 +43,27 @@ constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 template <int C, int NT, bool SPLIT>
 struct Geo {
     static constexpr int ROWS = NT * 16;
-    static constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row: an odd number of 16-byte slots
+    // Bank conflicts of the fragment reads.  A ds_read_b128 is served in four groups of sixteen lanes, and a group mixes
+    // eight rows of lane group kq = 0 (or 2) with the OTHER eight rows of kq = 1 (or 3): its sixteen 16-byte pieces fall
+    // on sixteen different slots of the 256-byte bank row only if the pieces of kq and kq + 1 of the same row are a
+    // multiple of 256 B apart (and rows advance by an odd number of slots).  With one row of 2 C bytes per pixel and the
+    // second lane group at + C bytes that holds for C = 256 and 512 only: the 64 / 128 / 192 / 320 / 384-channel
+    // instances of rounds 3-4 read with two-way conflicts on every fragment (SQ_LDS_BANK_CONFLICT = half of
+    // SQ_LDS_IDX_ACTIVE on Go 9x9 16x128, `tools/pmc_workload.sh`).  For those an image is TWO planes — channels
+    // [0, C/2) and [C/2, C) of every row, rows of C + 16 bytes, the planes a multiple of 256 B apart — and lane group kq
+    // reads plane kq & 1 at (kq >> 1) * C/2 bytes: the same channel assignment {0, C/2, C/4, 3C/4}[kq] as before, so the
+    // weight packing does not change.
+    static constexpr bool TWO = C % 256 != 0;
+    static constexpr int RS = TWO ? C + 16 : C * 2 + 16;  // LDS bytes per pixel row (of a plane): an odd number of 16-byte slots
     static constexpr int IMG = ROWS * RS;
-    // hi block = [X][Y][16 all-zero rows], lo block = the same DELTA bytes later: one address array serves both images
-    // of a pair (lo = hi + DELTA, zero rows included); DELTA is a multiple of 256 B so the bank pattern is the same
+    // hi block = [X][Y][16 all-zero rows] (TWO: once per plane), lo block = the same DELTA bytes later: one address array
+    // serves both images of a pair (lo = hi + DELTA, zero rows included); DELTA and PLANE are multiples of 256 B so the
+    // bank pattern is the same
     static constexpr int XH = 0, YH = IMG, ZH = 2 * IMG;
-    static constexpr int DELTA = (2 * IMG + 16 * RS + 255) / 256 * 256;
+    static constexpr int PLANE = TWO ? (2 * IMG + 16 * RS + 255) / 256 * 256 : 0;
+    static constexpr int DELTA = TWO ? 2 * PLANE : (2 * IMG + 16 * RS + 255) / 256 * 256;
+    // byte offset, within a pixel row's address, of the channel at byte `cb` of the logical row (channel index * 2)
+    __device__ static constexpr int chan_off(int cb) { return TWO ? (cb >= C ? PLANE + cb - C : cb) : cb; }
     static constexpr int PARTS = SPLIT ? 2 : 1;
     // (the stem input — rows of 64 B per chunk of 32 input planes — is staged in the Y image, which nothing else touches
     // before the first block's epilogue)
@@ -153,11 +168,18 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     // ---- zero rows and the stem input (f32 -> hi/lo, 32 sc channels per square; rows beyond the batch are zero), staged
     // in the Y image: rows of 64 B per chunk of 32 input planes (ChessStdMapper 21 planes: one chunk; ChessHistoryMapper,
     // chess.rs:32-39, 34 / 47 / 60 planes: two) ----
+    // (two planes: chunk k sits in the Y rows of plane k & 1, at (k >> 1) * 64 of a row of 64 ceil(sc / 2) bytes)
     constexpr int stem_h = YH, stem_l = YH + DELTA;
-    const int srow = 64 * sc, spieces = 8 * sc;
+    const int srow = L::TWO ? 64 * ((sc + 1) >> 1) : 64 * sc, spieces = 8 * sc;
+    auto stem_at = [&](int row, int chunk) __attribute__((always_inline)) {
+        return L::TWO ? (chunk & 1) * L::PLANE + row * srow + (chunk >> 1) * 64 : row * srow + chunk * 64;
+    };
     for (int id = tid; id < 16 * RS / 16; id += 256) {
-        *reinterpret_cast<uint4 *>(lds + ZH + id * 16) = make_uint4(0, 0, 0, 0);
-        if constexpr (SPLIT) *reinterpret_cast<uint4 *>(lds + ZH + DELTA + id * 16) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int plane = 0; plane < (L::TWO ? 2 : 1); plane++) {
+            *reinterpret_cast<uint4 *>(lds + ZH + plane * L::PLANE + id * 16) = make_uint4(0, 0, 0, 0);
+            if constexpr (SPLIT) *reinterpret_cast<uint4 *>(lds + ZH + plane * L::PLANE + DELTA + id * 16) = make_uint4(0, 0, 0, 0);
+        }
     }
     for (int id = tid; id < L::ROWS * spieces; id += 256) {  // (row, 4-channel piece)
         const int row = id / spieces, c4 = id - row * spieces;
@@ -182,19 +204,19 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             }
             h16x4 hi, lo;
             split4(v, hi, lo);
-            *reinterpret_cast<h16x4 *>(lds + stem_h + row * srow + c4 * 8) = hi;
-            if constexpr (SPLIT) *reinterpret_cast<h16x4 *>(lds + stem_l + row * srow + c4 * 8) = lo;
+            *reinterpret_cast<h16x4 *>(lds + stem_h + stem_at(row, c4 >> 3) + (c4 & 7) * 8) = hi;
+            if constexpr (SPLIT) *reinterpret_cast<h16x4 *>(lds + stem_l + stem_at(row, c4 >> 3) + (c4 & 7) * 8) = lo;
         } else if constexpr (SPLIT) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (have) v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(a.x0) + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
             h16x4 hi, lo;
             split4(v, hi, lo);
-            *reinterpret_cast<h16x4 *>(lds + stem_h + row * srow + c4 * 8) = hi;
-            *reinterpret_cast<h16x4 *>(lds + stem_l + row * srow + c4 * 8) = lo;
+            *reinterpret_cast<h16x4 *>(lds + stem_h + stem_at(row, c4 >> 3) + (c4 & 7) * 8) = hi;
+            *reinterpret_cast<h16x4 *>(lds + stem_l + stem_at(row, c4 >> 3) + (c4 & 7) * 8) = lo;
         } else {
             h16x4 v = h16x4{};
             if (have) v = *reinterpret_cast<const h16x4 *>(static_cast<const h16 *>(a.x0) + ((size_t)board0 * a.hw + row) * a.ldx0 + c4 * 4);
-            *reinterpret_cast<h16x4 *>(lds + stem_h + row * srow + c4 * 8) = v;
+            *reinterpret_cast<h16x4 *>(lds + stem_h + stem_at(row, c4 >> 3) + (c4 & 7) * 8) = v;
         }
     }
 
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         }
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            const int off = (nt * 16 + fr + shift) * srow + chunk * 64 + kq * 16;  // stem: natural k (channel = 32 chunk + 8 kq + j)
+            const int off = stem_at(nt * 16 + fr + shift, chunk) + kq * 16;  // stem: natural k (channel = 32 chunk + 8 kq + j)
             const bool valid = (ok >> nt) & 1;
             bh[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + stem_h + off) : h16x8{};
             if constexpr (SPLIT) bl[nt] = valid ? *reinterpret_cast<const h16x8 *>(lds + stem_l + off) : h16x8{};
@@ -278,14 +300,19 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     }
 
     const int lane_row = fr * RS;
-    const int epi_base = lane_row + ((wave * OT) * 16 + kq * 4) * 2;
+    const int epi_base = lane_row + ((wave * OT) * 16 + kq * 4) * 2;  // (one plane: C = 256, 512)
+    // this lane's four channels of output tile ot, pixel row of tile nt: byte offset within an image
+    auto epi_off = [&](int ot, int nt) __attribute__((always_inline)) {
+        if constexpr (L::TWO) return lane_row + nt * 16 * RS + L::chan_off(((wave * OT + ot) * 16 + kq * 4) * 2);
+        else return epi_base + nt * 16 * RS + ot * 32;
+    };
     // epilogue: [relu]; [+ residual X]; -> (hi, lo) -> the image pair at dst_h
     auto epilogue = [&](int dst_h, bool relu, bool residual) __attribute__((always_inline)) {
 #pragma unroll
         for (int ot = 0; ot < OT; ot++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                const int off = epi_base + nt * 16 * RS + ot * 32;
+                const int off = epi_off(ot, nt);
                 f32x4 v = acc[ot][nt];
                 if (relu) {
 #pragma unroll
@@ -317,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
     // ---- convolution passes over the LDS images.  Channel assignment of a k-step (as in kz_tower.hip): lane group kq
     // reads the 16-byte piece at kq_off + 16 ch of the row, i.e. channels 8 ch + {0, C/2, C/4, 3C/4}[kq] + j; the weights
     // are packed with the same assignment ----
-    const int kq_off = C * (kq & 1) + (C / 2) * (kq >> 1);
+    const int kq_off = L::TWO ? L::PLANE * (kq & 1) + (C / 2) * (kq >> 1) : C * (kq & 1) + (C / 2) * (kq >> 1);
     const int frag_base = lane_row + kq_off;
     // T[nt] = LDS address, in the hi block, of this lane's fragment row (pixel shifted by the tap) or of a zero row
     auto tap_rows = [&](int tap, int src_h, int (&T)[NT]) __attribute__((always_inline)) {
@@ -394,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                 const f32x4 pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
-                    const int off = epi_base + nt * 16 * RS + ot * 32;
+                    const int off = epi_off(ot, nt);
                     f32x4 v = acc[ot][nt];
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
@@ -460,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         for (int k = 0; k < PER; k++) {
             const int id = tid + k * 256;
             if (id < PIECES) {
-                const int r = id / (C / 4), p4 = id - r * (C / 4), off = r * RS + p4 * 8;
+                const int r = id / (C / 4), p4 = id - r * (C / 4), off = r * RS + L::chan_off(p4 * 8);
                 const h16x4 xh = *reinterpret_cast<const h16x4 *>(lds + XH + off), yh = *reinterpret_cast<const h16x4 *>(lds + YH + off);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
