@@ -73,9 +73,23 @@ struct Geo {
     static constexpr int G = C / 32;    // k-steps per tap
     static constexpr int STEP = PARTS * 4 * OT * 64;  // uint4 per k-step: [hi | lo][wave 4][ot][lane 64]
     static_assert(C % 64 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
-    // weight ring depth in k-steps (a divisor of G; five stages of 320 channels next to six pixel tiles do not fit the registers)
-    static constexpr int PF = G % 4 == 0 ? 4 : G % 3 == 0 ? 3 : (G % 5 == 0 && NT < 6) ? 5 : 2;
-    static_assert(G % PF == 0, "ring stage of a k-step must not depend on the tap");
+    // Weight ring depth in k-steps.  A weight fragment is requested PF k-steps before its MFMAs, and an L2 round trip under
+    // this load is ~2,000 cycles: a k-step of OT * NT MFMAs (16 cycles each, twice that wall time with two workgroups per
+    // CU) must be shorter than latency / PF or every k-step waits for its weights.  At 256 channels and two boards (kz_tower.hip:
+    // 32 MFMAs = 512 cycles, PF = 4) that holds; at 128 channels and one board a k-step is 8-12 MFMAs and four stages
+    // cover 800 cycles — the round-4 counters of Go 9x9 16x128 (tools/pmc_workload.sh) show the matrix pipe busy 38 % of
+    // the time AT FULL CLOCK, each k-step taking ~500 cycles = latency / 4.  So the ring is as deep as the registers allow:
+    // the tap loop is unrolled U taps at a time (all nine for <= 128 channels, three otherwise) and PF divides U * G, so
+    // that a k-step's stage is still a compile-time constant.  (Split arithmetic: three MFMAs per product, k-steps three
+    // times as long, two register sets per stage: six stages; the chess network's fused attention heads run passes of
+    // G = 8 k-steps, so its ring stays at four.)  From 192 channels up a k-step is long enough for a ring that divides G
+    // (3, 4 or 5 stages), and a deeper one was measured SLOWER there in same-box A/Bs (192: 663k -> 638k evals/s with nine
+    // stages; 320: 262k -> 242k with six; 256 on Go 9x9: 330k -> 295k with eight; split 192: 285k -> 263k with six): those
+    // launches are bound by the matrix cores' power, not by latency, and the extra registers and bytes in flight only cost.
+    static constexpr int PF = G <= 4 ? (SPLIT ? 6 : G == 2 ? 18 : 12)
+                                     : G % 4 == 0 ? 4 : G % 3 == 0 ? 3 : (G % 5 == 0 && NT < 6) ? 5 : 2;
+    static constexpr int U = G % PF == 0 ? 1 : G <= 4 ? 9 : 3;  // (a ring that divides G keeps the one-tap loop body)
+    static_assert((U * G) % PF == 0 && (9 * G) % PF == 0, "ring stage of a k-step must be a compile-time constant");
 };
 
 struct SplitDev {
@@ -366,11 +380,14 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             if constexpr (SPLIT) bl[0][nt] = rd(T[nt], DELTA);
         }
 #pragma nounroll
-        for (int tap = 0; tap < 9; tap++) {
+        for (int tb = 0; tb < 9; tb += L::U)
+#pragma unroll
+        for (int tu = 0; tu < L::U; tu++) {
+            const int tap = tb + tu;
             tap_rows(tap + 1 < 9 ? tap + 1 : tap, src_h, Tn);
 #pragma unroll
             for (int ch = 0; ch < G; ch++) {
-                const int stage = ch % PF, cur = ch & 1, nxt = cur ^ 1;
+                const int stage = (tu * G + ch) % PF, cur = ch & 1, nxt = cur ^ 1;
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     bh[nxt][nt] = ch < G - 1 ? rd(T[nt], (ch + 1) * 16) : rd(Tn[nt], 0);
