@@ -82,11 +82,13 @@ struct Geo {
     // the tap loop is unrolled U taps at a time (all nine for <= 128 channels, three otherwise) and PF divides U * G, so
     // that a k-step's stage is still a compile-time constant.  (Split arithmetic: three MFMAs per product, k-steps three
     // times as long, two register sets per stage: six stages; the chess network's fused attention heads run passes of
-    // G = 8 k-steps, so its ring stays at four.)  From 192 channels up a k-step is long enough for a ring that divides G
+    // G = 8 k-steps, so its ring stays at four.)  Same-box A/Bs at 128 channels (Go 9x9 16x128 b=2048 / Ataxx 8x128 b=256,
+    // evals/s): plain f16 with 4 / 9 / 12 / 18 stages 1.006M / 1.402M / 1.384M / 1.384M and 3.46M / 4.59M / 4.47M / 4.52M;
+    // split with 4 / 6 / 9 / 12 stages 547k / 596k / 595k / 513k (12 stages spill) and 1.795M / 1.930M / 1.941M / 1.737M.  From 192 channels up a k-step is long enough for a ring that divides G
     // (3, 4 or 5 stages), and a deeper one was measured SLOWER there in same-box A/Bs (192: 663k -> 638k evals/s with nine
     // stages; 320: 262k -> 242k with six; 256 on Go 9x9: 330k -> 295k with eight; split 192: 285k -> 263k with six): those
     // launches are bound by the matrix cores' power, not by latency, and the extra registers and bytes in flight only cost.
-    static constexpr int PF = G <= 4 ? (SPLIT ? 6 : G == 2 ? 18 : 12)
+    static constexpr int PF = G <= 4 ? (SPLIT ? 6 : G == 2 ? 18 : 9)
                                      : G % 4 == 0 ? 4 : G % 3 == 0 ? 3 : (G % 5 == 0 && NT < 6) ? 5 : 2;
     static constexpr int U = G % PF == 0 ? 1 : G <= 4 ? 9 : 3;  // (a ring that divides G keeps the one-tap loop body)
     static_assert((U * G) % PF == 0 && (9 * G) % PF == 0, "ring stage of a k-step must be a compile-time constant");
