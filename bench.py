@@ -463,6 +463,8 @@ def seam_run(exe, model_path, seconds, cfg, dtype, devices):
                           str(cfg["device_decode"]), ",".join(str(d) for d in devices), cfg["work"]],
                          capture_output=True, text=True, timeout=120, env=env)
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    if not rec["evals_per_s"] > 0:
+        raise RuntimeError("the seam answered no evaluation in the timed window (stalled)")
     return {"config": cfg["name"], "work": cfg["work"], "value": rec["evals_per_s"], "unit": "evals/s", "fill": rec["fill"],
             "executor_threads": rec["gpu_threads"], "pipeline_depth": rec["pipeline_depth"], "device_decode": rec["device_decode"],
             "generator_threads": rec["generator_threads"], "concurrent_games": rec["concurrent_games"],

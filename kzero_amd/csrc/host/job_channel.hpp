@@ -46,6 +46,17 @@ class JobClient {
         return receiver;
     }
 
+    // not in the reference: the reply goes to a channel the caller owns, so that one thread can stand for many games and
+    // take their replies in the order they arrive (the reference's games are independent futures; a thread that waited
+    // for its requests in submission order could starve the executors' partial batches: tests/cpp/bench_executor.cpp)
+    void map_into(std::vector<X> x, Sender<std::vector<Y>> reply) const {
+        if (x.empty()) {
+            reply.send({});
+        } else if (!sender_.send(Job<X, Y>{std::move(x), std::move(reply)})) {
+            throw std::runtime_error("job channel: executor is gone");
+        }
+    }
+
     // job_channel.rs:48-50
     std::vector<Y> map_blocking(std::vector<X> x) const {
         auto r = map(std::move(x)).recv();

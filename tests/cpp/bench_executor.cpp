@@ -97,15 +97,16 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
         for (int t = 0; t < a.generators; t++, gi++)
             gens.emplace_back([&, gi, client = dev->eval_client, seed = 100 + t + 1000 * dev->device] {
                 std::mt19937 r(seed);
-                std::vector<Receiver<std::vector<ZeroEvaluation>>> inflight;
-                auto request = [&] { return client.map(make_request(r, st.search_batch_size)); };
-                for (size_t gme = 0; gme < games_per_thread; gme++) inflight.push_back(request());
-                size_t next = 0;
+                // one reply channel for all of this thread's games: replies are taken in the order they ARRIVE, like the
+                // reference's independent game futures.  (Waiting for them in submission order deadlocks now and then
+                // with several executor threads: every generator waits for a request that sits in some executor's
+                // partial batch while the answered ones are not replaced — seen once as a 0 evals/s record.)
+                auto [reply_tx, reply_rx] = bounded<std::vector<ZeroEvaluation>>(games_per_thread);
+                for (size_t gme = 0; gme < games_per_thread; gme++) client.map_into(make_request(r, st.search_batch_size), reply_tx);
                 while (!stop) {
-                    auto y = inflight[next].recv();
+                    auto y = reply_rx.recv();
                     if (!y) break;
-                    inflight[next] = request();
-                    next = (next + 1) % inflight.size();
+                    client.map_into(make_request(r, st.search_batch_size), reply_tx);
                     gen_cpu[gi] = thread_cpu_ns();
                 }
             });
@@ -170,7 +171,7 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
         std::snprintf(buf, sizeof buf, "%s%d", i ? ", " : "", a.devices[i]);
         devs_json += buf;
     }
-    const double evals_s = real / dt, mevals = real / 1e6;
+    const double evals_s = real / dt, mevals = (real ? real : 1) / 1e6;  // (a stalled run prints 0 evals/s, not inf)
     // ---- projection to one node of eight GPUs at this per-device rate: host cores (the whole process's CPU seconds per
     // second: executors, generators' request handling, the HIP runtime's own threads) and PCIe bytes ----
     const double per_dev_rate = evals_s / nd, cores_per_device = cpu_s / dt / nd;

@@ -498,6 +498,22 @@ static void test_job_channel() {
     auto fut = client.map_async({5});
     auto single = client.map_async_single(7);
     CHECK(fut.get() == std::vector<int>{10} && single.get() == 14);
+    // map_into (not in the reference): several requests answered into ONE reply channel, in the order they are served
+    {
+        auto [reply_tx, reply_rx] = bounded<std::vector<int>>(4);
+        client.map_into({1}, reply_tx);
+        client.map_into({}, reply_tx);  // the empty request short-circuits here too
+        client.map_into({2, 3}, reply_tx);
+        std::multiset<size_t> sizes;
+        int sum = 0;
+        for (int k = 0; k < 3; k++) {
+            auto y = reply_rx.recv();
+            CHECK(y.has_value());
+            sizes.insert(y->size());
+            for (int v : *y) sum += v;
+        }
+        CHECK((sizes == std::multiset<size_t>{0, 1, 2}) && sum == 12);
+    }
     client = JobClient<int, int>();  // drop the last sender -> the worker sees Disconnected
     server = JobServer<int, int>();
     worker.join();
@@ -979,6 +995,63 @@ static void test_spawn_all_devices() {
     }
 }
 
+// The load generator of tests/cpp/bench_executor.cpp: threads that each stand for many games and take the replies in the
+// order they arrive.  With the reference's sizing rule (server_alphazero.rs:47) this keeps several executor threads fed
+// for ever; taking the replies in SUBMISSION order instead does not (a thread can wait for a request that sits in an
+// executor's partial batch while its answered games are not replaced), which is why `map_into` exists.
+static void test_multiplexed_generators() {
+    for (size_t depth : {1, 2}) {
+        StartupSettings st;
+        st.gpu_threads_per_device = 4;
+        st.gpu_batch_size = 32;
+        st.search_batch_size = 4;  // RunCondition::JobCount(8)
+        st.pipeline_depth = depth;
+        EvalCounters counters;
+        PackedMapper mapper{1, 2, 4, 1, 3};
+        auto all = spawn_all_devices<PackedBoard, PackedMapper, FakeDeviceNet, std::shared_ptr<const FakeGraph>>({0}, st, mapper, 0,
+                                                                                                              &counters);
+        all[0]->send_graph(std::make_shared<const FakeGraph>(FakeGraph{1}));
+        const DeviceSizing sizing(st);
+        const size_t n_threads = 3, games_per_thread = ceil_div(sizing.concurrent_games, n_threads), target = 30000;
+        std::atomic<size_t> answered{0};
+        std::atomic<bool> stalled{false};
+        std::vector<std::thread> gens;
+        for (size_t t = 0; t < n_threads; t++)
+            gens.emplace_back([&, client = all[0]->eval_client] {
+                auto request = [&] {
+                    std::vector<PackedBoard> x(st.search_batch_size);
+                    for (auto &b : x) b.bits.assign(1, 0), b.scalars = {1.f};
+                    return x;
+                };
+                auto [reply_tx, reply_rx] = bounded<std::vector<ZeroEvaluation>>(games_per_thread);
+                for (size_t g = 0; g < games_per_thread; g++) client.map_into(request(), reply_tx);
+                while (answered < target && !stalled) {
+                    auto y = reply_rx.recv();
+                    if (!y || y->size() != st.search_batch_size) break;
+                    answered += y->size();
+                    client.map_into(request(), reply_tx);
+                }
+            });
+        // watchdog: progress every 5 s or the test fails instead of hanging
+        std::thread watchdog([&] {
+            size_t last = 0;
+            for (int quiet = 0; answered < target && quiet < 50;) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                const size_t now = answered;
+                quiet = now == last ? quiet + 1 : 0;
+                last = now;
+                if (quiet >= 50) stalled = true;
+            }
+        });
+        watchdog.join();
+        CHECK(!stalled && answered >= target);
+        if (stalled) std::_Exit(1);  // (generators are blocked in recv(): nothing to join)
+        for (auto &g : gens) g.join();
+        all[0]->join();
+        CHECK(counters.real >= target);
+    }
+}
+
 int main(int argc, char **argv) {
     const std::string golden = argc > 1 ? argv[1] : "tests/golden";
     std::fputs("bitbuffer\n", stderr); test_bitbuffer();
@@ -995,6 +1068,7 @@ int main(int argc, char **argv) {
     std::fputs("pipelined job_count\n", stderr); test_pipelined_job_count();
     std::fputs("symmetry\n", stderr); test_symmetry(golden);
     std::fputs("devices\n", stderr); test_spawn_all_devices();
+    std::fputs("multiplexed generators\n", stderr); test_multiplexed_generators();
     if (g_failed) {
         std::fprintf(stderr, "%d check(s) failed\n", g_failed);
         return 1;
