@@ -13,6 +13,11 @@
 #define KZ_HEADS_STAMP(slot) do { } while (0)
 #endif
 
+template <int N>
+struct IntC {
+    static constexpr int value = N;
+};
+
 template <int C>
 __device__ __forceinline__ int plane_of(int kq) {  // byte offset of lane group kq's 16-byte piece within a step
     return C == 256 ? 256 * kq : 256 * (kq & 1) + 128 * (kq >> 1);
@@ -92,8 +97,9 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
     float wpre[WPRE];
 #pragma unroll
     for (int k = 0; k < WPRE; k++) {
-        const int i = fseg + k * nseg;
-        wpre[k] = (fseg < nseg && i < n_in) ? a.sh_w1t[(size_t)i * a.hs + fj] : 0.0f;
+        const int i = fseg + k * nseg, ic = i < n_in ? i : n_in - 1;  // (fseg >= nseg: a thread without a segment reads row ic too)
+        const float v = a.sh_w1t[(size_t)ic * a.hs + fj];
+        wpre[k] = i < n_in ? v : 0.0f;
     }
     const float b1v = tid < a.nb * a.hs ? a.sh_b1[tid % a.hs] : 0.0f;
     const float b2v = tid < boards * 5 ? a.sh_b2[tid % 5] : 0.0f;
@@ -127,27 +133,61 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
     // one input are contiguous) for all boards of the workgroup at once; the segments meet through LDS
     {
         const int seg = fseg, j = fj;
-        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (seg < nseg) {
+        // branch free: an input past the end has weight 0 and reads the last activation; a board past a.nb repeats the last
+        // board and is not stored (with a branch per term the LDS reads waited for each other: 350 cycles per input)
+        auto narrow = [&](auto nbc) {
+            constexpr int NBB = decltype(nbc)::value;
+            float part[NBB];
+            int boff[NBB];
+#pragma unroll
+            for (int bb = 0; bb < NBB; bb++) {
+                part[bb] = 0.0f;
+                boff[bb] = (bb < a.nb ? bb : a.nb - 1) * n_in;
+            }
 #pragma unroll
             for (int k = 0; k < WPRE; k++) {
-                const int i = seg + k * nseg;
-                if (i < n_in) {
+                const int i = seg + k * nseg, ic = i < n_in ? i : n_in - 1;
 #pragma unroll
-                    for (int bb = 0; bb < 4; bb++)
-                        if (bb < a.nb) part[bb] += wpre[k] * sact[bb * n_in + i];
+                for (int bb = 0; bb < NBB; bb++) part[bb] += wpre[k] * sact[boff[bb] + ic];
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (eight inputs' LDS reads in flight, not all of them)
+            }
+            // the rest in batches of WB loads, the next batch requested before this one is used: a thread of a wide head
+            // (ScalarHead(8, 128) on a 9x9 board: 324 inputs per thread) waited for ~40 L2 round trips in a row when the
+            // loop asked for eight weights at a time
+            constexpr int WB = 32;
+            auto fetch = [&](float (&wv)[WB], int i0) {
+#pragma unroll
+                for (int k = 0; k < WB; k++) {
+                    const int i = i0 + k * nseg, ic = i < n_in ? i : n_in - 1;
+                    const float v = a.sh_w1t[(size_t)ic * a.hs + j];
+                    wv[k] = i < n_in ? v : 0.0f;
+                }
+            };
+            int i0 = seg + WPRE * nseg;
+            if (i0 < n_in) {
+                float wcur[WB];
+                fetch(wcur, i0);
+                for (; i0 < n_in; i0 += WB * nseg) {
+                    float wnext[WB];
+                    fetch(wnext, i0 + WB * nseg);  // (zeros past the end)
+#pragma unroll
+                    for (int k = 0; k < WB; k++) {
+                        const int i = i0 + k * nseg, ic = i < n_in ? i : n_in - 1;
+#pragma unroll
+                        for (int bb = 0; bb < NBB; bb++) part[bb] += wcur[k] * sact[boff[bb] + ic];
+                        if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < WB; k++) wcur[k] = wnext[k];
                 }
             }
-#pragma unroll 8
-            for (int i = seg + WPRE * nseg; i < n_in; i += nseg) {
-                const float w = a.sh_w1t[(size_t)i * a.hs + j];
 #pragma unroll
-                for (int bb = 0; bb < 4; bb++)
-                    if (bb < a.nb) part[bb] += w * sact[bb * n_in + i];
-            }
-#pragma unroll
-            for (int bb = 0; bb < 4; bb++)
+            for (int bb = 0; bb < NBB; bb++)
                 if (bb < a.nb) sred[(seg * a.nb + bb) * a.hs + j] = part[bb];
+        };
+        if (seg < nseg) {
+            if (a.nb <= 2) narrow(IntC<2>{});
+            else narrow(IntC<4>{});
         }
     }
     KZ_HEADS_STAMP(58);

@@ -51,7 +51,7 @@ def rate(model, dtype, game, batch, seconds, engines, n_bool=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
-    ap.add_argument("--filter", default="")
+    ap.add_argument("--filter", default="", help="comma-separated substrings of case ids")
     ap.add_argument("--seconds", type=float, default=0.3)
     ap.add_argument("--engines", default="2,3",
                     help="engines (streams) per point, comma separated: the best rate is recorded with its engine count (the "
@@ -67,7 +67,7 @@ def main():
         from tests import oracle_lib as O
     rows = []
     for case in sweep_cases.CASES:
-        if args.filter and args.filter not in case.id:
+        if args.filter and not any(f in case.id for f in args.filter.split(",")):
             continue
         blob = synth.random_model(case.game, case.depth, case.channels, case.head, seed=11, **case.kw)
         model = capi.Model(blob=blob)
