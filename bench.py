@@ -73,7 +73,17 @@ KERNEL_SOURCE = {
     "kz_tower_resident_split": "kz_tower_split.hip", "kz_tower_resident_f16g": "kz_tower_split.hip",
     "kz_board_conv_f16": "kz_board_conv.hip", "kz_board_conv_split16": "kz_board_conv.hip", "kz_conv_igemm_f16": "kz_kernels.hip", "kz_conv_igemm_f32": "kz_kernels.hip",
 }
+# device code a kernel source pulls in (hashed with it: a traffic record goes stale when either changes)
+KERNEL_DEVICE_HEADERS = {"kz_tower_f32.hip": ["kz_conv_heads.hpp"], "kz_tower_split.hip": ["kz_conv_heads.hpp"]}
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "hbm_traffic.json")
+
+
+def kernel_source_hash(kernel: str) -> str:
+    h = hashlib.sha256()
+    src = KERNEL_SOURCE[kernel]
+    for name in [src] + KERNEL_DEVICE_HEADERS.get(src, []):
+        h.update(open(os.path.join(REPO, "kzero_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse_args(argv=None):
@@ -207,8 +217,7 @@ def committed_traffic(kernel: str, workload: str, batch: int):
     correction) — reported only while the kernel's source file still has the hash it had when the passes ran."""
     try:
         table = json.load(open(TRAFFIC_FILE))
-        src = os.path.join(REPO, "kzero_amd", "csrc", KERNEL_SOURCE[kernel])
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        sha = kernel_source_hash(kernel)
     except (OSError, ValueError, KeyError):
         return None, None
     for rec in table.get("records", []):

@@ -48,10 +48,10 @@ def main():
     match = KERNEL_MATCH[kernel]
     kname, fetch_kib, n = mean_counter(fetch_dir, "FETCH_SIZE", match)
     _, write_kib, _ = mean_counter(write_dir, "WRITE_SIZE", match)
-    src = os.path.join(REPO, "kzero_amd", "csrc", bench.KERNEL_SOURCE[kernel])
     rec = {"kernel": kernel, "kernel_symbol": kname, "workload": wl, "dtype": dt, "batch": batch,
            "source_file": bench.KERNEL_SOURCE[kernel],
-           "source_sha256_16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
+           "source_headers": bench.KERNEL_DEVICE_HEADERS.get(bench.KERNEL_SOURCE[kernel], []),
+           "source_sha256_16": bench.kernel_source_hash(kernel),
            "fetch_size_kib_per_launch": round(fetch_kib, 2), "write_size_kib_per_launch": round(write_kib, 2),
            "launches_averaged": n,
            "traffic_bytes_per_launch": round((2 * fetch_kib + write_kib) * 1024, 1),
