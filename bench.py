@@ -43,7 +43,7 @@ WORKLOADS = {
                          engines={"f16": 2, "f32": 2, "f32split16": 2},
                          label="Chess 20x256 ResNet b=256"),
     "ataxx-8x128": dict(game="ataxx-7", depth=8, channels=128, head="ataxx_conv", batch=256, steps=10000,
-                        engines={"f16": 3, "f32": 2, "f32split16": 3},
+                        engines={"f16": 3, "f32": 3, "f32split16": 3},  # (f32: 517k with three, 507k with two)
                         label="Ataxx 7x7 8x128 ResNet b=256"),
     "go19-40x256": dict(game="go-19", depth=40, channels=256, head="conv", batch=512, steps=400,
                         engines={"f16": 1, "f32": 1, "f32split16": 1},
