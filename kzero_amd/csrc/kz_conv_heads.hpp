@@ -26,10 +26,10 @@ __device__ __forceinline__ int plane_of(int kq) {  // byte offset of lane group 
 // Images: rows of C f32 (natural channel order), row stride RS = 4 C + 16 bytes, NT tiles of 16 rows; `xin` = LDS offset of
 // the tower output (after the final BN), `hin` = of the policy head's hidden layer (Conv1x1 C->C + ReLU), `scratch` = of
 // 16 * RS bytes the tail may overwrite (the f32 launch's zero rows).  board0 / boards / rows_valid: this workgroup's
-// boards.  Every thread of the 256 calls it; the caller has synchronised the workgroup behind the images' last writes.
+// boards; rows_img: rows an image really holds (a tile row behind them is read as the last row and never emitted).  Every thread of the 256 calls it; the caller has synchronised the workgroup behind the images' last writes.
 template <int C, int NT, typename Dev>
 __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds, int scratch, int xin, int hin, int board0,
-                                               int boards, int rows_valid) {
+                                               int boards, int rows_valid, int rows_img = NT * 16) {
     constexpr int G = C / 16, RS = C * 4 + 16, ZERO = 0;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -38,34 +38,36 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
     const int koff = plane_of<C>(kq);
     (void)ZERO;
     // A 1x1 convolution with at most 32 output channels (two 16-channel tiles, zero-padded by the host) on the MFMAs:
-    // the row tiles are split over the waves (wave w: tiles w and w + 4), every wave streams the whole (small)
-    // weight fragment set: 16 * C/16 MFMAs per wave.  emit(oc, row, value) for this lane's 2 x 2 x 4 results.
+    // the row tiles are split over the waves (wave w: tiles w, w + 4 and w + 8), every wave streams the whole (small)
+    // weight fragment set: 16 * C/16 MFMAs per wave and tile.  emit(oc, row, value) for this lane's 2 x TW x 4 results.
+    constexpr int TW = (NT + 3) / 4;  // tiles per wave
     auto small_conv = [&](int img, const f32x4 *wfrag /* [G][2][64] */, auto emit) {
-        f32x4 sa[2][2];
+        f32x4 sa[2][TW];
+        int base[TW];
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int t = 0; t < 2; t++) sa[mt][t] = f32x4{0, 0, 0, 0};
-        const bool two = wave + 4 < NT;
-        const int base0 = img + (wave * 16 + fr) * RS + koff;
-        const int base1 = two ? base0 + 64 * RS : base0;
+        for (int t = 0; t < TW; t++) {
+            sa[0][t] = sa[1][t] = f32x4{0, 0, 0, 0};
+            const int row = (wave + 4 * t) * 16 + fr;
+            base[t] = img + (row < rows_img ? row : rows_img - 1) * RS + koff;
+        }
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const f32x4 w0 = wfrag[(g * 2 + 0) * 64 + lane], w1 = wfrag[(g * 2 + 1) * 64 + lane];
-            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(lds + base0 + g * 16);
-            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(lds + base1 + g * 16);
+            f32x4 bt[TW];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                sa[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], b0[q], sa[0][0], 0, 0, 0);
-                sa[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], b0[q], sa[1][0], 0, 0, 0);
-                sa[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], b1[q], sa[0][1], 0, 0, 0);
-                sa[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], b1[q], sa[1][1], 0, 0, 0);
-            }
+            for (int t = 0; t < TW; t++) bt[t] = *reinterpret_cast<const f32x4 *>(lds + base[t] + g * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < TW; t++) {
+                    sa[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], bt[t][q], sa[0][t], 0, 0, 0);
+                    sa[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], bt[t][q], sa[1][t], 0, 0, 0);
+                }
         }
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < TW; t++) {
             const int row = (wave + 4 * t) * 16 + fr;
-            if ((t == 0 || two) && row < rows_valid) {
+            if (wave + 4 * t < NT && row < rows_valid) {
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++)
 #pragma unroll

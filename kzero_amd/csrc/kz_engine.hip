@@ -130,6 +130,7 @@ struct kz_engine {
     bool fused_split = false;  // the split-f16 launch with the scalar head and the policy head inside
     bool fused_pairs = false;  // the plain-f16 generic launch with the conv policy head and the scalar head inside
     bool nb4 = false;        // resident chess tower with four boards per workgroup (KZ_TOWER_NB=4)
+    bool t32_dense3 = false;  // exact-f32 launch with three 7x7 boards per workgroup (experiment build: KZ_T32_BOARDS=3)
     void *xres = nullptr;    // its residual scratch
     std::string path;
 
@@ -435,6 +436,7 @@ struct kz_engine {
                 hd.scalars = d_scalars; hd.policy = d_policy;
                 hd.nonfinite_flag = nf_flag; hd.epoch = nf_epoch;
             }
+            t.dense3 = t32_dense3;
             prof.begin(split16 ? "kz_tower_resident_split" : pairs16 ? "kz_tower_resident_f16g" : "kz_tower_resident_f32", stream);
             if (split16) kz::launch_tower_split(t, stream);
             else if (pairs16) kz::launch_tower_pairs(t, false, stream);  // f16 tensors behind the same pointers
@@ -779,6 +781,10 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         e->fused_heads = false;
         e->path = "tower_resident_f16";
     }
+    const char *t32b = getenv("KZ_T32_BOARDS");
+    e->t32_dense3 = e->resident32 && !e->split16 && !e->pairs16 && t32b && atoi(t32b) == 3 &&
+                    kz::tower32_dense3_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
+                                                 m.channels, m.sh_conv.cout, m.sh_fc0.out, e->fused32);
 #endif
 
     {
@@ -907,7 +913,7 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     int per = 0, wgs = 0;
     if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
     else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
-    else if (e->resident32) per = kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
+    else if (e->resident32) per = e->t32_dense3 ? 3 : kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
     else if (e->path == "board_conv_split16") wgs = kz::board_conv_workgroups(batch, m.h, m.w, m.channels);
     else if (e->path == "board_conv_f16")

@@ -172,6 +172,7 @@ struct Tower32Args {
     size_t bits_stride = 0;
     const float *scalars_in = nullptr;
     int n_scalar = 0, n_bool = 0;
+    bool dense3 = false;  // launch_tower32, experiment build: three 7x7 boards per workgroup (tower32_dense3_supported)
     // launch_tower32 only: the conv policy head (Conv1x1 C->C + ReLU in the weight stream as one more centre-tap layer,
     // then Conv1x1 C->pc, post_act.py:75-110) and the scalar head (post_act.py:8-31) in the same launch — the tower
     // output never leaves LDS and `y` is not written.  tower32_heads_supported says for which models.
@@ -194,6 +195,8 @@ struct Tower32Args {
     } heads;
 };
 bool tower32_supported(int dtype, int h, int w, int channels, int depth);
+// (experiment build only; false in the product) Tower32Args::dense3 may be set for this network
+bool tower32_dense3_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs, bool heads);
 // conv / ataxx_conv policy head + a scalar head whose activations fit the launch's spare LDS
 bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs);
 // the same question for any launch that ends in kz_conv_heads.hpp with nt tiles of 16 pixel rows per workgroup

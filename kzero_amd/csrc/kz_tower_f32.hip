@@ -78,13 +78,16 @@ struct TowerF32Dev {
 };
 
 
-template <int C, int NT, bool HEADS>
+// DENSE: an image holds the workgroup's nb * hw pixel rows and nothing behind them (the rows that fill the last tile up
+// to 16 are not stored: as inputs they are zero rows, as outputs they are not written) — what makes room for THREE 7x7
+// boards (147 rows in ten tiles, 160 KB of LDS to the byte) where the padded image holds two (98 rows in seven tiles).
+template <int C, int NT, bool HEADS, bool DENSE = false>
 __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
     constexpr int OT = C / 64;           // 16-channel output tiles per wave
     constexpr int G = C / 16;            // steps per tap in a tower layer
     constexpr int ROWS = NT * 16;
     constexpr int RS = C * 4 + 16;       // row stride: odd number of 16-byte slots
-    constexpr int ZERO = 0, IMG0 = 16 * RS, IMG1 = IMG0 + ROWS * RS;
+    constexpr int ZERO = 0, IMG0 = 16 * RS;
     constexpr int STEP = 4 * OT * 64;    // f32x4 per step: [wave][ot][lane]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
@@ -94,6 +97,8 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
     const int board0 = blockIdx.x * a.nb;
     const int boards = min(a.nb, a.batch - board0);
     const int rows_valid = boards * a.hw;
+    const int rows_img = DENSE ? a.nb * a.hw : ROWS;  // rows an image holds
+    const int IMG1 = IMG0 + rows_img * RS;
     KZ_STAMP(0);
 
     // zero rows; padding rows of image 0 (their outputs are never stored, but keep them finite)
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
         const int pieces = a.stem_groups * 4;  // 16-byte pieces per row
         for (int i = tid; i < ROWS * pieces; i += 256) {
             const int r = i / pieces, p = i - r * pieces;
+            if (DENSE && r >= rows_img) continue;
             f32x4 v = f32x4{0, 0, 0, 0};
             if (r < rows_valid) {
                 if (a.bits) {  // F0 (rust/kz-core/src/mapping/mod.rs:40-63, bit order bit_buffer.rs:73-75): scalar planes, then bit planes
@@ -177,6 +183,10 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
                 for (int nt = 0; nt < NT; nt++)
                     acc[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ot][s], bf[nt][s], acc[ot][nt], 0, 0, 0);
     };
+    // rows this lane may store (bit nt: row fr of tile nt is part of the image)
+    unsigned wmask = 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) wmask |= (unsigned)(nt * 16 + fr < rows_img) << nt;
     // [relu]; [+ residual from the out image, in place]; [final BN]; 16-byte stores into the out image
     auto epilogue = [&](bool relu, bool residual, bool post) {
 #pragma unroll
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
             }
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
+                if (DENSE && !((wmask >> nt) & 1)) continue;
                 f32x4 *slot = reinterpret_cast<f32x4 *>(lds + out + (nt * 16 + fr) * RS + oc * 4);
                 f32x4 v = acc[ot][nt];
                 if (relu) {
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_f32(TowerF32Dev a) {
     } else {
         // ---- heads on the images in LDS: `out` holds the tower output, `in` the policy head's hidden layer; the zero rows
         // are dead by now: scratch for the scalar head (kz_conv_heads.hpp) ----
-        conv_heads_f32<C, NT>(a, lds, ZERO, out, in, board0, boards, rows_valid);
+        conv_heads_f32<C, NT>(a, lds, ZERO, out, in, board0, boards, rows_valid, rows_img);
         KZ_STAMP(61);
     }
     KZ_STAMP(62);
@@ -343,14 +354,14 @@ int tiles_for(int hw, int channels) {
     return 0;
 }
 
-template <int C, int NT, bool HEADS>
+template <int C, int NT, bool HEADS, bool DENSE = false>
 void launch1(const TowerF32Dev &d, int grid, hipStream_t stream) {
-    constexpr int LDS_BYTES = (16 + 2 * NT * 16) * (C * 4 + 16);
+    const int LDS_BYTES = (16 + 2 * (DENSE ? d.nb * d.hw : NT * 16)) * (C * 4 + 16);
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((done_mask >> (dev & 63)) & 1)) {
-        (void)hipFuncSetAttribute((const void *)kz_tower_resident_f32<C, NT, HEADS>,
+        (void)hipFuncSetAttribute((const void *)kz_tower_resident_f32<C, NT, HEADS, DENSE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         done_mask |= 1ull << (dev & 63);
     }
@@ -362,7 +373,7 @@ void launch1(const TowerF32Dev &d, int grid, hipStream_t stream) {
     TowerF32Dev ds = d;
     ds.stamps = stamp_buf;
     if (launches == 20) (void)hipMemsetAsync(stamp_buf, 0, stamp_bytes, stream);
-    kz_tower_resident_f32<C, NT, HEADS><<<grid, 256, LDS_BYTES, stream>>>(ds);
+    kz_tower_resident_f32<C, NT, HEADS, DENSE><<<grid, 256, LDS_BYTES, stream>>>(ds);
     if (launches++ == 20 && getenv("KZ_T32_STAMP_FILE")) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> host(stamp_bytes / 8);
@@ -373,14 +384,14 @@ void launch1(const TowerF32Dev &d, int grid, hipStream_t stream) {
         }
     }
 #else
-    kz_tower_resident_f32<C, NT, HEADS><<<grid, 256, LDS_BYTES, stream>>>(d);
+    kz_tower_resident_f32<C, NT, HEADS, DENSE><<<grid, 256, LDS_BYTES, stream>>>(d);
 #endif
 }
 
-template <int C, int NT>
+template <int C, int NT, bool DENSE = false>
 void launch(const TowerF32Dev &d, bool heads, int grid, hipStream_t stream) {
-    if (heads) launch1<C, NT, true>(d, grid, stream);
-    else launch1<C, NT, false>(d, grid, stream);
+    if (heads) launch1<C, NT, true, DENSE>(d, grid, stream);
+    else launch1<C, NT, false, DENSE>(d, grid, stream);
 }
 
 }  // namespace
@@ -393,10 +404,10 @@ bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, in
     return conv_heads_fit(tiles_for(h * w, channels), policy_kind, extra_moves, pc, h, w, channels, hc, hs);
 }
 
-// kz_conv_heads.hpp on a launch of nt tiles of 16 rows: at most 8 tiles (two per wave) and four boards
+// kz_conv_heads.hpp on a launch of nt tiles of 16 rows: at most 12 tiles (three per wave) and four boards
 bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs) {
     const int hw = h * w;
-    if (!nt || nt > 8 || (policy_kind != 0 && policy_kind != 1) || extra_moves < 0 || hc < 1 || hs < 1 || hs > 256) return false;
+    if (!nt || nt > 12 || (policy_kind != 0 && policy_kind != 1) || extra_moves < 0 || hc < 1 || hs < 1 || hs > 256) return false;
     if (policy_kind == 0 && extra_moves) return false;
     if (pc < 1 || pc > 32 || hc + (extra_moves ? 1 : 0) > 32) return false;  // two 16-channel tiles per small conv
     const int nb = nt * 16 / hw, nseg = 256 / hs;
@@ -452,6 +463,18 @@ void tower32_pack_small_weights(const float *sh_w0, int hc, const float *pe_wc, 
                     }
 }
 
+// (experiment build) three 7x7 boards per workgroup in ten tiles with DENSE images: 147 of 160 tile rows are boards
+// instead of 98 of 112, and a workgroup is 7 % faster per board — but a batch of 256 is 86 workgroups, and with the two to
+// four launches an executor keeps in flight the chip's 256 CUs are not filled: 458k evals/s with three engines and 517k
+// with four against 520k / 520k for two boards (tools/ab_a1_f32.sh).  It would pay from batch 768 on.
+bool tower32_dense3_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs, bool heads) {
+#ifdef KZ_EXPERIMENTS
+    return channels == 128 && h * w == 49 && (!heads || conv_heads_fit(10, policy_kind, extra_moves, pc, h, w, channels, hc, hs));
+#else
+    return false;
+#endif
+}
+
 int tower32_boards_per_workgroup(int h, int w, int channels) {
     const int nt = tiles_for(h * w, channels);
     return nt ? nt * 16 / (h * w) : 0;
@@ -504,7 +527,7 @@ void launch_tower32(const Tower32Args &t, hipStream_t stream) {
     d.hw = t.h * t.w;
     d.depth = t.depth;
     d.stem_groups = (t.c_in + 15) / 16;
-    const int nt = tiles_for(d.hw, t.channels);
+    const int nt = t.dense3 ? 10 : tiles_for(d.hw, t.channels);
     d.nb = nt * 16 / d.hw;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
@@ -523,6 +546,9 @@ void launch_tower32(const Tower32Args &t, hipStream_t stream) {
     d.scalars = hd.scalars; d.policy = hd.policy; d.nonfinite_flag = hd.nonfinite_flag;
     const int grid = (t.batch + d.nb - 1) / d.nb;
     if (t.channels == 256) launch<256, 4>(d, hd.on, grid, stream);
+#ifdef KZ_EXPERIMENTS
+    else if (nt == 10) launch<128, 10, true>(d, hd.on, grid, stream);
+#endif
     else if (nt == 7) launch<128, 7>(d, hd.on, grid, stream);
     else if (nt == 6) launch<128, 6>(d, hd.on, grid, stream);
     else launch<128, 4>(d, hd.on, grid, stream);

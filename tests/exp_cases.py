@@ -1,6 +1,7 @@
 """Parity cases of the EXPERIMENT build (kzero_amd/libkzhip_exp.so: `KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh`): the kernel
 organisations that were built, measured and not adopted — four boards per workgroup (kz_tower4.hip), two Go boards per
-workgroup (kz_board_conv2.hip), the 32x32x16 MFMA variants, hipGraph replay — each against the product kernels compiled
+workgroup (kz_board_conv2.hip), the 32x32x16 MFMA variants, hipGraph replay, three Ataxx boards per workgroup of the
+exact-f32 launch — each against the product kernels compiled
 into the same library and against the oracle.  None of this code is in libkzhip.so.
 
 Not collected by `pytest tests/` (the file name does not match test_*.py): tests/test_gpu_experiments.py runs it in a
@@ -193,3 +194,39 @@ def test_hip_graph_replay_is_the_same_forward_pass(dev, game, depth, channels, h
             with pytest.raises(capi.KzError, match="non-finite activation"):
                 big.synchronize()
             big.synchronize()  # reported once
+
+
+def test_three_board_f32_launch_agrees_with_the_oracle(dev):
+    """KZ_T32_BOARDS=3: the exact-f32 one-launch network with THREE 7x7 boards per workgroup (ten tiles, images that hold
+    the boards' 147 rows and nothing behind them, three row tiles per wave in the heads' small convolutions) on BASELINE
+    configs[1] against the oracle and the product's two-board launch, ragged last workgroups included.  Measured (round 4,
+    tools/ab_a1_f32.sh): 7 % faster per board and workgroup, but a batch of 256 is 86 workgroups — 458k evals/s with three
+    engines, 517k with four, against 520k for two boards."""
+    blob = synth.random_model("ataxx-7", 8, 128, "ataxx_conv", seed=11)
+    bits, scalars_in = synth.random_boards("ataxx-7", 256, seed=12)
+    net = O.OracleNet(blob)
+    dense = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    s_ref, p_ref = net.forward(dense, threads=os.cpu_count() or 1)
+    model = capi.Model(blob=blob)
+    two = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F32)
+    os.environ["KZ_T32_BOARDS"] = "3"
+    try:
+        three = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F32)
+        os.environ["KZ_NO_FUSED_HEADS"] = "1"
+        three_tower = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F32)
+    finally:
+        os.environ.pop("KZ_T32_BOARDS", None)
+        os.environ.pop("KZ_NO_FUSED_HEADS", None)
+    assert two.launch_geometry(256) == (128, 2)
+    assert three.tower_path == "tower_resident_f32+heads" and three.launch_geometry(256) == (86, 3)
+    assert three_tower.tower_path == "tower_resident_f32" and three_tower.launch_geometry(5) == (2, 3)
+    for n in (256, 7, 5, 4, 3, 2, 1):
+        s3, p3 = three.eval_packed(bits[:n], scalars_in[:n])
+        assert_f32(s3, s_ref[:n], f"scalars, {n} boards")
+        assert_f32(p3, p_ref[:n], f"policy, {n} boards")
+        s2, p2 = two.eval_packed(bits[:n], scalars_in[:n])
+        assert_f32(s3, s2, f"scalars vs two boards, {n} boards")
+        assert_f32(p3, p2, f"policy vs two boards, {n} boards")
+        st, pt = three_tower.eval_packed(bits[:n], scalars_in[:n])
+        assert_f32(pt, p_ref[:n], f"policy, separate heads, {n} boards")
+        assert_f32(st, s_ref[:n], f"scalars, separate heads, {n} boards")
