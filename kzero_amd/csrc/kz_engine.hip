@@ -126,6 +126,7 @@ struct kz_engine {
     std::vector<void *> allocs, pinned;
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
     bool bsplit = false;  // split16 per layer through kz_board_conv_split16 (Go-size boards)
+    bool wide = false;    // the plain-f16 one-launch tower with twice the boards per workgroup (PathPlan::wide)
     bool fused32 = false;  // the exact-f32 resident launch with the conv policy head and the scalar head inside
     bool fused_split = false;  // the split-f16 launch with the scalar head and the policy head inside
     bool fused_pairs = false;  // the plain-f16 generic launch with the conv policy head and the scalar head inside
@@ -437,6 +438,7 @@ struct kz_engine {
                 hd.nonfinite_flag = nf_flag; hd.epoch = nf_epoch;
             }
             t.dense3 = t32_dense3;
+            t.wide = wide;
             prof.begin(split16 ? "kz_tower_resident_split" : pairs16 ? "kz_tower_resident_f16g" : "kz_tower_resident_f32", stream);
             if (split16) kz::launch_tower_split(t, stream);
             else if (pairs16) kz::launch_tower_pairs(t, false, stream);  // f16 tensors behind the same pointers
@@ -763,6 +765,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     e->split16 = plan.split16;
     e->bsplit = plan.bsplit;
     e->pairs16 = plan.pairs16;
+    e->wide = plan.wide;
     e->fused_pairs = plan.fused_pairs;
     e->fused32 = plan.fused32;
     e->fused_split = plan.fused_split;
@@ -773,6 +776,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     if (notower && notower[0] == '1' && e->resident) {
         e->resident = e->fused_heads = false;
         e->pairs16 = kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
+        e->wide = false;
         e->path = e->pairs16 ? "tower_resident_f16g" : "conv_igemm_f16";
     }
     const char *nb_env = getenv("KZ_TOWER_NB");
@@ -912,7 +916,7 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     const Model &m = *e->model;
     int per = 0, wgs = 0;
     if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
-    else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16);
+    else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16, e->wide);
     else if (e->resident32) per = e->t32_dense3 ? 3 : kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
     else if (e->path == "board_conv_split16") wgs = kz::board_conv_workgroups(batch, m.h, m.w, m.channels);

@@ -172,6 +172,7 @@ struct Tower32Args {
     size_t bits_stride = 0;
     const float *scalars_in = nullptr;
     int n_scalar = 0, n_bool = 0;
+    bool wide = false;    // launch_tower_pairs: twice the boards per workgroup (tower_split_wide_supported)
     bool dense3 = false;  // launch_tower32, experiment build: three 7x7 boards per workgroup (tower32_dense3_supported)
     // launch_tower32 only: the conv policy head (Conv1x1 C->C + ReLU in the weight stream as one more centre-tap layer,
     // then Conv1x1 C->pc, post_act.py:75-110) and the scalar head (post_act.py:8-31) in the same launch — the tower
@@ -217,7 +218,10 @@ void launch_tower32(const Tower32Args &a, hipStream_t stream);
 // (f32 in/out), `weights` = tower_split_pack_weights stream: 9 * ceil(c_in / 32) stem k-steps, then 9*C/32 per tower
 // convolution ----
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split);
-int tower_split_boards_per_workgroup(int h, int w, int channels, bool split);
+int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, bool wide = false);
+// plain f16, 128 channels: twice the boards per workgroup (Tower32Args::wide) when max_batch still gives >= 128 workgroups
+// (and, for four or more boards, when giving up the fused conv heads pays: depth >= 12)
+bool tower_split_wide_supported(int h, int w, int channels, int max_batch, int depth, bool fused_heads_possible);
 size_t tower_split_stem_elems(int channels, int c_in, bool split);              // f16 elements of the 9 * ceil(c_in / 32) stem k-steps
 size_t tower_split_weight_elems(int channels, int depth, int c_in, bool split);  // f16 elements: stem + 2 * depth layers
 void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool stem, bool split, uint16_t *dst);

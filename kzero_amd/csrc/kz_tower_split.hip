@@ -1092,11 +1092,23 @@ int split_tiles_for(int hw, int channels, bool split) {
     if (channels == 256 || channels == 320) return channels == 320 && split ? 0 : hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
     if (channels == 384 || channels == 512) return !split && hw <= 64 ? 4 : 0;
     if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
-    // (two 8x8 boards in eight tiles were measured at 64 / 128 / 192 channels: at 128, 0.29 against 0.32 of the peak with two
-    // engines, 0.37 against 0.38 with three, 0.29 against 0.32 with four; at 192, 0.42 against 0.45 — half as many
-    // workgroups, and the launch is not bound by the weight stream in the first place)
+    // (twice the boards per workgroup at 128 channels in plain f16: split_wide_tiles_for)
     if (channels == 128 || channels == 64) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
     return 0;
+}
+
+// Twice the boards per workgroup for the plain-f16 launch at 128 channels: two 8x8 boards in 8 tiles, two 9x9 boards in 11
+// (162 of 176 rows are boards; one board in six tiles: 81 of 96), four 7x7 or eight 5x5 boards in 13.  The weight stream
+// is read once per workgroup, so this halves the bytes a workgroup pulls from L2 per board.  While these launches waited
+// for their weights (four ring stages, rounds 1-3) that was measured SLOWER (half as many workgroups); since the deeper
+// ring (round 4) they are bound by the chip's power like the 256-channel launches, and less data moved per MFMA is more
+// MFMAs per watt: Go 9x9 16x128 at batch 2048 1.40M -> 1.62M evals/s, chess x 128 1.59M -> 1.69M (batch 256) / 1.57M ->
+// 1.70M (1024), Ataxx 7x7 x 128 (20 blocks) at batch 1024 2.04M -> 2.27M — but only with enough workgroups to fill the chip (Ataxx at
+// batch 256: 64 workgroups, 2.02M -> 1.69M), and not at 64 channels (latency-bound: 4.44M -> 3.97M at batch 256) or 192
+// (no difference).  No fused conv heads at these sizes (the tail's f32 row images do not fit the LDS).
+int split_wide_tiles_for(int hw, int channels) {
+    if (channels != 128) return 0;
+    return hw == 64 ? 8 : hw == 81 ? 11 : (hw == 49 || hw == 25) ? 13 : 0;
 }
 
 template <int C, int NT, bool SPLIT, int HEADS = 0>
@@ -1292,9 +1304,21 @@ bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool
     return depth >= 1 && c_in >= 1 && (c_in + 31) / 32 <= channels / 32 && h >= 2 && w >= 2 && w <= 32 && nt != 0;
 }
 
-int tower_split_boards_per_workgroup(int h, int w, int channels, bool split) {
-    const int nt = split_tiles_for(h * w, channels, split);
+int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, bool wide) {
+    const int nt = wide ? split_wide_tiles_for(h * w, channels) : split_tiles_for(h * w, channels, split);
     return nt ? nt * 16 / (h * w) : 0;
+}
+
+// whether a plain-f16 engine of this shape takes the wide tiles: at least 128 workgroups at max_batch — and, where the
+// narrow launch would carry the conv heads inside (fused_heads_possible) and the wide one holds four or more boards, a
+// tower deep enough to pay for the three head launches: same-box at batch 1024, Ataxx 7x7 x 128 with 20 blocks 1.98M ->
+// 2.18M evals/s, with 8 blocks 4.51M -> 4.36M (two 9x9 boards win at any depth: 8 blocks 2.43M -> 3.05M)
+bool tower_split_wide_supported(int h, int w, int channels, int max_batch, int depth, bool fused_heads_possible) {
+    const int nt = split_wide_tiles_for(h * w, channels);
+    if (!nt || !split_tiles_for(h * w, channels, false)) return false;
+    const int per = nt * 16 / (h * w);
+    if (per >= 4 && fused_heads_possible && depth < 12) return false;
+    return (max_batch + per - 1) / per >= 128;
 }
 
 size_t tower_split_stem_elems(int channels, int c_in, bool split) {  // f16 elements of the stem's k-steps
@@ -1481,7 +1505,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     d.w_ = t.w;
     d.hw = t.h * t.w;
     d.stem_chunks = (t.c_in + 31) / 32;
-    const int nt = split_tiles_for(d.hw, t.channels, split);
+    const int nt = !split && t.wide ? split_wide_tiles_for(d.hw, t.channels) : split_tiles_for(d.hw, t.channels, split);
     d.nb = nt * 16 / d.hw;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;
@@ -1541,6 +1565,9 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else if (t.channels == 192) launch<192, 6, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 4) launch<128, 4, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 7) launch<128, 7, false>(d, grid, stream);
+        else if (t.channels == 128 && nt == 8) launch<128, 8, false>(d, grid, stream);
+        else if (t.channels == 128 && nt == 11) launch<128, 11, false>(d, grid, stream);
+        else if (t.channels == 128 && nt == 13) launch<128, 13, false>(d, grid, stream);
         else if (t.channels == 128) launch<128, 6, false>(d, grid, stream);
         else if (nt == 4) launch<64, 4, false>(d, grid, stream);
         else if (nt == 7) launch<64, 7, false>(d, grid, stream);

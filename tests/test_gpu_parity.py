@@ -961,41 +961,49 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
             assert_f32(pd, p_ref, f"split16 fused, dense input, policy b={batch}")
 
 
-@pytest.mark.parametrize("game,depth,channels,head,batches", [
-    ("ataxx-7", 8, 128, "ataxx_conv", (1, 2, 13, 256)),  # BASELINE configs[1]'s network in f16: two boards per workgroup
-    ("chess", 2, 128, "attention", (3, 40)),             # 128 channels on an 8x8 board
-    ("go-9", 2, 128, "conv", (3, 11)),                   # 81 pixels: six tiles
-    ("go-9", 2, 256, "conv", (5, 64)),                   # 256 channels on 81 squares: six tiles, one board per workgroup
-    ("ataxx-7", 4, 64, "ataxx_conv", (7, 256)),          # BASELINE configs[0]'s network (64 channels)
-    ("go-19", 2, 128, "conv", (2,)),                     # 361 squares: not a shape of the launch
+@pytest.mark.parametrize("game,depth,channels,head,batches,max_batch", [
+    ("ataxx-7", 8, 128, "ataxx_conv", (1, 2, 13, 256), 256),  # BASELINE configs[1]'s network in f16: two boards per workgroup
+    ("chess", 2, 128, "attention", (3, 40), 64),              # 128 channels on an 8x8 board: one board per workgroup ...
+    ("chess", 2, 128, "attention", (1, 3, 40, 256), 256),     # ... two (eight tiles) when that still makes 128 workgroups
+    ("go-9", 2, 128, "conv", (3, 11), 64),                    # 81 pixels: six tiles, heads in the launch
+    ("go-9", 2, 128, "conv", (1, 2, 3, 11, 256), 256),        # two 9x9 boards in eleven tiles, separate heads
+    ("ataxx-7", 12, 128, "ataxx_conv", (1, 3, 4, 5, 9, 512), 512),  # four 7x7 boards in thirteen tiles (deep towers only)
+    ("go-9", 2, 256, "conv", (5, 64), 256),                   # 256 channels on 81 squares: six tiles, one board per workgroup
+    ("ataxx-7", 4, 64, "ataxx_conv", (7, 256), 256),          # BASELINE configs[0]'s network (64 channels)
+    ("go-19", 2, 128, "conv", (2,), 256),                     # 361 squares: not a shape of the launch
 ])
-def test_resident_f16g_tower(dev, game, depth, channels, head, batches):
+def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batch):
     """The one-launch f16 tower for the shapes the chess launch does not take (kz_tower_resident_split without its lo
     halves): against the oracle at the f16 tolerance, and against the per-layer implicit GEMM of the same engine — same
     operands and rounding points — at the far tighter summation-order bound."""
     blob = synth.random_model(game, depth, channels, head, seed=91)
     net = O.OracleNet(blob)
     model = capi.Model(blob=blob)
-    eng = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+    eng = capi.Engine(model, dev, max_batch, capi.KZ_DTYPE_F16)
     if game == "go-19":
         assert not eng.tower_path.startswith("tower_resident_f16g")
         return
+    # at 128 channels an engine whose max_batch still gives 128 workgroups takes twice the boards per workgroup (round 4)
+    wide_boards = {("chess", 256): 2, ("go-9", 256): 2, ("ataxx-7", 512): 4}.get((game, max_batch)) if channels == 128 else None
+    if channels == 128:
+        per = wide_boards or {"chess": 1, "go-9": 1, "ataxx-7": 2}[game]
+        assert eng.launch_geometry(max_batch) == ((max_batch + per - 1) // per, per)
     # conv-policy networks at 128 channels (256 on <= 64 squares) carry their heads in the launch since round 3: the tail of
-    # the exact-f32 launch on f32 copies of the f16 images
-    fused = head in ("ataxx_conv", "conv") and channels == 128
+    # the exact-f32 launch on f32 copies of the f16 images (not with the wide tiles: the f32 images do not fit)
+    fused = head in ("ataxx_conv", "conv") and channels == 128 and not wide_boards
     assert eng.tower_path == ("tower_resident_f16g+heads" if fused else "tower_resident_f16g")
     tower_only = eng
     if fused:
         os.environ["KZ_NO_FUSED_HEADS"] = "1"
         try:
-            tower_only = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+            tower_only = capi.Engine(model, dev, max_batch, capi.KZ_DTYPE_F16)
         finally:
             del os.environ["KZ_NO_FUSED_HEADS"]
         assert tower_only.tower_path == "tower_resident_f16g"
     os.environ["KZ_FORCE_GENERIC"] = "1"
     os.environ["KZ_NO_BOARD_CONV"] = "1"
     try:
-        gen = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+        gen = capi.Engine(model, dev, max_batch, capi.KZ_DTYPE_F16)
     finally:
         del os.environ["KZ_FORCE_GENERIC"], os.environ["KZ_NO_BOARD_CONV"]
     assert gen.tower_path == "conv_igemm_f16"
