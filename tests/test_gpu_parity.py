@@ -968,6 +968,7 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     ("go-9", 2, 128, "conv", (3, 11), 64),                    # 81 pixels: six tiles, heads in the launch
     ("go-9", 2, 128, "conv", (1, 2, 3, 11, 256), 256),        # two 9x9 boards in eleven tiles, separate heads
     ("ataxx-7", 12, 128, "ataxx_conv", (1, 3, 4, 5, 9, 512), 512),  # four 7x7 boards in thirteen tiles (deep towers only)
+    ("ataxx-5", 12, 128, "ataxx_conv", (1, 7, 8, 9, 17, 1024), 1024),  # eight 5x5 boards in thirteen tiles
     ("go-9", 2, 256, "conv", (5, 64), 256),                   # 256 channels on 81 squares: six tiles, one board per workgroup
     ("ataxx-7", 4, 64, "ataxx_conv", (7, 256), 256),          # BASELINE configs[0]'s network (64 channels)
     ("go-19", 2, 128, "conv", (2,), 256),                     # 361 squares: not a shape of the launch
@@ -984,7 +985,7 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
         assert not eng.tower_path.startswith("tower_resident_f16g")
         return
     # at 128 channels an engine whose max_batch still gives 128 workgroups takes twice the boards per workgroup (round 4)
-    wide_boards = {("chess", 256): 2, ("go-9", 256): 2, ("ataxx-7", 512): 4}.get((game, max_batch)) if channels == 128 else None
+    wide_boards = {("chess", 256): 2, ("go-9", 256): 2, ("ataxx-7", 512): 4, ("ataxx-5", 1024): 8}.get((game, max_batch)) if channels == 128 else None
     if channels == 128:
         per = wide_boards or {"chess": 1, "go-9": 1, "ataxx-7": 2}[game]
         assert eng.launch_geometry(max_batch) == ((max_batch + per - 1) // per, per)
