@@ -14,10 +14,24 @@ CASES = [("chess", 20, 256, "attention", 256, capi.KZ_DTYPE_F16, 200),
          ("go-9", 6, 128, "conv", 200, capi.KZ_DTYPE_F32, 200),            # the same with the extra-move head, one board per workgroup
          ("go-19", 6, 256, "conv", 509, capi.KZ_DTYPE_F16, 150),           # round 3 board-tile kernel: ring-register prefetch, odd batch
          ("chess", 6, 256, "attention", 251, capi.KZ_DTYPE_F32_SPLIT16, 150),  # round 3: split launch with the heads inside
-         ("go-19", 3, 128, "conv", 203, capi.KZ_DTYPE_F32_SPLIT16, 100)]       # round 3: per-layer split board-tile kernel
+         ("go-19", 3, 128, "conv", 203, capi.KZ_DTYPE_F32_SPLIT16, 100),       # round 3: per-layer split board-tile kernel
+         # round 4: wide stems, the new channel counts, widened towers, the attention head on the matrix cores (f16 / f32),
+         # two / four boards per workgroup of the plain-f16 launch, the branch-free heads tail with a wide scalar head
+         ("chess-hist-3", 4, 256, "attention", 255, capi.KZ_DTYPE_F16, 150),
+         ("chess-hist-2", 4, 256, "attention", 251, capi.KZ_DTYPE_F32_SPLIT16, 100),
+         ("chess", 4, 192, "attention", 255, capi.KZ_DTYPE_F16, 150),
+         ("chess", 4, 192, "attention", 255, capi.KZ_DTYPE_F32_SPLIT16, 100),
+         ("chess", 4, 384, "attention", 255, capi.KZ_DTYPE_F16, 100),
+         ("chess", 4, 96, "attention", 255, capi.KZ_DTYPE_F16, 150),
+         ("chess", 4, 128, "attention", 301, capi.KZ_DTYPE_F16, 200),
+         ("chess", 4, 128, "attention", 255, capi.KZ_DTYPE_F32, 100),
+         ("go-9", 4, 128, "conv", 1025, capi.KZ_DTYPE_F16, 150),
+         ("ataxx-7", 12, 128, "ataxx_conv", 1021, capi.KZ_DTYPE_F16, 100),
+         ("go-19", 4, 256, "conv", 131, capi.KZ_DTYPE_F32_SPLIT16, 60)]
+KW = {("go-9", 1025): dict(scalar_hidden_channels=8, scalar_hidden_size=128)}
 bad = 0
 for game, depth, ch, head, batch, dtype, reps in CASES:
-    blob = synth.random_model(game, depth, ch, head, seed=9)
+    blob = synth.random_model(game, depth, ch, head, seed=9, **KW.get((game, batch), {}))
     bits, sc = synth.random_boards(game, batch, seed=10)
     engines = [capi.Engine(capi.Model(blob=blob), 0, batch, dtype) for _ in range(2)]
     s0, p0 = engines[0].eval_packed(bits, sc)
