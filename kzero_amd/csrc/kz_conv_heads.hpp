@@ -1,6 +1,7 @@
-// kz_conv_heads.hpp — the scalar head and the conv policy heads (ConvPolicyHead, AtaxxConvPolicyHead) on two f32 row images
-// that already sit in LDS: the tail of the one-launch networks.  Shared by the exact-f32 launch (kz_tower_f32.hip) and the
-// split-f16 launch (kz_tower_split.hip, which converts its (hi, lo) images to f32 rows first).  Arithmetic follows
+// kz_conv_heads.hpp — the scalar head and the conv policy heads (ConvPolicyHead, AtaxxConvPolicyHead) on two images (the tower
+// output and the policy head's hidden layer) that already sit in LDS: the tail of the one-launch networks.  Shared by the
+// exact-f32 launch (kz_tower_f32.hip), the split-f16 launch (kz_tower_split.hip, which converts its (hi, lo) images to f32
+// rows first) and the plain-f16 launch (which runs the two small convolutions on its f16 images).  Arithmetic follows
 // python/lib/model/post_act.py:8-31 (scalar head) and :75-110 (conv policy heads).
 //
 // Device code only; included INSIDE `namespace kz { namespace {` of a .hip file, after f32x4 is defined.  `Dev` is the
@@ -23,58 +24,19 @@ __device__ __forceinline__ int plane_of(int kq) {  // byte offset of lane group 
     return C == 256 ? 256 * kq : 256 * (kq & 1) + 128 * (kq >> 1);
 }
 
-// Images: rows of C f32 (natural channel order), row stride RS = 4 C + 16 bytes, NT tiles of 16 rows; `xin` = LDS offset of
-// the tower output (after the final BN), `hin` = of the policy head's hidden layer (Conv1x1 C->C + ReLU), `scratch` = of
-// 16 * RS bytes the tail may overwrite (the f32 launch's zero rows).  board0 / boards / rows_valid: this workgroup's
-// boards; rows_img: rows an image really holds (a tile row behind them is read as the last row and never emitted).  Every thread of the 256 calls it; the caller has synchronised the workgroup behind the images' last writes.
-template <int C, int NT, typename Dev>
-__device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds, int scratch, int xin, int hin, int board0,
-                                               int boards, int rows_valid, int rows_img = NT * 16) {
-    constexpr int G = C / 16, RS = C * 4 + 16, ZERO = 0;
+// The tail behind the two small convolutions' operands: small_conv(which, emit) runs the 1x1 convolution with at most 32
+// output channels over the tower output (which = 0: the scalar head's filters and the extra-move filter) or over the policy
+// head's hidden layer (which = 1: the policy planes) on the matrix cores and calls emit(mt, q, row, value) for this lane's
+// results — output channel mt * 16 + kq * 4 + q of pixel row `row` (the accumulator layout of a 16x16 MFMA with the weights as
+// the row operand), rows of this workgroup's boards only.  Two providers: conv_heads_f32 below (f32 row images, exact-f32
+// MFMAs: the exact-f32 and the split launches) and the plain-f16 launch's own (kz_tower_split.hip: f16 MFMAs straight on its
+// f16 images).
+template <int C, int NT, typename Dev, typename SmallConv>
+__device__ __forceinline__ void conv_heads_tail(const Dev &a, unsigned char *lds, int scratch, int board0, int boards,
+                                                int rows_valid, SmallConv small_conv) {
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int fr = lane & 15, kq = lane >> 4;
-    const int koff = plane_of<C>(kq);
-    (void)ZERO;
-    // A 1x1 convolution with at most 32 output channels (two 16-channel tiles, zero-padded by the host) on the MFMAs:
-    // the row tiles are split over the waves (wave w: tiles w, w + 4 and w + 8), every wave streams the whole (small)
-    // weight fragment set: 16 * C/16 MFMAs per wave and tile.  emit(oc, row, value) for this lane's 2 x TW x 4 results.
-    constexpr int TW = (NT + 3) / 4;  // tiles per wave
-    auto small_conv = [&](int img, const f32x4 *wfrag /* [G][2][64] */, auto emit) {
-        f32x4 sa[2][TW];
-        int base[TW];
-#pragma unroll
-        for (int t = 0; t < TW; t++) {
-            sa[0][t] = sa[1][t] = f32x4{0, 0, 0, 0};
-            const int row = (wave + 4 * t) * 16 + fr;
-            base[t] = img + (row < rows_img ? row : rows_img - 1) * RS + koff;
-        }
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const f32x4 w0 = wfrag[(g * 2 + 0) * 64 + lane], w1 = wfrag[(g * 2 + 1) * 64 + lane];
-            f32x4 bt[TW];
-#pragma unroll
-            for (int t = 0; t < TW; t++) bt[t] = *reinterpret_cast<const f32x4 *>(lds + base[t] + g * 16);
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int t = 0; t < TW; t++) {
-                    sa[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], bt[t][q], sa[0][t], 0, 0, 0);
-                    sa[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], bt[t][q], sa[1][t], 0, 0, 0);
-                }
-        }
-#pragma unroll
-        for (int t = 0; t < TW; t++) {
-            const int row = (wave + 4 * t) * 16 + fr;
-            if (wave + 4 * t < NT && row < rows_valid) {
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) emit(mt, q, row, sa[mt][t][q]);
-            }
-        }
-    };
+    const int kq = lane >> 4;
     // the zero rows are dead by now: scratch for the scalar head
     const int n_in = a.hc * a.hw, nseg = 256 / a.hs;
     float *sact = reinterpret_cast<float *>(lds + scratch);  // [nb][hc*hw] channel-major like nn.Flatten on NCHW (post_act.py:16)
@@ -109,7 +71,7 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
     KZ_HEADS_STAMP(56);
     // scalar head Conv1x1 C->hc + ReLU and the extra moves' Conv1x1 C->1 (post_act.py:8-31, :86-96): one small conv over x
     bool bad = false;  // a non-finite sum = a non-finite value somewhere in this board's tower output
-    small_conv(xin, a.small_w, [&](int mt, int q, int row, float v) {
+    small_conv(0, [&](int mt, int q, int row, float v) {
         const int oc = mt * 16 + kq * 4 + q;
         const int bb = (int)(((unsigned)row * a.inv_hw) >> 16), p = row - bb * a.hw;
         if (oc < a.hc) {
@@ -122,7 +84,7 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
     KZ_HEADS_STAMP(57);
     if (bad && a.nonfinite_flag) *reinterpret_cast<volatile int *>(a.nonfinite_flag) = a.epoch;  // (plain store: the flag may live in pinned host memory)
     // policy (post_act.py:75-110): Conv1x1 C->pc on the hidden layer, channel-major flatten
-    small_conv(hin, a.small_w + G * 2 * 64, [&](int mt, int q, int row, float v) {
+    small_conv(1, [&](int mt, int q, int row, float v) {
         const int oc = mt * 16 + kq * 4 + q;
         const int bb = (int)(((unsigned)row * a.inv_hw) >> 16), p = row - bb * a.hw;
         if (oc < a.pc) a.policy[(size_t)(board0 + bb) * a.policy_len + oc * a.hw + p] = v + pb[mt][q];
@@ -220,4 +182,61 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
         for (int i = 0; i < a.hs; i++) s += sw2[j * a.hs + i] * shid[bb * a.hs + i];
         a.scalars[(size_t)(board0 + bb) * 5 + j] = s;
     }
+}
+
+// Images: rows of C f32 (natural channel order), row stride RS = 4 C + 16 bytes, NT tiles of 16 rows; `xin` = LDS offset of
+// the tower output (after the final BN), `hin` = of the policy head's hidden layer (Conv1x1 C->C + ReLU), `scratch` = of
+// 16 * RS bytes the tail may overwrite (the f32 launch's zero rows).  board0 / boards / rows_valid: this workgroup's
+// boards; rows_img: rows an image really holds (a tile row behind them is read as the last row and never emitted).
+// Every thread of the 256 calls it; the caller has synchronised the workgroup behind the images' last writes.
+template <int C, int NT, typename Dev>
+__device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds, int scratch, int xin, int hin, int board0,
+                                               int boards, int rows_valid, int rows_img = NT * 16) {
+    constexpr int G = C / 16, RS = C * 4 + 16;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int fr = lane & 15, kq = lane >> 4;
+    const int koff = plane_of<C>(kq);
+    // A 1x1 convolution with at most 32 output channels (two 16-channel tiles, zero-padded by the host) on the MFMAs:
+    // the row tiles are split over the waves (wave w: tiles w, w + 4 and w + 8), every wave streams the whole (small)
+    // weight fragment set: 16 * C/16 MFMAs per wave and tile.
+    constexpr int TW = (NT + 3) / 4;  // tiles per wave
+    auto small_conv = [&](int which, auto emit) {
+        const int img = which ? hin : xin;
+        const f32x4 *wfrag = a.small_w + which * (G * 2 * 64);  // [G][2][64]
+        f32x4 sa[2][TW];
+        int base[TW];
+#pragma unroll
+        for (int t = 0; t < TW; t++) {
+            sa[0][t] = sa[1][t] = f32x4{0, 0, 0, 0};
+            const int row = (wave + 4 * t) * 16 + fr;
+            base[t] = img + (row < rows_img ? row : rows_img - 1) * RS + koff;
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const f32x4 w0 = wfrag[(g * 2 + 0) * 64 + lane], w1 = wfrag[(g * 2 + 1) * 64 + lane];
+            f32x4 bt[TW];
+#pragma unroll
+            for (int t = 0; t < TW; t++) bt[t] = *reinterpret_cast<const f32x4 *>(lds + base[t] + g * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < TW; t++) {
+                    sa[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q], bt[t][q], sa[0][t], 0, 0, 0);
+                    sa[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q], bt[t][q], sa[1][t], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < TW; t++) {
+            const int row = (wave + 4 * t) * 16 + fr;
+            if (wave + 4 * t < NT && row < rows_valid) {
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) emit(mt, q, row, sa[mt][t][q]);
+            }
+        }
+    };
+    conv_heads_tail<C, NT>(a, lds, scratch, board0, boards, rows_valid, small_conv);
 }

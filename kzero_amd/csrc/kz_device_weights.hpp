@@ -222,11 +222,19 @@ struct DeviceWeights {
             if (conv_heads) {  // the policy head's hidden layer as one more pass; the small convolutions as for the f32 launch
                 kz::tower_split_pack_conv_heads(m.p_conv0.w.data(), C, split16, packed.data() + tower_elems);
                 for (int o = 0; o < C; o++) bias[(size_t)(1 + 2 * m.depth) * C + o] = m.p_conv0.b[o];
-                std::vector<float> small(kz::tower32_small_weight_elems(C));
-                kz::tower32_pack_small_weights(m.sh_conv.w.data(), m.sh_conv.cout,
-                                               m.policy_extra_moves ? m.p_extra_conv.w.data() : nullptr, m.p_conv1.w.data(),
-                                               m.policy_conv_channels, C, small.data());
-                if (upload_f32(small, &h32_small)) return 1;
+                if (pairs16) {  // the plain-f16 launch runs the two small convolutions as f16 MFMAs
+                    std::vector<uint16_t> small(kz::tower_split_small_weight16_elems(C));
+                    kz::tower_split_pack_small_weights16(m.sh_conv.w.data(), m.sh_conv.cout,
+                                                         m.policy_extra_moves ? m.p_extra_conv.w.data() : nullptr,
+                                                         m.p_conv1.w.data(), m.policy_conv_channels, C, small.data());
+                    if (upload(small.data(), small.size() * 2, (void **)&h32_small)) return 1;
+                } else {
+                    std::vector<float> small(kz::tower32_small_weight_elems(C));
+                    kz::tower32_pack_small_weights(m.sh_conv.w.data(), m.sh_conv.cout,
+                                                   m.policy_extra_moves ? m.p_extra_conv.w.data() : nullptr, m.p_conv1.w.data(),
+                                                   m.policy_conv_channels, C, small.data());
+                    if (upload_f32(small, &h32_small)) return 1;
+                }
             }
             if (heads) {
                 kz::tower_split_pack_heads(m.p_bulk.w.data(), m.p_bulk.b.data(), m.p_under.w.data(), m.p_under.b.data(),

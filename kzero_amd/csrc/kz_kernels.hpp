@@ -201,7 +201,10 @@ bool tower32_dense3_supported(int policy_kind, int extra_moves, int pc, int h, i
 // conv / ataxx_conv policy head + a scalar head whose activations fit the launch's spare LDS
 bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs);
 // the same question for any launch that ends in kz_conv_heads.hpp with nt tiles of 16 pixel rows per workgroup
-bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs);
+bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs,
+                    size_t scratch_bytes = 0);
+// the plain-f16 launch keeps the tail's scratch behind its own images: this much
+constexpr size_t F16_TAIL_SCRATCH_BYTES = 16 * 1024;
 size_t tower32_small_weight_elems(int channels);
 void tower32_pack_small_weights(const float *sh_w0, int hc, const float *pe_wc /* or null */, const float *p_w1, int pc,
                                 int channels, float *dst);
@@ -220,8 +223,7 @@ void launch_tower32(const Tower32Args &a, hipStream_t stream);
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split);
 int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, bool wide = false);
 // plain f16, 128 channels: twice the boards per workgroup (Tower32Args::wide) when max_batch still gives >= 128 workgroups
-// (and, for four or more boards, when giving up the fused conv heads pays: depth >= 12)
-bool tower_split_wide_supported(int h, int w, int channels, int max_batch, int depth, bool fused_heads_possible);
+bool tower_split_wide_supported(int h, int w, int channels, int max_batch);
 size_t tower_split_stem_elems(int channels, int c_in, bool split);              // f16 elements of the 9 * ceil(c_in / 32) stem k-steps
 size_t tower_split_weight_elems(int channels, int depth, int c_in, bool split);  // f16 elements: stem + 2 * depth layers
 void tower_split_pack_weights(const float *oihw, int cout, int cin, int hw, bool stem, bool split, uint16_t *dst);
@@ -235,9 +237,14 @@ void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const floa
 // ... and for the conv policy heads (Ataxx, Go 9x9) at 128 / 256 channels: the policy head's Conv1x1 C->C rides behind the
 // tower as one more pass (its bias as one more bias row), the rest is the exact-f32 launch's tail (Tower32Args::Heads with
 // small_w set, as for launch_tower32) on f32 copies of the LDS images
-// (split = false: the same in the plain-f16 launch, launch_tower_pairs(t, false): "tower_resident_f16g+heads")
+// (split = false: the plain-f16 launch, launch_tower_pairs(t, false): "tower_resident_f16g+heads" — the same tail with its
+// two small convolutions as f16 MFMAs on the f16 images: Heads::small_w = tower_split_pack_small_weights16; wide: with
+// Tower32Args::wide)
 bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs,
-                                      bool split);
+                                      bool split, bool wide = false);
+size_t tower_split_small_weight16_elems(int channels);  // f16 elements
+void tower_split_pack_small_weights16(const float *sh_w0, int hc, const float *pe_wc /* or null */, const float *p_w1, int pc,
+                                      int channels, uint16_t *dst);
 size_t tower_split_conv_heads_weight_elems(int channels, bool split);
 void tower_split_pack_conv_heads(const float *w /* [C][C] */, int channels, bool split, uint16_t *dst);
 // the same launch without the lo halves (split = false): plain f16 arithmetic, x0 and y are f16 tensors behind the

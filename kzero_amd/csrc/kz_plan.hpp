@@ -95,11 +95,10 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
     p.pairs16 = dtype == KZ_DTYPE_F16 && !p.resident && !force && !p.keep && !env_on("KZ_NO_RESIDENT_F16G") &&
                 kz::tower_split_supported(m.h, m.w, m.channels, m.depth, m.c_in, false);
     p.board_conv = board_conv_ok && !p.pairs16 && !p.bsplit;
-    const bool pairs_heads_ok = p.pairs16 && !nofuse &&
-                                kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h,
-                                                                     m.w, m.channels, m.sh_conv.cout, m.sh_fc0.out, false);
-    p.wide = p.pairs16 && kz::tower_split_wide_supported(m.h, m.w, m.channels, max_batch, m.depth, pairs_heads_ok);
-    p.fused_pairs = pairs_heads_ok && !p.wide;
+    p.wide = p.pairs16 && kz::tower_split_wide_supported(m.h, m.w, m.channels, max_batch);
+    p.fused_pairs = p.pairs16 && !nofuse &&
+                    kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
+                                                         m.channels, m.sh_conv.cout, m.sh_fc0.out, false, p.wide);
     p.fused32 = p.resident32 && !p.split16 && !nofuse &&
                 kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w, m.channels,
                                             m.sh_conv.cout, m.sh_fc0.out);

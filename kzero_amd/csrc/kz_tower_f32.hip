@@ -404,17 +404,18 @@ bool tower32_heads_supported(int policy_kind, int extra_moves, int pc, int h, in
     return conv_heads_fit(tiles_for(h * w, channels), policy_kind, extra_moves, pc, h, w, channels, hc, hs);
 }
 
-// kz_conv_heads.hpp on a launch of nt tiles of 16 rows: at most 12 tiles (three per wave) and four boards
-bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs) {
+// kz_conv_heads.hpp on a launch of nt tiles of 16 rows: at most 16 tiles (four per wave) and four boards
+bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs, size_t scratch_bytes) {
     const int hw = h * w;
-    if (!nt || nt > 12 || (policy_kind != 0 && policy_kind != 1) || extra_moves < 0 || hc < 1 || hs < 1 || hs > 256) return false;
+    if (!nt || nt > 16 || (policy_kind != 0 && policy_kind != 1) || extra_moves < 0 || hc < 1 || hs < 1 || hs > 256) return false;
     if (policy_kind == 0 && extra_moves) return false;
     if (pc < 1 || pc > 32 || hc + (extra_moves ? 1 : 0) > 32) return false;  // two 16-channel tiles per small conv
     const int nb = nt * 16 / hw, nseg = 256 / hs;
     if (nb > 4) return false;
     // the zero rows' LDS: conv activations, extra-move plane, hidden, last Linear's weights, partial sums
     const size_t floats = (size_t)nb * hc * hw + (size_t)nb * hw + (size_t)nb * hs + (size_t)5 * hs + (size_t)nseg * nb * hs;
-    return floats * 4 <= (size_t)16 * (channels * 4 + 16);
+    // (scratch_bytes = 0: the zero rows of the f32 images, what the exact-f32 and the split launches have)
+    return floats * 4 <= (scratch_bytes ? scratch_bytes : (size_t)16 * (channels * 4 + 16));
 }
 
 size_t tower32_heads_weight_elems(int channels) { return (size_t)channels * channels; }

@@ -118,6 +118,7 @@ struct SplitDev {
     int hc, hs, pc, policy_len, zero_tail, extra;
     const float *sh_w1t, *p_b1, *pe_bc, *pe_wl, *pe_bl;
     const f32x4 *small_w;
+    const uint4 *small_w16;  // plain f16: the two small convolutions as f16 fragments (tower_split_pack_small_weights16)
     float *scalars, *policy;
     int *nonfinite_flag;
     int epoch;
@@ -496,45 +497,87 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
         }
         epilogue(YH, true, false);
         __syncthreads();
-        // Both images, (hi, lo) — or plain f16 — -> f32 rows in the layout of kz_tower_f32.hip ([16 scratch rows][X][Y], row stride 4 C + 16),
-        // through registers (everything else in LDS is dead); then the exact-f32 launch's own tail.
-        constexpr int RS32 = C * 4 + 16, X32 = 16 * RS32, Y32 = X32 + L::ROWS * RS32;
-        static_assert(Y32 + L::ROWS * RS32 <= 160 * 1024, "the f32 images fit a CU's LDS (the launcher asks for them)");
-        constexpr int PIECES = L::ROWS * (C / 4), PER = (PIECES + 255) / 256;
-        f32x4 vx[PER], vy[PER];
+        if constexpr (!SPLIT) {
+            // Plain f16: the two small convolutions run as f16 MFMAs straight on the two f16 images (the tower's own fragment
+            // reads: lane group kq's 16-byte piece of k-step g at kq_off + 16 g of the row; the weights packed to match),
+            // row tiles split over the waves like in the f32 provider; the tail's scratch is F16_TAIL_SCRATCH_BYTES BEHIND the
+            // launch's own LDS (the launcher asks for them), so no f32 copies of the images and any number of tiles.
+            constexpr int TW = (NT + 3) / 4;
+            auto small_conv = [&](int which, auto emit) {
+                const int img = which ? YH : XH;
+                const uint4 *wfrag = a.small_w16 + which * (G * 2 * 64);  // [G][2][64]
+                f32x4 sa[2][TW];
+                int base[TW];
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int id = tid + k * 256;
-            if (id < PIECES) {
-                const int r = id / (C / 4), p4 = id - r * (C / 4), off = r * RS + L::chan_off(p4 * 8);
-                const h16x4 xh = *reinterpret_cast<const h16x4 *>(lds + XH + off), yh = *reinterpret_cast<const h16x4 *>(lds + YH + off);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    vx[k][j] = (float)xh[j];
-                    vy[k][j] = (float)yh[j];
+                for (int t = 0; t < TW; t++) {
+                    sa[0][t] = sa[1][t] = f32x4{0, 0, 0, 0};
+                    const int row = (wave + 4 * t) * 16 + fr;
+                    base[t] = img + (row < L::ROWS ? row : L::ROWS - 1) * RS + kq_off;
                 }
-                if constexpr (SPLIT) {
-                    const h16x4 xl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off), yl = *reinterpret_cast<const h16x4 *>(lds + YH + DELTA + off);
+#pragma unroll
+                for (int gs = 0; gs < G; gs++) {
+                    const uint4 w0 = wfrag[(gs * 2 + 0) * 64 + lane], w1 = wfrag[(gs * 2 + 1) * 64 + lane];
+                    const h16x8 a0 = *reinterpret_cast<const h16x8 *>(&w0), a1 = *reinterpret_cast<const h16x8 *>(&w1);
+#pragma unroll
+                    for (int t = 0; t < TW; t++) {
+                        const h16x8 b = *reinterpret_cast<const h16x8 *>(lds + base[t] + gs * 16);
+                        sa[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, sa[0][t], 0, 0, 0);
+                        sa[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, sa[1][t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TW; t++) {
+                    const int row = (wave + 4 * t) * 16 + fr;
+                    if (wave + 4 * t < NT && row < rows_valid) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) emit(mt, q, row, sa[mt][t][q]);
+                    }
+                }
+            };
+            conv_heads_tail<C, NT>(a, lds, L::LDS_BYTES, board0, boards, rows_valid, small_conv);
+        } else {
+            // Both images, (hi, lo) — or plain f16 — -> f32 rows in the layout of kz_tower_f32.hip ([16 scratch rows][X][Y], row stride 4 C + 16),
+            // through registers (everything else in LDS is dead); then the exact-f32 launch's own tail.
+            constexpr int RS32 = C * 4 + 16, X32 = 16 * RS32, Y32 = X32 + L::ROWS * RS32;
+            static_assert(Y32 + L::ROWS * RS32 <= 160 * 1024, "the f32 images fit a CU's LDS (the launcher asks for them)");
+            constexpr int PIECES = L::ROWS * (C / 4), PER = (PIECES + 255) / 256;
+            f32x4 vx[PER], vy[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int id = tid + k * 256;
+                if (id < PIECES) {
+                    const int r = id / (C / 4), p4 = id - r * (C / 4), off = r * RS + L::chan_off(p4 * 8);
+                    const h16x4 xh = *reinterpret_cast<const h16x4 *>(lds + XH + off), yh = *reinterpret_cast<const h16x4 *>(lds + YH + off);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        vx[k][j] += (float)xl[j];
-                        vy[k][j] += (float)yl[j];
+                        vx[k][j] = (float)xh[j];
+                        vy[k][j] = (float)yh[j];
+                    }
+                    if constexpr (SPLIT) {
+                        const h16x4 xl = *reinterpret_cast<const h16x4 *>(lds + XH + DELTA + off), yl = *reinterpret_cast<const h16x4 *>(lds + YH + DELTA + off);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            vx[k][j] += (float)xl[j];
+                            vy[k][j] += (float)yl[j];
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int id = tid + k * 256;
-            if (id < PIECES) {
-                const int r = id / (C / 4), p4 = id - r * (C / 4);
-                *reinterpret_cast<f32x4 *>(lds + X32 + r * RS32 + p4 * 16) = vx[k];
-                *reinterpret_cast<f32x4 *>(lds + Y32 + r * RS32 + p4 * 16) = vy[k];
+            for (int k = 0; k < PER; k++) {
+                const int id = tid + k * 256;
+                if (id < PIECES) {
+                    const int r = id / (C / 4), p4 = id - r * (C / 4);
+                    *reinterpret_cast<f32x4 *>(lds + X32 + r * RS32 + p4 * 16) = vx[k];
+                    *reinterpret_cast<f32x4 *>(lds + Y32 + r * RS32 + p4 * 16) = vy[k];
+                }
             }
+            __syncthreads();
+            conv_heads_f32<C, NT>(a, lds, 0, X32, Y32, board0, boards, rows_valid);
         }
-        __syncthreads();
-        conv_heads_f32<C, NT>(a, lds, 0, X32, Y32, board0, boards, rows_valid);
     }
 
     if constexpr (HEADS == 1) {
@@ -1116,9 +1159,11 @@ void launch(const SplitDev &d, int grid, hipStream_t stream) {
     static thread_local unsigned long long done_mask = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    // (the conv heads' tail wants the two images as f32 rows: more than the plain-f16 launch's own LDS)
-    constexpr int F32_IMAGES = (16 + 2 * NT * 16) * (C * 4 + 16);
-    constexpr int LDS = HEADS == 2 && F32_IMAGES > Geo<C, NT, SPLIT>::LDS_BYTES ? F32_IMAGES : Geo<C, NT, SPLIT>::LDS_BYTES;
+    // (the conv heads' tail: the split launch wants the two images as f32 rows; the plain-f16 launch the tail's scratch,
+    // F16_TAIL_SCRATCH_BYTES, behind its own images)
+    constexpr int F32_IMAGES = (16 + 2 * NT * 16) * (C * 4 + 16), OWN = Geo<C, NT, SPLIT>::LDS_BYTES;
+    constexpr int LDS = HEADS != 2 ? OWN : !SPLIT ? OWN + (int)F16_TAIL_SCRATCH_BYTES : F32_IMAGES > OWN ? F32_IMAGES : OWN;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT, SPLIT, HEADS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1309,15 +1354,11 @@ int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, boo
     return nt ? nt * 16 / (h * w) : 0;
 }
 
-// whether a plain-f16 engine of this shape takes the wide tiles: at least 128 workgroups at max_batch — and, where the
-// narrow launch would carry the conv heads inside (fused_heads_possible) and the wide one holds four or more boards, a
-// tower deep enough to pay for the three head launches: same-box at batch 1024, Ataxx 7x7 x 128 with 20 blocks 1.98M ->
-// 2.18M evals/s, with 8 blocks 4.51M -> 4.36M (two 9x9 boards win at any depth: 8 blocks 2.43M -> 3.05M)
-bool tower_split_wide_supported(int h, int w, int channels, int max_batch, int depth, bool fused_heads_possible) {
+// whether a plain-f16 engine of this shape takes the wide tiles: at least 128 workgroups at max_batch
+bool tower_split_wide_supported(int h, int w, int channels, int max_batch) {
     const int nt = split_wide_tiles_for(h * w, channels);
     if (!nt || !split_tiles_for(h * w, channels, false)) return false;
     const int per = nt * 16 / (h * w);
-    if (per >= 4 && fused_heads_possible && depth < 12) return false;
     return (max_batch + per - 1) / per >= 128;
 }
 
@@ -1446,12 +1487,14 @@ void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const floa
 
 // ---- conv policy heads in the split launch: the shapes of the exact-f32 launch's fused heads at 128 / 256 channels ----
 bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs,
-                                      bool split) {
+                                      bool split, bool wide) {
     if (channels != 128 && channels != 256) return false;
-    const int nt = split_tiles_for(h * w, channels, split);
-    // (instances: <256, 4> and <128, 4 / 6 / 7>; the f32 row images of the tail must fit the LDS next to nothing else)
-    if (nt == 0 || (channels == 256 && nt != 4) || (size_t)(16 + 2 * nt * 16) * (channels * 4 + 16) > (size_t)160 * 1024) return false;
-    return conv_heads_fit(nt, policy_kind, extra_moves, pc, h, w, channels, hc, hs);
+    const int nt = !split && wide ? split_wide_tiles_for(h * w, channels) : split_tiles_for(h * w, channels, split);
+    // instances: <256, 4> and <128, 4 / 6 / 7> (plain f16: <128, 8 / 11 / 13> too).  Split arithmetic: the f32 row images of the
+    // tail must fit the LDS next to nothing else; plain f16: the tail's scratch behind the launch's own images.
+    if (nt == 0 || (channels == 256 && nt != 4)) return false;
+    if (split && (size_t)(16 + 2 * nt * 16) * (channels * 4 + 16) > (size_t)160 * 1024) return false;
+    return conv_heads_fit(nt, policy_kind, extra_moves, pc, h, w, channels, hc, hs, split ? 0 : F16_TAIL_SCRATCH_BYTES);
 }
 
 size_t tower_split_conv_heads_weight_elems(int channels, bool split) { return (size_t)(channels / 32) * (split ? 2 : 1) * channels * 32; }  // one pass
@@ -1480,6 +1523,36 @@ void tower_split_pack_conv_heads(const float *w, int channels, bool split, uint1
                         if (split) step[part + e] = lb;
                     }
     }
+}
+
+size_t tower_split_small_weight16_elems(int channels) { return (size_t)2 * (channels / 32) * 2 * 64 * 8; }
+
+// The plain-f16 launch's two small convolutions ([hc (+ 1 extra-move)][C] over the tower output, [pc][C] over the policy
+// head's hidden layer; at most 32 output channels each, zero-padded) as f16 MFMA row-operand fragments in the tower layers'
+// channel assignment: [conv 2][k-step C/32][tile 2][lane 64][8]
+void tower_split_pack_small_weights16(const float *sh_w0, int hc, const float *pe_wc, const float *p_w1, int pc, int channels,
+                                      uint16_t *dst) {
+    const int C = channels;
+    size_t o = 0;
+    for (int conv = 0; conv < 2; conv++)
+        for (int chunk = 0; chunk < C / 32; chunk++)
+            for (int mt = 0; mt < 2; mt++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int kq = lane >> 4, oc = 16 * mt + (lane & 15);
+                        const int ch = 8 * chunk + (C / 2) * (kq & 1) + (C / 4) * (kq >> 1) + j;
+                        float v = 0.0f;
+                        if (conv == 0) {
+                            if (oc < hc) v = sh_w0[(size_t)oc * C + ch];
+                            else if (oc == hc && pe_wc) v = pe_wc[ch];
+                        } else if (oc < pc) {
+                            v = p_w1[(size_t)oc * C + ch];
+                        }
+                        const _Float16 h = (_Float16)v;
+                        uint16_t hb;
+                        __builtin_memcpy(&hb, &h, 2);
+                        dst[o++] = hb;
+                    }
 }
 
 void launch_tower_split(const Tower32Args &t, hipStream_t stream) { launch_tower_pairs(t, true, stream); }
@@ -1520,6 +1593,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
             d.hc = hd.hc; d.hs = hd.hs; d.pc = hd.pc; d.policy_len = hd.policy_len; d.zero_tail = hd.zero_tail; d.extra = hd.extra;
             d.sh_w1t = hd.sh_w1t; d.p_b1 = hd.p_b1; d.pe_bc = hd.pe_bc; d.pe_wl = hd.pe_wl; d.pe_bl = hd.pe_bl;
             d.small_w = reinterpret_cast<const f32x4 *>(hd.small_w);
+            d.small_w16 = reinterpret_cast<const uint4 *>(hd.small_w);  // (one pointer: f32 fragments for the split launch, f16 for the plain one)
             if (split) {
                 if (t.channels == 256) launch<256, 4, true, 2>(d, grid, stream);
                 else if (nt == 4) launch<128, 4, true, 2>(d, grid, stream);
@@ -1529,6 +1603,9 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
                 if (t.channels == 256) launch<256, 4, false, 2>(d, grid, stream);
                 else if (nt == 4) launch<128, 4, false, 2>(d, grid, stream);
                 else if (nt == 7) launch<128, 7, false, 2>(d, grid, stream);
+                else if (nt == 8) launch<128, 8, false, 2>(d, grid, stream);
+                else if (nt == 11) launch<128, 11, false, 2>(d, grid, stream);
+                else if (nt == 13) launch<128, 13, false, 2>(d, grid, stream);
                 else launch<128, 6, false, 2>(d, grid, stream);
             }
             return;

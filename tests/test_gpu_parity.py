@@ -966,9 +966,9 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     ("chess", 2, 128, "attention", (3, 40), 64),              # 128 channels on an 8x8 board: one board per workgroup ...
     ("chess", 2, 128, "attention", (1, 3, 40, 256), 256),     # ... two (eight tiles) when that still makes 128 workgroups
     ("go-9", 2, 128, "conv", (3, 11), 64),                    # 81 pixels: six tiles, heads in the launch
-    ("go-9", 2, 128, "conv", (1, 2, 3, 11, 256), 256),        # two 9x9 boards in eleven tiles, separate heads
-    ("ataxx-7", 12, 128, "ataxx_conv", (1, 3, 4, 5, 9, 512), 512),  # four 7x7 boards in thirteen tiles (deep towers only)
-    ("ataxx-5", 12, 128, "ataxx_conv", (1, 7, 8, 9, 17, 1024), 1024),  # eight 5x5 boards in thirteen tiles
+    ("go-9", 2, 128, "conv", (1, 2, 3, 11, 256), 256),        # two 9x9 boards in eleven tiles
+    ("ataxx-7", 2, 128, "ataxx_conv", (1, 3, 4, 5, 9, 512), 512),  # four 7x7 boards in thirteen tiles
+    ("ataxx-5", 2, 128, "ataxx_conv", (1, 7, 8, 9, 17, 1024), 1024),  # eight 5x5 boards in thirteen tiles
     ("go-9", 2, 256, "conv", (5, 64), 256),                   # 256 channels on 81 squares: six tiles, one board per workgroup
     ("ataxx-7", 4, 64, "ataxx_conv", (7, 256), 256),          # BASELINE configs[0]'s network (64 channels)
     ("go-19", 2, 128, "conv", (2,), 256),                     # 361 squares: not a shape of the launch
@@ -990,8 +990,9 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
         per = wide_boards or {"chess": 1, "go-9": 1, "ataxx-7": 2}[game]
         assert eng.launch_geometry(max_batch) == ((max_batch + per - 1) // per, per)
     # conv-policy networks at 128 channels (256 on <= 64 squares) carry their heads in the launch since round 3: the tail of
-    # the exact-f32 launch on f32 copies of the f16 images (not with the wide tiles: the f32 images do not fit)
-    fused = head in ("ataxx_conv", "conv") and channels == 128 and not wide_boards
+    # the exact-f32 launch with its two small convolutions as f16 MFMAs on the f16 images (round 4; any number of tiles)
+    # (at most four boards per workgroup in the tail: eight 5x5 boards run their heads as separate launches)
+    fused = head in ("ataxx_conv", "conv") and channels == 128 and (wide_boards or 1) <= 4
     assert eng.tower_path == ("tower_resident_f16g+heads" if fused else "tower_resident_f16g")
     tower_only = eng
     if fused:
