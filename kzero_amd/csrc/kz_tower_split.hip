@@ -1134,8 +1134,11 @@ int split_tiles_for(int hw, int channels, bool split) {
     // (the plain-f16 launch has half the LDS footprint: 256 / 320 channels fit up to 96 squares — Go 9x9)
     if (channels == 256 || channels == 320) return channels == 320 && split ? 0 : hw <= 64 ? 4 : (!split && hw <= 96) ? 6 : 0;
     if (channels == 384 || channels == 512) return !split && hw <= 64 ? 4 : 0;
-    if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
+    if (channels == 192) return split ? (hw <= 64 ? 4 : 0) : hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : hw <= 176 ? 11 : 0;
     // (twice the boards per workgroup at 128 channels in plain f16: split_wide_tiles_for)
+    // (128 channels in plain f16: the eleven- and thirteen-tile instances of the wide tiles also take ONE board of up to 208
+    // squares — Go 13x13 — where the per-layer kernel was the only f16 path)
+    if (channels == 128 && !split && hw > 96) return hw <= 176 ? 11 : hw <= 208 ? 13 : 0;
     if (channels == 128 || channels == 64) return hw * 2 <= 112 ? 7 : hw <= 64 ? 4 : hw <= 96 ? 6 : 0;
     return 0;
 }
@@ -1639,6 +1642,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else if (t.channels == 256) launch<256, 4, false>(d, grid, stream);
         else if (t.channels == 192 && nt == 4) launch<192, 4, false>(d, grid, stream);
         else if (t.channels == 192 && nt == 7) launch<192, 7, false>(d, grid, stream);
+        else if (t.channels == 192 && nt == 11) launch<192, 11, false>(d, grid, stream);
         else if (t.channels == 192) launch<192, 6, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 4) launch<128, 4, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 7) launch<128, 7, false>(d, grid, stream);
