@@ -13,7 +13,7 @@
 //!    tanh(value), softmax(wdl) and the per-move probabilities — 0.2 KB instead of 7.5 KB per chess evaluation over
 //!    PCIe and no softmax on this thread.  Measured with the C++ mirror of this file (tests/cpp/bench_executor.cpp,
 //!    chess 20x256 f16, ONE executor thread, move generation + a SipHash lookup per move on it): host decode
-//!    257-323k evals/s box to box (the thread is the bottleneck: 3.2-3.9 CPU-s per million evaluations), device decode
+//!    257-350k evals/s box to box (the thread is the bottleneck: 3.2-3.9 CPU-s per million evaluations), device decode
 //!    404-505k with the thread working 0.8-0.9 of a core, the GPU alone 482-527k.  `KZ_HIP_DECODE=host` keeps the reference's own `decode_output` call (bit-identical softmax; set
 //!    gpu_threads_per_device >= 4 with it for a 256-channel chess network in f16).
 //!
