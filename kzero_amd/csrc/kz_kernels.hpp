@@ -172,7 +172,8 @@ struct Tower32Args {
     size_t bits_stride = 0;
     const float *scalars_in = nullptr;
     int n_scalar = 0, n_bool = 0;
-    bool wide = false;    // launch_tower_pairs: twice the boards per workgroup (tower_split_wide_supported)
+    bool wide = false;    // launch_tower_pairs: twice the boards per workgroup (tower_split_wide_supported) — the engine's
+                          // choice at max_batch; a launch whose own batch is too small for it takes the narrow tiles
     bool dense3 = false;  // launch_tower32, experiment build: three 7x7 boards per workgroup (tower32_dense3_supported)
     // launch_tower32 only: the conv policy head (Conv1x1 C->C + ReLU in the weight stream as one more centre-tap layer,
     // then Conv1x1 C->pc, post_act.py:75-110) and the scalar head (post_act.py:8-31) in the same launch — the tower

@@ -1581,7 +1581,10 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     d.w_ = t.w;
     d.hw = t.h * t.w;
     d.stem_chunks = (t.c_in + 31) / 32;
-    const int nt = !split && t.wide ? split_wide_tiles_for(d.hw, t.channels) : split_tiles_for(d.hw, t.channels, split);
+    // (an engine that takes the wide tiles still launches the narrow ones for a batch too small to fill 128 wide workgroups:
+    // the same weight stream, twice the workgroups, half the time per workgroup)
+    const bool wide = !split && t.wide && tower_split_wide_supported(t.h, t.w, t.channels, t.batch);
+    const int nt = wide ? split_wide_tiles_for(d.hw, t.channels) : split_tiles_for(d.hw, t.channels, split);
     d.nb = nt * 16 / d.hw;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;

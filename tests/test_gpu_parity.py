@@ -989,6 +989,9 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
     if channels == 128:
         per = wide_boards or {"chess": 1, "go-9": 1, "ataxx-7": 2}[game]
         assert eng.launch_geometry(max_batch) == ((max_batch + per - 1) // per, per)
+        if wide_boards:  # a batch too small for 128 wide workgroups is launched with the narrow tiles (same weights)
+            narrow = {"chess": 1, "go-9": 1, "ataxx-7": 2, "ataxx-5": 4}[game]
+            assert eng.launch_geometry(9) == ((9 + narrow - 1) // narrow, narrow)
     # conv-policy networks at 128 channels (256 on <= 64 squares) carry their heads in the launch since round 3: the tail of
     # the exact-f32 launch with its two small convolutions as f16 MFMAs on the f16 images (round 4; any number of tiles)
     # (at most four boards per workgroup in the tail: eight 5x5 boards run their heads as separate launches)
