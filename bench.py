@@ -53,6 +53,11 @@ WORKLOADS = {
     "go9-16x128": dict(game="go-9", depth=16, channels=128, head="conv", batch=2048, steps=1000,
                        engines={"f16": 2, "f32": 2, "f32split16": 2},
                        label="Go 9x9 16x128 ResNet b=2048 (loop_main_alpha.py)"),
+    # diagnostic workloads (tools/pmc_workload.sh): chess towers off the flagship width; not part of the default line
+    "chess-20x192": dict(game="chess", depth=20, channels=192, head="attention", batch=256, steps=2000,
+                         engines={"f16": 3, "f32": 2, "f32split16": 2}, label="Chess 20x192 ResNet b=256"),
+    "chess-20x384": dict(game="chess", depth=20, channels=384, head="attention", batch=256, steps=1000,
+                         engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x384 ResNet b=256"),
 }
 # the other single-GPU BASELINE configs, reported as sub-records of the default line
 OTHERS = [("ataxx-8x128", "f32"), ("ataxx-8x128", "f32split16"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"),

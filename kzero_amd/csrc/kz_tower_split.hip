@@ -1143,7 +1143,7 @@ int split_tiles_for(int hw, int channels, bool split) {
     return 0;
 }
 
-// Twice the boards per workgroup for the plain-f16 launch at 128 channels: two 8x8 boards in 8 tiles, two 9x9 boards in 11
+// Twice the boards per workgroup for the plain-f16 launch at 128 (and 192) channels: two 8x8 boards in 8 tiles, two 9x9 boards in 11
 // (162 of 176 rows are boards; one board in six tiles: 81 of 96), four 7x7 or eight 5x5 boards in 13.  The weight stream
 // is read once per workgroup, so this halves the bytes a workgroup pulls from L2 per board.  While these launches waited
 // for their weights (four ring stages, rounds 1-3) that was measured SLOWER (half as many workgroups); since the deeper
@@ -1153,6 +1153,10 @@ int split_tiles_for(int hw, int channels, bool split) {
 // batch 256: 64 workgroups, 2.02M -> 1.69M), and not at 64 channels (latency-bound: 4.44M -> 3.97M at batch 256) or 192
 // (no difference).  No fused conv heads at these sizes (the tail's f32 row images do not fit the LDS).
 int split_wide_tiles_for(int hw, int channels) {
+    // (192 channels: measured late in round 4, chess x 192 at batch 256 / 1024 711k -> 805k / 653k -> 807k evals/s with two boards
+    // — its counters read 0.52 busy at 2.06 GHz with one board: neither the matrix cores' limit nor a full clock; three 7x7
+    // boards in ten tiles there, four do not fit the LDS)
+    if (channels == 192) return hw == 64 ? 8 : hw == 81 ? 11 : hw == 49 ? 10 : 0;
     if (channels != 128) return 0;
     return hw == 64 ? 8 : hw == 81 ? 11 : (hw == 49 || hw == 25) ? 13 : 0;
 }
@@ -1646,6 +1650,8 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else if (t.channels == 192 && nt == 4) launch<192, 4, false>(d, grid, stream);
         else if (t.channels == 192 && nt == 7) launch<192, 7, false>(d, grid, stream);
         else if (t.channels == 192 && nt == 11) launch<192, 11, false>(d, grid, stream);
+        else if (t.channels == 192 && nt == 8) launch<192, 8, false>(d, grid, stream);
+        else if (t.channels == 192 && nt == 10) launch<192, 10, false>(d, grid, stream);
         else if (t.channels == 192) launch<192, 6, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 4) launch<128, 4, false>(d, grid, stream);
         else if (t.channels == 128 && nt == 7) launch<128, 7, false>(d, grid, stream);

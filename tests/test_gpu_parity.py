@@ -969,6 +969,9 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     ("go-9", 2, 128, "conv", (1, 2, 3, 11, 256), 256),        # two 9x9 boards in eleven tiles
     ("ataxx-7", 2, 128, "ataxx_conv", (1, 3, 4, 5, 9, 512), 512),  # four 7x7 boards in thirteen tiles
     ("ataxx-5", 2, 128, "ataxx_conv", (1, 7, 8, 9, 17, 1024), 1024),  # eight 5x5 boards in thirteen tiles
+    ("chess", 2, 192, "attention", (1, 3, 40, 256), 256),     # 192 channels: two 8x8 boards per workgroup as well
+    ("go-9", 2, 192, "conv", (1, 2, 3, 256), 256),            # ... two 9x9 boards in eleven tiles
+    ("ataxx-7", 2, 192, "ataxx_conv", (1, 4, 5, 384), 384),   # ... three 7x7 boards in ten tiles
     ("go-9", 2, 256, "conv", (5, 64), 256),                   # 256 channels on 81 squares: six tiles, one board per workgroup
     ("ataxx-7", 4, 64, "ataxx_conv", (7, 256), 256),          # BASELINE configs[0]'s network (64 channels)
     ("go-19", 2, 128, "conv", (2,), 256),                     # 361 squares: not a shape of the launch
@@ -985,12 +988,13 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
         assert not eng.tower_path.startswith("tower_resident_f16g")
         return
     # at 128 channels an engine whose max_batch still gives 128 workgroups takes twice the boards per workgroup (round 4)
-    wide_boards = {("chess", 256): 2, ("go-9", 256): 2, ("ataxx-7", 512): 4, ("ataxx-5", 1024): 8}.get((game, max_batch)) if channels == 128 else None
-    if channels == 128:
-        per = wide_boards or {"chess": 1, "go-9": 1, "ataxx-7": 2}[game]
+    wide_boards = {("chess", 128, 256): 2, ("go-9", 128, 256): 2, ("ataxx-7", 128, 512): 4, ("ataxx-5", 128, 1024): 8,
+                   ("chess", 192, 256): 2, ("go-9", 192, 256): 2, ("ataxx-7", 192, 384): 3}.get((game, channels, max_batch))
+    if channels in (128, 192):
+        narrow = {"chess": 1, "go-9": 1, "ataxx-7": 2, "ataxx-5": 4}[game]
+        per = wide_boards or narrow
         assert eng.launch_geometry(max_batch) == ((max_batch + per - 1) // per, per)
         if wide_boards:  # a batch too small for 128 wide workgroups is launched with the narrow tiles (same weights)
-            narrow = {"chess": 1, "go-9": 1, "ataxx-7": 2, "ataxx-5": 4}[game]
             assert eng.launch_geometry(9) == ((9 + narrow - 1) // narrow, narrow)
     # conv-policy networks at 128 channels (256 on <= 64 squares) carry their heads in the launch since round 3: the tail of
     # the exact-f32 launch with its two small convolutions as f16 MFMAs on the f16 images (round 4; any number of tiles)
