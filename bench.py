@@ -58,6 +58,16 @@ WORKLOADS = {
                          engines={"f16": 3, "f32": 2, "f32split16": 2}, label="Chess 20x192 ResNet b=256"),
     "chess-20x384": dict(game="chess", depth=20, channels=384, head="attention", batch=256, steps=1000,
                          engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x384 ResNet b=256"),
+    "chess-20x64": dict(game="chess", depth=20, channels=64, head="attention", batch=256, steps=4000,
+                        engines={"f16": 3, "f32": 2, "f32split16": 3}, label="Chess 20x64 ResNet b=256"),
+    "chess-20x320": dict(game="chess", depth=20, channels=320, head="attention", batch=256, steps=1000,
+                         engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x320 ResNet b=256"),
+    "chess-20x512": dict(game="chess", depth=20, channels=512, head="attention", batch=256, steps=500,
+                         engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x512 ResNet b=256"),
+    "go9-20x256": dict(game="go-9", depth=20, channels=256, head="conv", batch=256, steps=1000,
+                       engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Go 9x9 20x256 ResNet b=256"),
+    "go13-20x128": dict(game="go-13", depth=20, channels=128, head="conv", batch=256, steps=1000,
+                        engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Go 13x13 20x128 ResNet b=256"),
 }
 # the other single-GPU BASELINE configs, reported as sub-records of the default line
 OTHERS = [("ataxx-8x128", "f32"), ("ataxx-8x128", "f32split16"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"),
