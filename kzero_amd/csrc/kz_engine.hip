@@ -90,17 +90,29 @@ namespace {
 // multiply-adds and buy the one-launch and board-tile kernels instead of the generic implicit GEMM (chess x 96 channels,
 // f16: 0.53M -> 1.0M evals/s; x 160: 0.24M -> 0.6M).  Exact f32 keeps its implicit GEMM (the f32 one-launch tower exists
 // for 128 / 256 channels only and the f32 matrix rate makes the zero work expensive).
-std::shared_ptr<Model> effective_model(const kz_model *model, int dtype_in) {
+std::shared_ptr<Model> effective_model(const kz_model *model, int dtype_in, int max_batch) {
     const Model &m = *model->m;
     if (dtype_in == KZ_DTYPE_F32 || m.channels % 64 == 0 || m.channels > 512 || m.depth < 1 || env_on("KZ_FORCE_GENERIC") ||
         env_on("KZ_KEEP_ACTIVATIONS"))
         return model->m;
-    std::lock_guard<std::mutex> lock(model->widened_mutex);
-    if (!model->widened_tried) {
-        model->widened_tried = true;
-        model->widened.reset(kz::pad_channels(m, round_up(m.channels, 64)));
+    std::shared_ptr<Model> wide;
+    {
+        std::lock_guard<std::mutex> lock(model->widened_mutex);
+        if (!model->widened_tried) {
+            model->widened_tried = true;
+            model->widened.reset(kz::pad_channels(m, round_up(m.channels, 64)));
+        }
+        wide = model->widened;
     }
-    return model->widened ? model->widened : model->m;
+    if (!wide) return model->m;
+    // The zero filters only pay when they buy another kernel: a widened tower that still takes the generic implicit GEMM
+    // (Go 19x19 x 96 channels at max_batch 8: too few workgroups for the board-tile kernel) would run (Cpad / C)^2 of the
+    // multiply-adds through the same kernel.  Keep the network as it is then — unless it is refused as it is (split16).
+    PathPlan pw, po;
+    std::string why;
+    if (!plan_path(*wide, max_batch, dtype_in, pw, why)) return model->m;
+    if (pw.path.compare(0, 10, "conv_igemm") == 0 && plan_path(m, max_batch, dtype_in, po, why)) return model->m;
+    return wide;
 }
 }  // namespace
 
@@ -743,7 +755,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     HIP_TRY(hipSetDevice(device));
 
     std::unique_ptr<kz_engine, void (*)(kz_engine *)> e(new kz_engine(), kz_engine_destroy);
-    e->model = effective_model(model, split16 ? KZ_DTYPE_F32_SPLIT16 : dtype);
+    e->model = effective_model(model, split16 ? KZ_DTYPE_F32_SPLIT16 : dtype, max_batch);
     e->out_channels = model->m->channels;
     const Model &m = *e->model;
     e->device = device;
@@ -890,7 +902,7 @@ KZ_API int kz_model_supports_dtype(const kz_model *model, int dtype) {
     // < 2 GiB, asked here for one board)
     PathPlan plan;
     std::string why;
-    return plan_path(*effective_model(model, dtype), 1, dtype, plan, why) ? 1 : 0;
+    return plan_path(*effective_model(model, dtype, 1), 1, dtype, plan, why) ? 1 : 0;
 }
 
 KZ_API int kz_model_plan(const kz_model *model, int max_batch, int dtype, kz_path_plan *out) {
@@ -899,7 +911,7 @@ KZ_API int kz_model_plan(const kz_model *model, int max_batch, int dtype, kz_pat
     if (dtype != KZ_DTYPE_F32 && dtype != KZ_DTYPE_F16 && dtype != KZ_DTYPE_F32_SPLIT16) return fail("kz_model_plan: unknown dtype");
     PathPlan plan;
     std::string why;
-    if (!plan_path(*effective_model(model, dtype), max_batch, dtype, plan, why)) return fail("kz_model_plan: " + why);
+    if (!plan_path(*effective_model(model, dtype, max_batch), max_batch, dtype, plan, why)) return fail("kz_model_plan: " + why);
     memset(out, 0, sizeof *out);
     snprintf(out->tower_path, sizeof out->tower_path, "%s", plan.path.c_str());
     out->launches_per_batch = plan.launches;

@@ -116,6 +116,17 @@ void launch_decode_output(const float *scalars, const float *logits, int batch, 
                           const int64_t *move_offsets, const int32_t *move_indices, float *values, float *probs,
                           int *error_flag, const int *nonfinite_flag, int epoch, hipStream_t stream);
 
+// The same decode as the LAST STEP OF A LAUNCH that has the heads inside (kz_decode_dev.hpp): with move_offsets set, a
+// "...+heads" launch writes values [batch][5] and probs (parallel to move_indices) instead of the raw scalars and logits —
+// no decode launch, and all five pointers may be the slot's pinned host staging (every word read or written once).
+// error_flag: set to 1 where kz_decode_output raises bit 0; the range check keeps its own flag (ScalarHeadArgs).
+struct DecodeArgs {
+    const int64_t *move_offsets = nullptr;  // [batch + 1] CSR; nullptr: no decode
+    const int32_t *move_indices = nullptr;
+    float *values = nullptr, *probs = nullptr;
+    int *error_flag = nullptr;
+};
+
 // ---- per-layer 3x3 convolution with the board as an LDS-resident spatial tile (kz_board_conv.hip): f16, cin and cout
 // multiples of 64, h*w <= 384.  Same epilogue contract as ConvArgs. ----
 struct BoardConvArgs {
@@ -194,6 +205,8 @@ struct Tower32Args {
         float *scalars = nullptr, *policy = nullptr;  // [batch][5], [batch][policy_len]
         int *nonfinite_flag = nullptr;                // range check, see ScalarHeadArgs
         int epoch = 0;
+        DecodeArgs decode;  // set: decode_output inside the launch (the conv policy heads still write `policy`, which
+                            // must then be device memory: the decode gathers from it)
     } heads;
 };
 bool tower32_supported(int dtype, int h, int w, int channels, int depth);
@@ -297,6 +310,7 @@ struct TowerArgs {
     float *scalars, *policy;
     int *nonfinite_flag;  // fused heads only: see ScalarHeadArgs
     int epoch;
+    DecodeArgs decode;    // fused heads only; set: decode_output inside the launch, scalars / policy are not written
 };
 bool tower_resident_supported(int dtype, int h, int w, int channels, int depth, int c_in);
 int tower_resident_boards_per_workgroup();  // 2 (1 with KZ_TOWER_NB=1)

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <set>
@@ -446,9 +447,14 @@ struct Normalizer {
                 }
             } else if (n.op == "Slice") {
                 std::vector<int64_t> starts, ends, axes, steps;
-                const bool have = param_ints(n, "starts", 1, starts) && param_ints(n, "ends", 2, ends);
+                bool have = param_ints(n, "starts", 1, starts) && param_ints(n, "ends", 2, ends);
                 const bool have_axes = param_ints(n, "axes", 3, axes);
                 param_ints(n, "steps", 4, steps);
+                // a file controls these lengths: a node whose parameter vectors disagree is left unfolded (the matcher then
+                // rejects the graph with a message) instead of being indexed
+                if (have && (starts.empty() || ends.size() != starts.size() || (have_axes && axes.size() != starts.size()) ||
+                             (!steps.empty() && steps.size() != starts.size())))
+                    have = false;
                 if (have && get_ints(n.in[0], v)) {  // a slice of an integer tensor (1-D)
                     if (starts.size() == 1 && (!have_axes || (axes.size() == 1 && axes[0] == 0)) && (steps.empty() || steps[0] == 1)) {
                         const int64_t len = (int64_t)v.size();
@@ -627,7 +633,7 @@ struct Normalizer {
                 }
                 if (n->op == "Slice" && !selected) {
                     std::vector<int64_t> starts, ends, axes, steps;
-                    if (!param_ints(*n, "starts", 1, starts) || !param_ints(*n, "ends", 2, ends) || starts.size() != 1) break;
+                    if (!param_ints(*n, "starts", 1, starts) || !param_ints(*n, "ends", 2, ends) || starts.size() != 1 || ends.size() != 1) break;
                     if (param_ints(*n, "axes", 3, axes) && (axes.size() != 1 || axes[0] != 1)) break;
                     if (param_ints(*n, "steps", 4, steps) && (steps.size() != 1 || steps[0] != 1)) break;
                     if (axes.empty()) break;  // (without axes a one-element slice would cut the batch axis)
@@ -1050,6 +1056,9 @@ Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err) 
         return m.release();
     } catch (const Fail &f) {
         err = f.msg;
+        return nullptr;
+    } catch (const std::exception &e) {  // (length_error / bad_alloc from a file-controlled size must not cross the C ABI)
+        err = std::string("ONNX: ") + e.what();
         return nullptr;
     }
 }

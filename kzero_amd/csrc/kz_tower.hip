@@ -37,6 +37,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#include "kz_decode_dev.hpp"  // DecodeDev, decode_board_wave: decode_output as the last step of the launch
+
 constexpr int C = 256;          // tower channels (= attention query channels in the fused-heads variant)
 constexpr int RS = C * 2 + 16;  // LDS bytes per pixel row: 512 B of channels + 16 B pad, so that the 16 rows of a
                                 // fragment read fall on 16 different 16-byte slots of the 256-byte bank row
@@ -62,6 +64,7 @@ struct TowerDev {
     float *scalars, *policy;
     int *nonfinite_flag;  // range check (fused heads), see ScalarHeadArgs in kz_kernels.hpp
     int epoch;
+    DecodeDev dec;        // dec.move_offsets set: values / probabilities of the available moves instead of scalars / policy
 };
 
 template <int NB>
@@ -557,20 +560,35 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident(TowerDev a) {
                 }
         }
         // ---- H7: ScalarHead Linear(32 -> 5) (post_act.py:19)
+        const bool decode = a.dec.move_offsets != nullptr;
+        float *raw = reinterpret_cast<float *>(lds + L::ACT_OFF);  // (act is dead since H5: the decode's five scalars per board)
         if (tid < NB * 5) {
             const int b = tid / 5, k = tid % 5;
             const float *hid = reinterpret_cast<const float *>(lds + L::HID_OFF) + b * 32;
             float s = a.sh_b2[k];
             for (int i = 0; i < 32; i++) s += a.sh_w2[k * 32 + i] * hid[i];
-            if (board0 + b < a.batch) a.scalars[(size_t)(board0 + b) * 5 + k] = s;
+            if (decode) raw[b * 8 + k] = s;
+            else if (board0 + b < a.batch) a.scalars[(size_t)(board0 + b) * 5 + k] = s;
         }
         __syncthreads();
-        // ---- H8: policy.flatten(1)[:, FLAT_TO_ATT] (post_act.py:140): coalesced 1880-float rows
-        for (int b = 0; b < NB; b++) {
-            if (board0 + b >= a.batch) break;
-            const float *lg = reinterpret_cast<const float *>(lds + L::LOG_OFF) + b * 64 * LOGIT_LD;
-            float *pol = a.policy + (size_t)(board0 + b) * POLICY;
-            for (int k = tid; k < POLICY; k += 256) pol[k] = lg[a.att_idx[k]];
+        if (decode) {
+            // ---- H8': decode_output (common.rs:16-100) on the LDS-resident logits: wave b decodes board b.  The gather
+            // policy.flatten(1)[:, FLAT_TO_ATT] (post_act.py:140) happens per available move; q_to's image (X) is dead and
+            // holds the wave's staging
+            if (wave < NB && board0 + wave < a.batch) {
+                const float *lg = reinterpret_cast<const float *>(lds + L::LOG_OFF) + wave * 64 * LOGIT_LD;
+                float *stage = reinterpret_cast<float *>(lds + L::X_OFF + L::row_off(wave, 0));
+                decode_board_wave(a.dec, board0 + wave, lane, raw + wave * 8, stage, 64 * RS / 4,
+                                  [&](int idx) { return lg[a.att_idx[idx]]; });
+            }
+        } else {
+            // ---- H8: policy.flatten(1)[:, FLAT_TO_ATT] (post_act.py:140): coalesced 1880-float rows
+            for (int b = 0; b < NB; b++) {
+                if (board0 + b >= a.batch) break;
+                const float *lg = reinterpret_cast<const float *>(lds + L::LOG_OFF) + b * 64 * LOGIT_LD;
+                float *pol = a.policy + (size_t)(board0 + b) * POLICY;
+                for (int k = tid; k < POLICY; k += 256) pol[k] = lg[a.att_idx[k]];
+            }
         }
     }
 }
@@ -695,6 +713,8 @@ void launch_tower_resident(const TowerArgs &t, hipStream_t stream) {
     d.policy = t.policy;
     d.nonfinite_flag = t.nonfinite_flag;
     d.epoch = t.epoch;
+    d.dec = DecodeDev{t.fused_heads ? t.decode.move_offsets : nullptr, t.decode.move_indices, t.decode.values, t.decode.probs,
+                      t.decode.error_flag, POLICY};
     const bool heads = t.fused_heads;
     // (the dynamic-LDS attribute is per device: set it on every launch's current device, it is a cheap host call,
     //  but only once per kernel and device)

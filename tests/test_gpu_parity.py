@@ -424,6 +424,94 @@ def test_config_c1_f16_against_the_f32_accurate_launch_on_the_whole_batch(dev, c
     assert sm < 1e-3
 
 
+# what the Rust shim runs by default (KZ_HIP_DECODE=device, kzero_amd/rust/hip.rs): legal-move probabilities, f16
+# F16_PROB_ATOL: |delta p| of a softmax over 20-60 legal moves whose logits differ by <= F16_REL * scale (measured 6e-4)
+F16_PROB_ATOL = 2e-3
+F16_VALUE_ATOL = 5e-3
+
+
+def _c1_move_lists(policy_len, batch, seed, finished=()):
+    """Per-board legal-move lists of the size chess positions have (20-60 moves, distinct indices, available_moves()
+    order = arbitrary order); `finished` boards have none (common.rs:77 `map_or(vec![], ..)`)."""
+    rng = np.random.default_rng(seed)
+    lists = [rng.permutation(policy_len)[:int(n)].astype(np.int32) for n in rng.integers(20, 61, size=batch)]
+    for b in finished:
+        lists[b] = np.zeros(0, np.int32)
+    return lists
+
+
+@pytest.mark.parametrize("dtype", [capi.KZ_DTYPE_F16, capi.KZ_DTYPE_F32_SPLIT16], ids=["f16", "split16"])
+def test_config_c1_default_shim_entry_decoded_on_all_slots(dev, chess_full, chess_full_oracle, dtype):
+    """The entry points `HipNetwork` uses by default — kz_engine_submit_packed_decoded on all four slots, then
+    kz_engine_wait_decoded — on the flagship launches at BASELINE configs[2]'s size (chess 20x256, 256 boards, 20-60
+    legal moves per board, one finished game per batch), against
+      (a) the oracle's decode_output (common.rs:16-100) of the ORACLE's logits on all 256 boards, and
+      (b) this library's eval_packed + the oracle's decode_output on the host, on all 256 boards;
+    plus an out-of-range move index (the reference would panic on the slice index; here the wait fails) and a batch
+    that does not fill the last workgroup."""
+    blob, bits, scalars_in = chess_full
+    s_ora, p_ora = chess_full_oracle
+    net = O.OracleNet(blob)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 256, dtype)
+    assert eng.tower_path == ("tower_resident_f16+heads" if dtype == capi.KZ_DTYPE_F16 else "tower_resident_split16+heads")
+    s_own, p_own = eng.eval_packed(bits, scalars_in)
+    # four different batches in flight: slot k evaluates the boards rolled by 64 k with its own move lists
+    slots = []
+    for k in range(capi.KZ_ENGINE_SLOTS):
+        order = np.roll(np.arange(256), -64 * k)
+        moves = _c1_move_lists(net.policy_len, 256, seed=100 + k, finished=(17 + k,))
+        slots.append((order, moves, eng.submit_packed_decoded(k, bits[order], scalars_in[order], moves)))
+    worst_p = worst_v = worst_own = 0.0
+    for k in (2, 0, 3, 1):  # (any order of waits)
+        order, moves, off = slots[k]
+        v, probs = eng.wait_decoded(k, off)
+        v_ora, probs_ora = O.decode_output(s_ora[order], p_ora[order], moves)
+        v_own, probs_own = O.decode_output(s_own[order], p_own[order], moves)
+        assert probs[17 + k].size == 0
+        for b in range(256):
+            assert probs[b].shape == moves[b].shape
+            if moves[b].size:
+                assert abs(float(probs[b].sum()) - 1.0) < 1e-5
+                worst_p = max(worst_p, float(np.abs(probs[b] - probs_ora[b]).max()))
+                worst_own = max(worst_own, float(np.abs(probs[b] - probs_own[b]).max()))
+        worst_v = max(worst_v, float(np.abs(v[:, :4] - v_ora[:, :4]).max()))
+        # moves_left is a raw network output (common.rs:61): the logit tolerance applies
+        if dtype == capi.KZ_DTYPE_F16:
+            assert_f16(v[:, 4:], v_ora[:, 4:], f"slot {k} moves_left")
+        else:
+            assert_f32(v[:, 4:], v_ora[:, 4:], f"slot {k} moves_left")
+        worst_own = max(worst_own, float(np.abs(v - v_own).max()))
+    print(f"[decoded {eng.tower_path}] vs oracle: max |dprob| {worst_p:.2e}, max |dvalue, dwdl| {worst_v:.2e}; "
+          f"vs own logits decoded on the host: {worst_own:.2e}")
+    if dtype == capi.KZ_DTYPE_F16:
+        assert worst_p <= F16_PROB_ATOL and worst_v <= F16_VALUE_ATOL
+    else:
+        assert worst_p <= F32_ATOL and worst_v <= F32_ATOL
+    assert worst_own <= 2e-6  # same logits, expf / tanhf on the device against the host's
+    # a ragged batch: 37 boards (the last workgroup holds one board), every board its own list
+    moves = _c1_move_lists(net.policy_len, 37, seed=7)
+    v, probs = eng.wait_decoded(1, eng.submit_packed_decoded(1, bits[:37], scalars_in[:37], moves))
+    v_own, probs_own = O.decode_output(s_own[:37], p_own[:37], moves)
+    np.testing.assert_allclose(v, v_own, rtol=0, atol=2e-6)
+    for a, b in zip(probs, probs_own):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+    # an index outside the policy: the wait that returns the batch fails, the slot and the engine stay usable
+    bad = [m.copy() for m in moves]
+    bad[20][3] = net.policy_len
+    off = eng.submit_packed_decoded(2, bits[:37], scalars_in[:37], bad)
+    with pytest.raises(capi.KzError, match="strictly positive"):
+        eng.wait_decoded(2, off)
+    bad[20][3] = -1
+    off = eng.submit_packed_decoded(2, bits[:37], scalars_in[:37], bad)
+    with pytest.raises(capi.KzError, match="strictly positive"):
+        eng.wait_decoded(2, off)
+    v2, probs2 = eng.wait_decoded(2, eng.submit_packed_decoded(2, bits[:37], scalars_in[:37], moves))
+    assert np.array_equal(v2, v) and all(np.array_equal(a, b) for a, b in zip(probs2, probs))
+    # the undecoded entry points still serve the same engine
+    s3, p3 = eng.wait_view(3, eng.submit_packed(3, bits, scalars_in))
+    assert np.array_equal(s3, s_own) and np.array_equal(p3, p_own)
+
+
 G8_PICK = np.arange(0, 512, 32)  # 16 boards spread over the batch (rounds 2-3: 8)
 
 

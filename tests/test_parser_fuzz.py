@@ -32,3 +32,57 @@ def test_parsers_survive_mutated_files():
                              env={**os.environ, "UBSAN_OPTIONS": "print_stacktrace=1"})
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
         assert "parser fuzz ok" in out.stdout
+
+
+def _fuzz_exe():
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "fuzz_parsers")
+    srcs = [os.path.join(REPO, "tests", "cpp", "fuzz_parsers.cpp"), os.path.join(CSRC, "kz_model.cpp"),
+            os.path.join(CSRC, "kz_onnx.cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=undefined"] + srcs + ["-o", exe])
+    return exe
+
+
+@pytest.mark.timeout(600)
+def test_slice_nodes_with_mismatched_parameter_lengths(tmp_path):
+    """Slice parameter vectors whose lengths disagree (round-4 advisor finding: `ends[0]` of an empty vector, `axes[k]`
+    beyond a one-element vector) must be rejected or left unfolded — never indexed.  Crafted from the golden graphs; the
+    byte-level mutation fuzz above does not produce them."""
+    import sys
+    sys.path.insert(0, REPO)
+    from oracle import onnx_wire as W
+
+    def rewrite(src, pick, attrs, keep_inputs=1):
+        m = W.Model(open(os.path.join(GOLDEN, src), "rb").read())
+        slices = [n for n in m.nodes if n.op == "Slice"]
+        n = slices[pick]
+        n.inputs = n.inputs[:keep_inputs]
+        n.attrs = [W.attr_ints(k, v) for k, v in attrs.items()]
+        return m.serialize()
+
+    v9 = os.path.join("onnx_variants", "chess_2x32_att.opset9.onnx")
+    crafted = {
+        # a slice of an integer tensor (the Shape output) with one start and no end
+        "int_empty_ends": rewrite(v9, 1, {"starts": [0], "ends": [], "axes": [0]}),
+        # a slice of a graph tensor with nine starts, one end, one axis
+        "short_axes": rewrite(v9, 0, {"starts": list(range(9)), "ends": [1], "axes": [1]}),
+        "short_ends": rewrite(v9, 2, {"starts": [0, 0], "ends": [1], "axes": [1, 2]}),
+        "short_steps": rewrite(v9, 0, {"starts": [0, 0], "ends": [1, 1], "axes": [1, 2], "steps": [1]}),
+        "no_starts": rewrite(v9, 0, {"starts": [], "ends": [], "axes": []}),
+        # the legacy (value, wdl, policy) outputs: the row pick reads ends[0] after checking starts only
+        "legacy_empty_ends": rewrite(os.path.join("onnx_variants", "ataxx7_2x16.legacy3.onnx"), 0,
+                                     {"starts": [0], "ends": [], "axes": [1]}),
+        "legacy_two_ends": rewrite(os.path.join("onnx_variants", "go9_2x16_conv_terr.legacy3.onnx"), 0,
+                                   {"starts": [0], "ends": [1, 2], "axes": [1]}),
+    }
+    files = []
+    for name, blob in crafted.items():
+        p = tmp_path / f"{name}.onnx"
+        p.write_bytes(blob)
+        files.append(str(p))
+    out = subprocess.run([_fuzz_exe(), "40", "3"] + files, capture_output=True, text=True, timeout=400,
+                         env={**os.environ, "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "parser fuzz ok" in out.stdout
