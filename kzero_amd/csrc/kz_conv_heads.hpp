@@ -7,7 +7,7 @@
 // Device code only; included INSIDE `namespace kz { namespace {` of a .hip file, after f32x4 is defined.  `Dev` is the
 // launch's argument struct: it must have the members hc, hs, pc, policy_len, zero_tail, extra, epoch, hw, nb, inv_hw,
 // sh_b0, sh_w1t, sh_b1, sh_w2, sh_b2, p_b1, pe_bc, pe_wl, pe_bl, small_w (tower32_pack_small_weights), scalars, policy,
-// nonfinite_flag.
+// nonfinite_flag, dec (DecodeDev, kz_decode_dev.hpp — included before this file).
 #pragma once
 
 #ifndef KZ_HEADS_STAMP
@@ -31,9 +31,11 @@ __device__ __forceinline__ int plane_of(int kq) {  // byte offset of lane group 
 // the row operand), rows of this workgroup's boards only.  Two providers: conv_heads_f32 below (f32 row images, exact-f32
 // MFMAs: the exact-f32 and the split launches) and the plain-f16 launch's own (kz_tower_split.hip: f16 MFMAs straight on its
 // f16 images).
+// stage / stage_bytes: an LDS region that is dead once both small convolutions have run (the tower output's image), for
+// the in-launch decode_output's staging (a.dec.move_offsets set; 0 bytes: it re-reads instead).
 template <int C, int NT, typename Dev, typename SmallConv>
 __device__ __forceinline__ void conv_heads_tail(const Dev &a, unsigned char *lds, int scratch, int board0, int boards,
-                                                int rows_valid, SmallConv small_conv) {
+                                                int rows_valid, SmallConv small_conv, int stage = 0, int stage_bytes = 0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int kq = lane >> 4;
@@ -176,11 +178,28 @@ __device__ __forceinline__ void conv_heads_tail(const Dev &a, unsigned char *lds
     }
     __syncthreads();
     KZ_HEADS_STAMP(59);
+    const bool decode = a.dec.move_offsets != nullptr;
     if (tid < boards * 5) {
         const int bb = tid / 5, j = tid - bb * 5;
         float s = b2v;
         for (int i = 0; i < a.hs; i++) s += sw2[j * a.hs + i] * shid[bb * a.hs + i];
-        a.scalars[(size_t)(board0 + bb) * 5 + j] = s;
+        if (decode) sred[bb * 8 + j] = s;  // (sred is dead: the hidden layer has been reduced)
+        else a.scalars[(size_t)(board0 + bb) * 5 + j] = s;
+    }
+    if (decode) {
+        // decode_output (common.rs:16-100) as the launch's last step: the logits were written to a.policy (device memory) by
+        // this workgroup above; wave w gathers and normalises the available moves of boards w, w + 4, ...
+        __threadfence();
+        __syncthreads();
+        const int wv = tid >> 6, cap = stage_bytes / 16;  // floats per wave
+        float *st = reinterpret_cast<float *>(lds + stage) + wv * cap;
+        for (int bb = wv; bb < boards; bb += 4) {
+            const float *lg = a.policy + (size_t)(board0 + bb) * a.policy_len;
+            decode_board_wave(a.dec, board0 + bb, lane, sred + bb * 8, st, cap, [&](int idx) {
+                // (a coherent load: the line may sit in this CU's vector cache from before the stores above)
+                return __hip_atomic_load(lg + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+        }
     }
 }
 
@@ -238,5 +257,5 @@ __device__ __forceinline__ void conv_heads_f32(const Dev &a, unsigned char *lds,
             }
         }
     };
-    conv_heads_tail<C, NT>(a, lds, scratch, board0, boards, rows_valid, small_conv);
+    conv_heads_tail<C, NT>(a, lds, scratch, board0, boards, rows_valid, small_conv, xin, rows_img * RS);
 }

@@ -167,6 +167,7 @@ struct kz_engine {
         int epoch = 0;  // what the flag reads when this submission saw a non-finite activation
         // device-side decode (N2): CSR move lists, decoded values, probabilities, error flag; grown on demand
         bool decoded = false;  // what is in flight was submitted with a move list
+        bool in_launch = false;  // ... and decoded by the network's own launch (the range check reports in h_sout's header)
         size_t move_cap = 0, moves = 0;
         int64_t *d_moff = nullptr, *h_moff = nullptr;
         int32_t *d_midx = nullptr, *h_midx = nullptr;
@@ -381,7 +382,11 @@ struct kz_engine {
         size_t stride;
         const void *scalars;
     };
-    int run_tower(int batch, float *d_scalars, float *d_policy, const PackedIn *packed = nullptr) {
+    // the one-launch networks ("...+heads") can end in decode_output (kz_decode_dev.hpp): no decode launch, nothing but the
+    // decoded values and the available moves' probabilities leave the launch
+    bool decode_in_launch() const { return fused_heads || fused32 || fused_split || fused_pairs; }
+    int run_tower(int batch, float *d_scalars, float *d_policy, const PackedIn *packed = nullptr,
+                  const kz::DecodeArgs *dec = nullptr) {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         if (resident) {
@@ -401,6 +406,7 @@ struct kz_engine {
             t.sh_w2 = wts->sh_w2; t.sh_b2 = wts->sh_b2; t.att_idx = wts->att_idx;
             t.scalars = d_scalars; t.policy = d_policy;
             t.nonfinite_flag = nf_flag; t.epoch = nf_epoch;
+            if (dec && fused_heads) t.decode = *dec;
             prof.begin("kz_tower_resident_f16", stream);
 #ifdef KZ_EXPERIMENTS
             if (nb4) kz::launch_tower_resident4(t, xres, stream);
@@ -449,6 +455,7 @@ struct kz_engine {
                 hd.scalars = d_scalars; hd.policy = d_policy;
                 hd.nonfinite_flag = nf_flag; hd.epoch = nf_epoch;
             }
+            if (dec && t.heads.on) t.heads.decode = *dec;
             t.dense3 = t32_dense3;
             t.wide = wide;
             prof.begin(split16 ? "kz_tower_resident_split" : pairs16 ? "kz_tower_resident_f16g" : "kz_tower_resident_f32", stream);
@@ -609,11 +616,13 @@ struct kz_engine {
         return 0;
     }
 
-    int forward_packed(const void *d_bits, size_t stride, const void *d_sin, int batch, void *d_sout, void *d_pol) {
+    // dec (decode_in_launch() engines only): the launch ends in decode_output and writes dec->values / dec->probs
+    int forward_packed(const void *d_bits, size_t stride, const void *d_sin, int batch, void *d_sout, void *d_pol,
+                       const kz::DecodeArgs *dec = nullptr) {
         const Model &m = *model;
         if (resident || resident32 || pairs16) {  // encode is fused into the tower launch
             const PackedIn in{d_bits, stride, d_sin};
-            if (run_tower(batch, (float *)d_sout, (float *)d_pol, &in)) return 1;
+            if (run_tower(batch, (float *)d_sout, (float *)d_pol, &in, dec)) return 1;
             return run_heads(batch, (float *)d_sout, (float *)d_pol);
         }
         prof.begin("kz_encode_packed", stream);
@@ -1112,6 +1121,21 @@ KZ_API int kz_engine_submit_packed_decoded(kz_engine *e, int slot, const uint8_t
         ~StreamSwap() { e->stream = saved; }
     } swap{e, e->stream};
     if (e->slot_stream[slot]) e->stream = e->slot_stream[slot];
+    if (e->zero_copy && e->decode_in_launch()) {
+        // ONE launch and no copy operation: it reads the packed boards and the move lists from the slot's pinned staging
+        // and writes the decoded values and the available moves' probabilities there (0.2 KB per chess evaluation cross
+        // PCIe); decode_output (common.rs:16-100) is the launch's last step.  The conv policy heads keep their logits in
+        // device memory (s.d_pol) for the gather; the attention network's never leave LDS.
+        e->arm(s);
+        e->nf_flag = reinterpret_cast<int *>(s.h_sout);
+        const kz::DecodeArgs dec{s.h_moff, s.h_midx, s.h_values, s.h_probs, s.h_err};
+        if (e->forward_packed(s.h_bits, bits_bytes, s.h_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol, &dec)) return 1;
+        HIP_TRY(hipEventRecord(s.done, e->stream));
+        s.batch = batch;
+        s.decoded = s.in_launch = true;
+        s.moves = total;
+        return 0;
+    }
     HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_moff, s.h_moff, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, e->stream));
@@ -1130,6 +1154,7 @@ KZ_API int kz_engine_submit_packed_decoded(kz_engine *e, int slot, const uint8_t
     HIP_TRY(hipEventRecord(s.done, e->stream));
     s.batch = batch;
     s.decoded = true;
+    s.in_launch = false;
     s.moves = total;
     return 0;
 }
@@ -1148,6 +1173,7 @@ KZ_API int kz_engine_wait_decoded(kz_engine *e, int slot, const float **values_o
     if (batch == 0) return 0;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(s.done));
+    if (s.in_launch && kz_engine::slot_nonfinite(s)) return fail(kz_engine::nonfinite_message("kz_engine_wait_decoded"));
     if (*s.h_err & 2) return fail(kz_engine::nonfinite_message("kz_engine_wait_decoded"));
     if (*s.h_err) return fail("kz_engine_wait_decoded: Softmax input sum must be strictly positive (or a move index is out of range)");
     return 0;

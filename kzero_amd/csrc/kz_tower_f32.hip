@@ -53,6 +53,7 @@ namespace {
 #define KZ_STAMP(slot) do { } while (0)
 #endif
 #define KZ_HEADS_STAMP(slot) KZ_STAMP(slot)
+#include "kz_decode_dev.hpp"  // DecodeDev, decode_board_wave: decode_output as the last step of the launch
 #include "kz_conv_heads.hpp"  // plane_of, conv_heads_f32 (inside this namespace)
 
 struct TowerF32Dev {
@@ -74,6 +75,7 @@ struct TowerF32Dev {
     const f32x4 *small_w;  // tower32_pack_small_weights: [over x: scalar-head conv rows, extra-move conv row][over hidden: policy conv]
     float *scalars, *policy;
     int *nonfinite_flag;
+    DecodeDev dec;  // dec.move_offsets set: decode_output inside the launch (policy must be device memory then)
     unsigned long long *stamps;  // (diagnostic build)
 };
 
@@ -545,6 +547,8 @@ void launch_tower32(const Tower32Args &t, hipStream_t stream) {
     d.small_w = static_cast<const f32x4 *>(static_cast<const void *>(hd.small_w));
     d.stamps = nullptr;
     d.scalars = hd.scalars; d.policy = hd.policy; d.nonfinite_flag = hd.nonfinite_flag;
+    d.dec = DecodeDev{hd.on ? hd.decode.move_offsets : nullptr, hd.decode.move_indices, hd.decode.values, hd.decode.probs,
+                      hd.decode.error_flag, hd.policy_len};
     const int grid = (t.batch + d.nb - 1) / d.nb;
     if (t.channels == 256) launch<256, 4>(d, hd.on, grid, stream);
 #ifdef KZ_EXPERIMENTS

@@ -31,6 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#include "kz_decode_dev.hpp"  // DecodeDev, decode_board_wave: decode_output as the last step of a launch with the heads inside
 #include "kz_conv_heads.hpp"  // conv_heads_f32: the conv policy heads and the scalar head on f32 row images in LDS
 
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
@@ -122,6 +123,7 @@ struct SplitDev {
     float *scalars, *policy;
     int *nonfinite_flag;
     int epoch;
+    DecodeDev dec;  // dec.move_offsets set (fused heads only): decode_output inside the launch
 };
 constexpr int HEAD_PASSES = 5, POLICY = 1880, LOGIT_LD = 96;
 
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
                     }
                 }
             };
-            conv_heads_tail<C, NT>(a, lds, L::LDS_BYTES, board0, boards, rows_valid, small_conv);
+            conv_heads_tail<C, NT>(a, lds, L::LDS_BYTES, board0, boards, rows_valid, small_conv, XH, L::IMG);
         } else {
             // Both images, (hi, lo) — or plain f16 — -> f32 rows in the layout of kz_tower_f32.hip ([16 scratch rows][X][Y], row stride 4 C + 16),
             // through registers (everything else in LDS is dead); then the exact-f32 launch's own tail.
@@ -744,15 +746,26 @@ __global__ __launch_bounds__(256, 1) void kz_tower_resident_split(SplitDev a) {
             }
         }
         // ---- H7: ScalarHead Linear(32 -> 5) (post_act.py:19)
+        const bool decode = a.dec.move_offsets != nullptr;
+        float *raw = reinterpret_cast<float *>(lds + ACT);  // (act is dead since H5: the decode's five scalars)
         if (tid < 5) {
             const float *hid = reinterpret_cast<const float *>(lds + HID);
             float sum = a.sh_b2[tid];
             for (int i = 0; i < 32; i++) sum += a.sh_w2[tid * 32 + i] * hid[i];
-            a.scalars[(size_t)board0 * 5 + tid] = sum;
+            if (decode) raw[tid] = sum;
+            else a.scalars[(size_t)board0 * 5 + tid] = sum;
         }
         __syncthreads();
-        // ---- H8: policy.flatten(1)[:, FLAT_TO_ATT] (post_act.py:140): coalesced 1880-float rows
-        {
+        if (decode) {
+            // ---- H8': decode_output (common.rs:16-100) on the LDS-resident logits: the gather of post_act.py:140 per
+            // available move, softmax, tanh / wdl — one wave; q_to's hi image (X) is dead and holds its staging
+            if (wave == 0) {
+                const float *lg = reinterpret_cast<const float *>(lds + LOG);
+                decode_board_wave(a.dec, board0, lane, raw, reinterpret_cast<float *>(lds + XH), L::IMG / 4,
+                                  [&](int idx) { return lg[a.att_idx[idx]]; });
+            }
+        } else {
+            // ---- H8: policy.flatten(1)[:, FLAT_TO_ATT] (post_act.py:140): coalesced 1880-float rows
             const float *lg = reinterpret_cast<const float *>(lds + LOG);
             float *pol = a.policy + (size_t)board0 * POLICY;
             for (int k = tid; k < POLICY; k += 256) pol[k] = lg[a.att_idx[k]];
@@ -1599,6 +1612,8 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         d.att_idx = hd.att_idx;
         d.scalars = hd.scalars; d.policy = hd.policy;
         d.nonfinite_flag = hd.nonfinite_flag; d.epoch = hd.epoch;
+        d.dec = DecodeDev{hd.decode.move_offsets, hd.decode.move_indices, hd.decode.values, hd.decode.probs, hd.decode.error_flag,
+                          hd.small_w ? hd.policy_len : POLICY};
         if (hd.small_w) {  // conv policy heads (tower_split_conv_heads_supported)
             d.hc = hd.hc; d.hs = hd.hs; d.pc = hd.pc; d.policy_len = hd.policy_len; d.zero_tail = hd.zero_tail; d.extra = hd.extra;
             d.sh_w1t = hd.sh_w1t; d.p_b1 = hd.p_b1; d.pe_bc = hd.pe_bc; d.pe_wl = hd.pe_wl; d.pe_bl = hd.pe_bl;
