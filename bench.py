@@ -9,10 +9,13 @@ with its own HIP stream(s).
 
 One JSON line on rank 0 carries
   * `value`: the K timed steps with the packed boards already resident in HBM and the outputs left in HBM (the
-    measurement contract: inputs resident when the timed region starts);
-  * `pcie_inclusive`: the same K steps through the host-pointer boundary the reference's `evaluate_batch` has
-    (cudnn.rs:55-87: host boards in, host results out): kz_engine_submit_packed -> kz_engine_wait_view, pinned staging,
-    H2D of 136 B and D2H of 7,540 B per evaluation inside the timed region, two slots per engine in flight;
+    measurement contract: inputs resident when the timed region starts).  The K-step region is timed `--repeats` times
+    (default 7), each bracketed by barrier + device sync on both sides; `value` is the MEDIAN region, `value_min` /
+    `value_max` the slowest and fastest, `ms_per_step` x `steps` = the median region;
+  * `value_host_boundary` (= `pcie_inclusive.value`): the same K steps, the same number of regions, through the
+    host-pointer boundary the reference's `evaluate_batch` has (cudnn.rs:55-87: host boards in, host results out):
+    kz_engine_submit_packed -> kz_engine_wait_view, pinned staging, H2D of 136 B and D2H of 7,540 B per evaluation inside
+    the timed region — THE number to hold against the reference's `real` evals/s; the contract keeps it out of `value`;
   * `roofline` for the dominant kernel, HIP events on the engines' own streams over the timed region;
   * `others` (N=1 only): the other single-GPU BASELINE configs as ~1 s sub-records — A1 Ataxx 8x128 f32 B=256, the G8
     network Go-19 40x256 f16 B=512, and the chess network through the <=1e-4-parity path (f32split16);
@@ -39,7 +42,7 @@ sys.path.insert(0, REPO)
 FULL_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set()
 
 WORKLOADS = {
-    "chess-20x256": dict(game="chess", depth=20, channels=256, head="attention", batch=256, steps=10000,
+    "chess-20x256": dict(game="chess", depth=20, channels=256, head="attention", batch=256, steps=2000,
                          engines={"f16": 2, "f32": 2, "f32split16": 2},
                          label="Chess 20x256 ResNet b=256"),
     "ataxx-8x128": dict(game="ataxx-7", depth=8, channels=128, head="ataxx_conv", batch=256, steps=10000,
@@ -70,6 +73,14 @@ WORKLOADS = {
                         engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Go 13x13 20x128 ResNet b=256"),
 }
 # the other single-GPU BASELINE configs, reported as sub-records of the default line
+# the headline network with other weight statistics (sub-records `weights`): the f16 matrix cores are power-limited and the
+# power they draw depends on the operands' bits (the same launch: 0.63 of peak on uniform random weights, 0.79 on all-zero
+# ones), so the headline's uniform PyTorch-default init comes with a measured band
+WEIGHT_VARIANTS = [
+    ("uniform (PyTorch default init: the headline's)", dict()),
+    ("kaiming_normal (N(0, sqrt(2 / fan_in)) convolution weights)", dict(init="kaiming_normal")),
+    ("trained-like scale (block_gain 3: the residual stream grows to ~170, logits to ~1.8e3)", dict(block_gain=3.0)),
+]
 OTHERS = [("ataxx-8x128", "f32"), ("ataxx-8x128", "f32split16"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"),
           ("go19-40x256", "f32split16"), ("go9-16x128", "f32split16"), ("go9-16x128", "f16")]
 
@@ -105,8 +116,10 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps; default: about 5 s of the workload (SURVEY.md §8(d)): chess 10000, ataxx 10000, go 400")
+                    help="timed steps per region; default: about 1 s of the workload (chess 2000, ataxx 10000, go 400)")
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="timed regions of --steps steps each (every one bracketed by barrier + sync); value = the median region")
     ap.add_argument("--batch", type=int, default=None,
                     help="executor batch (gpu_batch_size); default: BASELINE.json's for the workload (256; Go 512)")
     ap.add_argument("--engines", type=int, default=None,
@@ -219,7 +232,24 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
     t0 = time.perf_counter()
     net.forward(dense[:n], threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "evals/s", "cores": cores, "kind": "port",
+    a0 = None
+    try:  # BASELINE configs[0]: Ataxx 7x7, 4 blocks x 64 channels, the CPU executor on ONE thread (the generator's own)
+        from kzero_amd import synth
+        a0_blob = synth.random_model("ataxx-7", 4, 64, "ataxx_conv", seed=0)
+        a0_net = O.OracleNet(a0_blob)
+        a0_bits, a0_sin = synth.random_boards("ataxx-7", 256, seed=1000)
+        a0_dense = O.encode_input_full(a0_bits, a0_sin, a0_net.n_scalar, a0_net.n_bool, a0_net.h, a0_net.w)
+        a0_net.forward(a0_dense[:4], threads=1)
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < 2.0:
+            a0_net.forward(a0_dense[done % 256:done % 256 + 16], threads=1)
+            done += 16
+        a0 = {"config": "BASELINE configs[0]: Ataxx 7x7 4x64, CPU executor, 1 thread", "value": round(done / (time.perf_counter() - t0), 2),
+              "unit": "evals/s", "cores": 1, "kind": "port", "sample": f"{done} boards in batches of 16, oracle/kz_oracle.c, one thread"}
+    except Exception as ex:  # noqa: BLE001
+        a0 = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+    return {"value": round(n / dt, 3), "unit": "evals/s", "cores": cores, "kind": "port", "a0": a0,
             "sample": f"{n} boards of the same synthetic batch, oracle/kz_oracle.c f32 NCHW direct conv, "
                       f"OpenMP over boards on {cores} threads = the container's CPU quota (cgroup cpu.max; the affinity mask "
                       f"allows {affinity}, the machine reports {os.cpu_count()}: a whole socket is not this process's to "
@@ -246,14 +276,14 @@ def committed_traffic(kernel: str, workload: str, batch: int):
 class Workload:
     """One (network, dtype, batch) on one device: engines, resident inputs, the two kinds of step."""
 
-    def __init__(self, capi, synth, name, dtype_name, batch, n_engines, device, seed):
+    def __init__(self, capi, synth, name, dtype_name, batch, n_engines, device, seed, model_kw=None):
         import numpy as np
         self.np, self.capi = np, capi
         self.name, self.dtype_name, self.B, self.device = name, dtype_name, batch, device
         wl = WORKLOADS[name]
         self.wl = wl
         dtype = {"f16": capi.KZ_DTYPE_F16, "f32": capi.KZ_DTYPE_F32, "f32split16": capi.KZ_DTYPE_F32_SPLIT16}[dtype_name]
-        self.blob = synth.random_model(wl["game"], wl["depth"], wl["channels"], wl["head"], seed=0)
+        self.blob = synth.random_model(wl["game"], wl["depth"], wl["channels"], wl["head"], seed=0, **(model_kw or {}))
         self.model = capi.Model(blob=self.blob)
         self.info = self.model.info
         self.bits, self.scalars_in = synth.random_boards(wl["game"], batch, seed=seed)
@@ -413,10 +443,10 @@ class Workload:
         self.model.close()
 
 
-def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm):
+def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm, model_kw=None):
     """~`seconds` of timed steps of another BASELINE config on this GPU (N=1 only), device-resident like `value`."""
     wl = WORKLOADS[name]
-    w = Workload(capi, synth, name, dtype_name, wl["batch"], wl["engines"][dtype_name], device, seed=1000)
+    w = Workload(capi, synth, name, dtype_name, wl["batch"], wl["engines"][dtype_name], device, seed=1000, model_kw=model_kw)
     try:
         w.condition(w.step_resident, prewarm)
         t0 = time.perf_counter()
@@ -566,12 +596,15 @@ def fake_main(args, benchlib, rank, local_rank, world, dist):
     def step(i):
         time.sleep(args.fake_step * 1e-3 * (1 + rank))  # (rank r is r+1 times slower: the per-rank lines must show it)
     own = []
-    elapsed = benchlib.run_timed(step, lambda: None, args.steps, args.warmup, dist, own=own)
+    regions = benchlib.run_timed_regions(step, lambda: None, args.steps, args.warmup, args.repeats, dist, owns=own)
+    elapsed = benchlib.median_region(regions)
     per_rank = benchlib.gather_objects(dist, {"rank": rank, "device": device, "bus_id": seen[rank],
-                                              "evals_s": round(args.steps / own[0], 3)})
+                                              "evals_s": round(args.steps / benchlib.median_region(own), 3)})
     if rank == 0:
         print(json.dumps({"metric": "fake steps/sec (launcher test)", "value": round(args.steps * world / elapsed, 3),
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "regions": len(regions), "value_min": round(args.steps * world / max(regions), 3),
+                          "value_max": round(args.steps * world / min(regions), 3),
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "fake", "devices_seen": sorted(set(seen)),
                           "per_rank": per_rank,
@@ -619,33 +652,38 @@ def main():
     w = Workload(capi, synth, args.workload, args.dtype, args.batch, args.engines, device, benchlib.board_seed(rank))
     B = args.batch
 
-    # ---- timed region 1 (`value`): inputs resident in HBM, outputs left in HBM ----
+    # ---- timed regions 1 (`value`): inputs resident in HBM, outputs left in HBM; `--repeats` regions of K steps ----
     w.condition(w.step_resident, args.prewarm)
     own, h_own = [], []
-    elapsed = benchlib.run_timed(w.step_resident, w.sync, args.steps, args.warmup, dist,
-                                 on_timed_start=None if w.per_layer else (lambda: w.profiling(True)), own=own)
+    regions = benchlib.run_timed_regions(w.step_resident, w.sync, args.steps, args.warmup, args.repeats, dist,
+                                         on_timed_start=None if w.per_layer else (lambda: w.profiling(True)), owns=own)
     if w.per_layer:
         k_ms, k_n = w.instrumented_pass(w.step_resident, min(args.steps, 50))
     else:
         k_ms, k_n = w.kernel_time()
         w.profiling(False)
     w.check_finite()
+    elapsed = benchlib.median_region(regions)
     value = benchlib.whole_job_value(args.steps, B, world, elapsed)
+    region_values = [benchlib.whole_job_value(args.steps, B, world, t) for t in regions]
 
-    # ---- timed region 2 (`pcie_inclusive`): the same K steps through the host-pointer boundary ----
+    # ---- timed regions 2 (`value_host_boundary`): the same K steps through the host-pointer boundary ----
     host = None
     if not args.no_host_io:
         w.condition(w.step_host, min(args.prewarm, 0.1))
-        h_elapsed = benchlib.run_timed(w.step_host, w.sync, args.steps, args.warmup, dist,
-                                       on_timed_start=None if w.per_layer else (lambda: w.profiling(True)), own=h_own)
+        h_regions = benchlib.run_timed_regions(w.step_host, w.sync, args.steps, args.warmup, args.repeats, dist,
+                                               on_timed_start=None if w.per_layer else (lambda: w.profiling(True)), owns=h_own)
         if w.per_layer:
             h_ms, h_n = w.instrumented_pass(w.step_host, min(args.steps, 50))
         else:
             h_ms, h_n = w.kernel_time()
             w.profiling(False)
+        h_elapsed = benchlib.median_region(h_regions)
         h_value = benchlib.whole_job_value(args.steps, B, world, h_elapsed)
+        h_values = [benchlib.whole_job_value(args.steps, B, world, t) for t in h_regions]
         info = w.info
-        host = {"value": round(h_value, 1), "unit": "evals/s", "steps": args.steps,
+        host = {"value": round(h_value, 1), "value_min": round(min(h_values), 1), "value_max": round(max(h_values), 1),
+                "unit": "evals/s", "steps": args.steps, "regions": len(h_regions),
                 "ms_per_step": round(h_elapsed / args.steps * 1e3, 4), "of_resident": round(h_value / value, 4),
                 "engines_per_gpu": len(w.host_engines),
                 "entry_points": "kz_engine_submit_packed -> kz_engine_wait_view (pinned staging, "
@@ -659,9 +697,9 @@ def main():
     per_rank = benchlib.gather_objects(dist, {
         "rank": rank, "device": device, "bus_id": devices_seen[rank], "numa_node": numa["numa_node"],
         "numa_bound": numa["bound"], "numa_bound_before_first_hip_call": numa.get("bound_before_first_hip_call", False),
-        "host_cpus": numa["cpus"], "evals_s": round(args.steps * B / own[0], 1),
+        "host_cpus": numa["cpus"], "evals_s": round(args.steps * B / benchlib.median_region(own), 1),
         "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
-        "pcie_inclusive_evals_s": round(args.steps * B / h_own[0], 1) if h_own else None})
+        "pcie_inclusive_evals_s": round(args.steps * B / benchlib.median_region(h_own), 1) if h_own else None})
     if rank != 0:
         w.close()
         if dist is not None:
@@ -672,19 +710,32 @@ def main():
     wl = WORKLOADS[args.workload]
     metric = ("self-play NN evals/sec (node), Chess 20x256 ResNet b=256, 1/2/4/8 GPU" if args.is_default_line else
               f"self-play NN evals/sec (node), {wl['label'].rsplit(' b=', 1)[0]} b={B}, {world} GPU")
+    roof = w.roofline(k_ms, k_n, min(args.steps, 50) if w.per_layer else args.steps * len(regions), value / world)
+    if host:  # the same fraction for the number a caller of the host-pointer boundary gets
+        roof["host_boundary_frac"] = host["chip_frac"]
     out = {
         "metric": metric,
         "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        # value = the MEDIAN of `regions` timed regions of `steps` steps each (every region bracketed by barrier + device
+        # sync); ms_per_step x steps = that region
+        "regions": len(regions), "value_min": round(min(region_values), 1), "value_max": round(max(region_values), 1),
+        "region_values": [round(v, 1) for v in region_values],
+        # what the reference's evaluate_batch boundary delivers (host boards in, host results out): compare THIS with the
+        # reference's `real` evals/s; the measurement contract keeps it out of `value` (inputs resident in HBM)
+        "value_host_boundary": host["value"] if host else None,
+        "schema": "r5: value = median region; roofline.achieved/frac = the chip's (all concurrent launches; since r4), "
+                  "launch_achieved/launch_frac = one launch's (what frac meant in r1-r3)",
         "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, packed boards resident in HBM",
                    "engines_per_gpu": args.engines, "conditioning_s": args.prewarm, "tower_path": w.tower_path,
                    "parallelism": f"dp{world} (no collective)", "flop_per_eval": w.info.flops_per_eval,
+                   "weights": "PyTorch-default uniform init, seed 0 (others[].weights: the same network with other statistics)",
                    "device_resident_evals_s": round(value, 1),
-                   "pcie_inclusive_evals_s": host["value"] if host else None},
+                   "host_boundary_evals_s": host["value"] if host else None},
         "devices_seen": sorted(set(devices_seen)),
         "per_rank": per_rank,
-        "roofline": w.roofline(k_ms, k_n, min(args.steps, 50) if w.per_layer else args.steps, value / world),
+        "roofline": roof,
     }
     if host:
         out["pcie_inclusive"] = host
@@ -697,6 +748,15 @@ def main():
                 out["others"].append(sub_record(capi, synth, n, d, device, args.other_seconds, args.prewarm))
             except Exception as ex:  # noqa: BLE001
                 out["others"].append({"workload": n, "dtype": d, "error": f"{type(ex).__name__}: {ex}"[:300]})
+        # the headline network with other weight statistics, same box, same run (the matrix cores' power depends on the data)
+        for label, kw in WEIGHT_VARIANTS:
+            try:
+                rec = sub_record(capi, synth, "chess-20x256", "f16", device, args.other_seconds, args.prewarm, model_kw=kw)
+                rec["weights"] = label
+                out["others"].append(rec)
+            except Exception as ex:  # noqa: BLE001
+                out["others"].append({"workload": "chess-20x256", "dtype": "f16", "weights": label,
+                                      "error": f"{type(ex).__name__}: {ex}"[:300]})
     if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
         out["seam"] = seam_record(blob, args.seam_seconds)
         # ... and at the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity -> split16 for this network)

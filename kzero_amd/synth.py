@@ -61,8 +61,14 @@ def _uniform(rng, shape, fan_in):
     return rng.uniform(-bound, bound, size=shape).astype(np.float32)
 
 
+_INIT = "uniform"  # what _conv draws convolution weights from (set by random_model for the duration of one call)
+
+
 def _conv(rng, t, prefix, cout, cin, k):
-    t[prefix + ".weight"] = _uniform(rng, (cout, cin, k, k), cin * k * k)
+    if _INIT == "kaiming_normal":  # nn.init.kaiming_normal_(w, nonlinearity="relu"): N(0, sqrt(2 / fan_in))
+        t[prefix + ".weight"] = rng.normal(0.0, np.sqrt(2.0 / (cin * k * k)), size=(cout, cin, k, k)).astype(np.float32)
+    else:
+        t[prefix + ".weight"] = _uniform(rng, (cout, cin, k, k), cin * k * k)
     t[prefix + ".bias"] = _uniform(rng, (cout,), cin * k * k)
 
 
@@ -81,9 +87,25 @@ def _bn(rng, t, prefix, c):
 def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0, query_channels: int = None,
                  n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0,
                  dense_hidden_channels: int = None, dense_hidden_size: int = None, scalar_hidden_channels: int = 4,
-                 final_affine: bool = True) -> bytes:
+                 final_affine: bool = True, init: str = "uniform") -> bytes:
     """`block_gain` > 1 scales every block's second BatchNorm weight: the residual stream then grows from block to block
-    the way a trained network's does (a random-init tower keeps it within a few tens)."""
+    the way a trained network's does (a random-init tower keeps it within a few tens).
+    `init`: "uniform" = PyTorch's default for Conv2d / Linear (U(+-1/sqrt(fan_in))); "kaiming_normal" = convolution weights
+    from N(0, sqrt(2 / fan_in)) — a bell-shaped weight distribution with 2.4 x the standard deviation (the matrix cores'
+    power draw, and with it the clock they sustain, depends on the data: DESIGN.md, bench.py `weights`)."""
+    global _INIT
+    if init not in ("uniform", "kaiming_normal"):
+        raise ValueError(f"unknown init '{init}'")
+    _INIT = init
+    try:
+        return _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
+                             dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine)
+    finally:
+        _INIT = "uniform"
+
+
+def _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
+                  dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine) -> bytes:
     g = game_spec(game)
     size, n_scalar = g["size"], g["n_scalar"]
     n_bool = g["n_bool"] if n_bool is None else n_bool

@@ -13,7 +13,7 @@ for v in "$@"; do
   esac
   out=$PWD/gpurun_out/pmc_$set$v
   rm -rf $out
-  KZ_LIB_PATH=/root/repo/kzero_amd/libkzhip$v.so rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 bench.py --no-cpu-baseline --batch ${BATCH:-512} --engines 1 --steps 300 --warmup 20 ${BENCH_ARGS:-} > $out.log 2>&1
+  KZ_LIB_PATH=/root/repo/kzero_amd/libkzhip$v.so rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 bench.py --repeats 1 --no-cpu-baseline --batch ${BATCH:-512} --engines 1 --steps 300 --warmup 20 ${BENCH_ARGS:-} > $out.log 2>&1
   python3 - "$out/run_counter_collection.csv" "lib$v" <<'PY'
 import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))

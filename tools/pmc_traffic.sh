@@ -11,7 +11,7 @@ TAG=${WL}_${DT}
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$PWD/gpurun_out/pmc_traffic_${TAG}_$c
   rm -rf "$out"
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out" -o run -- python3 bench.py --workload $WL --dtype $DT \
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out" -o run -- python3 bench.py --repeats 1 --workload $WL --dtype $DT \
      ${BATCH:+--batch $BATCH} --engines 1 --steps ${STEPS:-60} --warmup ${WARMUP:-10} --prewarm 0 --no-cpu-baseline --no-others --no-host-io \
      > "$out.log" 2>&1
 done

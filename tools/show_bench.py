@@ -11,14 +11,15 @@ def roof(x):
             f"traffic {f['traffic']} ratio {f.get('traffic_ratio')}")
 
 
-print("value", r["value"], roof(r))
+print("value", r["value"], f"[{r.get('value_min')} .. {r.get('value_max')}] over {r.get('regions')} regions of {r['steps']} steps;",
+      "host boundary", r.get("value_host_boundary"), f"(frac {r['roofline'].get('host_boundary_frac')});", roof(r))
 if "pcie_inclusive" in r:
-    h = r["pcie_inclusive"]; print("pcie_inclusive", h["value"], "of_resident", h["of_resident"], "engines", h.get("engines_per_gpu"))
+    h = r["pcie_inclusive"]; print("pcie_inclusive", h["value"], f"[{h.get('value_min')} .. {h.get('value_max')}]", "of_resident", h["of_resident"], "engines", h.get("engines_per_gpu"))
 for o in r.get("others", []):
     if "error" in o:
         print(" ", o["workload"], o["dtype"], "ERROR", o["error"])
         continue
-    print(" ", o["workload"], o["dtype"], o["value"], o["tower_path"], roof(o))
+    print(" ", o["workload"], o["dtype"], o["value"], o["tower_path"], roof(o), ("| weights: " + o["weights"]) if "weights" in o else "")
 for key in ("seam", "seam_parity", "seam_one_process"):
     s = r.get(key)
     if not s:
@@ -34,4 +35,4 @@ for key in ("seam", "seam_parity", "seam_one_process"):
         print(f"  {key} [{run['config']}] {run['value']:.0f} evals/s fill {run['fill']} executor work util {run['executor_work_util']} (cpu {run['executor_cpu_util']}) "
               f"generators {run['generator_cpu_util']} host cpu s/Meval {run['host_cpu_s_per_Meval']} | x8: {p['cores_needed']} cores "
               f"of {p['cores_per_numa_node']} per node, {p['pcie_GBps']} GB/s PCIe")
-if "cpu_baseline" in r: print("cpu", r["cpu_baseline"]["value"], "cores", r["cpu_baseline"]["cores"], r["cpu_baseline"].get("error", ""))
+if "cpu_baseline" in r: print("cpu", r["cpu_baseline"]["value"], "cores", r["cpu_baseline"]["cores"], r["cpu_baseline"].get("error", ""), "| a0:", r["cpu_baseline"].get("a0"))
