@@ -10,13 +10,23 @@
 //
 //   workgroup = 24 tiles of 16 pixel rows (bpw boards, each padded to tpb = ceil(h*w/16) tiles; Go: 23 tiles, bpw = 1)
 //               x 64 output channels; 256 threads = 4 waves; wave = (row quarter: 6 tiles) x (all 64 output channels)
-//   LDS       = one 64-channel chunk of the image, WITH a zero halo: board b, pixel (y, x) is image row
-//               b*rpb + (y+1)*(w+1) + x+1 (the right halo of a line is the left halo of the next), so a tap is a constant
-//               row offset and needs no validity test in the k-loop — per tap and tile ONE v_add, against a
-//               compare/select chain per tile that made the loop issue-bound.  Two planes (channels [0,32) and
-//               [32,64)) of rows x 80 B, a multiple of 256 B apart: the two lane groups that share a ds_read_b128
-//               bank group read the two planes at the same row offset and rows advance by 5 sixteen-byte slots ->
-//               conflict-free fragment reads, except one 2-way pair in tiles that cross a line end.  Go: 66 KB.
+//   LDS       = one 64-channel chunk of the image, WITH a zero halo: board b, pixel (y, x) sits at 16-byte slot
+//               b*board16 + (y+1)*line16 + (x+1)*5 of a plane (a pixel row is 80 B = 5 slots: 64 B of channels + 16 B pad),
+//               so a tap is a constant byte offset and needs no validity test in the k-loop — per tap and tile ONE
+//               v_add, against a compare/select chain per tile that made the loop issue-bound.  Two planes (channels
+//               [0,32) and [32,64); split arithmetic: channel pieces {0,2} and {1,3} of the chunk, hi then lo) a multiple
+//               of 256 B apart: a ds_read_b128 is served in four groups of 16 lanes, each the sixteen pixel rows of a
+//               tile spread over lane groups kq and kq + 1, which read the two planes at the same row offset — a group
+//               is conflict-free when the sixteen rows fall on sixteen different 16-byte slots of the 256-byte bank row.
+//               Rows of a line advance by 5 slots (odd: 16 consecutive rows are 16 slots); a tile of 16 pixels that
+//               crosses a line end — 80 % of Go's tiles, 16 pixels on 19-wide lines — must see the same advance across
+//               the gap: line16 = 5*(w+1) + 11 slots (left halo row, w pixel rows, an 11-slot gap whose first 5 slots
+//               are the right halo row), so that line16 = 5*w (mod 16).  (Rounds 1-4 had line16 = 5*(w+1), the right
+//               halo of a line being the left halo of the next: pixel (y+1, 0) then sat 10 slots behind (y, w-1), rows
+//               r and r+16 of such a tile shared a slot and every group of the read took two cycles: SQ_LDS_BANK_CONFLICT
+//               was 44 % of SQ_LDS_IDX_ACTIVE on Go 19x19, 48 % in split arithmetic, whose four channel pieces in ONE
+//               plane conflicted on top of that.)  The gap costs 21 % more LDS per board: a board size that would lose a
+//               board per workgroup to it keeps the old line (Geometry::skew16 = 0).  Go: 75 KB, two workgroups per CU.
 //   registers = 96 accumulators + 24 fragment + 48 weight ring: < 256, two waves per SIMD.  The ring's 48 registers are
 //               also the staging buffer: during the last PF k-steps of a chunk a ring stage that has fed its MFMAs is not
 //               refilled with weights but with this thread's 12 pieces of the NEXT chunk's image (or, in the last chunk,
@@ -117,9 +127,11 @@ struct BoardConvDev {
     int bytes;          // size of y (and of the residual): boards * hw * ld * 2 (< 2^31)
     int bytes_x, ldx;   // the input's: ldx == ld unless the convolution has a single chunk (the stem: 64 input channels)
     int ld, boards, h, w_, hw, tpb, bpw, cin, relu, groups, nq;
-    unsigned inv_tpb, inv_w, inv_nhb;  // ceil(65536 / tpb), / w, / (halo rows per board): exact quotients for the small
-                                       // values they meet
-    int pitch, rpb, plane;  // halo image: w + 1 rows per line, (h + 2) * pitch + 1 rows per board, bytes per plane
+    unsigned inv_tpb, inv_w, inv_nhb;  // ceil(65536 / tpb), / w: exact quotients for the small values they meet;
+                                       // ceil(2^32 / halo slots per board and plane)
+    int pitch, plane;       // halo image: w + 1 rows per line (+ the gap), bytes per plane
+    int line16, board16;    // 16-byte slots per line (5 * pitch + skew) and per board ((h + 2) * line16 + 5)
+    unsigned inv_10;
     int rm_off;             // LDS offset of the 384 image-row indices (u16), behind the image / the epilogue's output tile
     // split arithmetic (kz_board_conv_split16) only: a tensor row is [hi 32 | lo 32] f16 per group of 32 channels (ld = 2 C);
     // y32 != nullptr: the result as f32 [pixels][ld32 = C] instead (the tower's last layer, for the f32 heads)
@@ -173,15 +185,20 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // Slot i of a thread = tile row (tid >> 3) + 32 i, 16-byte piece tid & 7 of its 64 channels; the same 12 slots serve
     // the staging of every chunk, the residual and the output stores.
     const int piece = tid & 7;
-    const int ls_piece = (piece >> 2) * a.plane + (piece & 3) * 16;
+    // f16: pieces 0..3 = channels [0, 32) -> plane 0, 4..7 -> plane 1.  SPLIT: pieces 0..3 = the hi halves of channel
+    // pieces c = 0..3, 4..7 their lo halves: channel piece c lives in plane c & 1 at 16 (c >> 1), lo 32 bytes behind hi —
+    // lane groups kq and kq + 1 then read the two planes at the same row offset, like the f16 instance
+    const int ls_piece = SPLIT ? (piece & 1) * a.plane + ((piece >> 1) & 1) * 16 + (piece >> 2) * 32
+                               : (piece >> 2) * a.plane + (piece & 3) * 16;
     // tile row r -> board b (of this workgroup), pixel q, image row; false for a padding row or a board beyond the batch
     // (every factor is below 2^24: v_mul_u32_u24 / v_mad_u32_u24 run at full rate, a 32-bit v_mul_lo_u32 at a quarter)
     auto locate = [&](int r, int &b, int &q, int &irow) __attribute__((always_inline)) {
         b = (int)(__umul24((unsigned)(r >> 4), a.inv_tpb) >> 16);     // tile / tpb (exact: tile < 24)
         q = r - (int)__umul24((unsigned)b, (unsigned)a.tpb * 16u);
         const int yy = (int)(__umul24((unsigned)q, a.inv_w) >> 16);   // q / w (exact: q < 512, w <= 32)
-        // (yy + 1) * pitch + (q - yy * w) + 1 with pitch = w + 1
-        irow = (int)__umul24((unsigned)b, (unsigned)a.rpb) + q + yy + a.pitch + 1;
+        // 16-byte slot of the pixel row: (yy + 1) * line16 + (q - yy * w + 1) * 5
+        irow = (int)__umul24((unsigned)b, (unsigned)a.board16) + (int)__umul24((unsigned)(yy + 1), (unsigned)a.line16) +
+               (q - (int)__umul24((unsigned)yy, (unsigned)a.w_) + 1) * 5;
         return b < a.bpw && q < a.hw && board0 + b < a.boards;
     };
 #ifdef KZ_BC_REALTIME
@@ -254,16 +271,25 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     int g = 0;  // k-step counter; at a chunk boundary the ring holds k-steps g .. g + PF - 1
 
     KZ_STAMP(21);
-    // zero the halo rows once (10 sixteen-byte pieces per row: 5 per plane); they are never written again, and the
-    // pixel rows are overwritten by every chunk.  Halo row k of a board: the line above the board (k < pitch), the left
-    // neighbour of every line (the right neighbour of the line before), the line below plus one.
+    // zero the halo once (it is never written again; the pixel rows are overwritten by every chunk): per board and plane
+    // the line above the board (line16 slots), the line below (5 * (pitch + 1) slots) and, per pixel line, the five slots of
+    // its left halo row and the five of its right one (with skew 0 the next line's left halo)
     {
-        const int nhb = 2 * a.pitch + a.h + 1;  // halo rows per board
-        for (int id = tid; id < a.bpw * nhb * 10; id += 256) {
-            const int k = (int)(((unsigned)id * 6554u) >> 16), pc = id - k * 10;  // id / 10 for id < 16384
-            const int b = (int)(((unsigned)k * a.inv_nhb) >> 16), kk = k - b * nhb;
-            const int row = b * a.rpb + (kk < a.pitch ? kk : kk < a.pitch + a.h ? (kk - a.pitch + 1) * a.pitch : (a.h + 1) * a.pitch + (kk - a.pitch - a.h));
-            *reinterpret_cast<uint4 *>(lds + (pc >= 5 ? a.plane + (pc - 5) * 16 : pc * 16) + row * PRS) = make_uint4(0, 0, 0, 0);
+        const int nhb = a.line16 + 5 * (a.pitch + 1) + 10 * a.h;  // halo slots per board and plane
+        for (int id = tid; id < 2 * a.bpw * nhb; id += 256) {
+            const int pb = (int)__umulhi((unsigned)id, a.inv_nhb), k = id - pb * nhb;  // id / nhb (plane-major, then board)
+            const int pl = pb >= a.bpw ? 1 : 0, b = pb - pl * a.bpw;
+            int slot16;
+            if (k < a.line16) {
+                slot16 = k;
+            } else if (k < a.line16 + 5 * (a.pitch + 1)) {
+                slot16 = (a.h + 1) * a.line16 + (k - a.line16);
+            } else {
+                const int kk = k - a.line16 - 5 * (a.pitch + 1);
+                const int y = (int)(((unsigned)kk * a.inv_10) >> 16), pc = kk - y * 10;
+                slot16 = (y + 1) * a.line16 + (pc < 5 ? pc : a.pitch * 5 + pc - 5);
+            }
+            *reinterpret_cast<uint4 *>(lds + pl * a.plane + (b * a.board16 + slot16) * 16) = make_uint4(0, 0, 0, 0);
         }
     }
 
@@ -276,7 +302,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     for (int i = 0; i < MTW; i++) {
         int b, q, irow;
         const bool valid = locate((wr * MTW + i) * 16 + fr, b, q, irow);
-        T0[i] = (valid ? irow : a.pitch + 1) * PRS + (SPLIT ? kq * 16 : (kq & 1) * a.plane + (kq >> 1) * 16);
+        T0[i] = (valid ? irow : a.line16 + 5) * 16 + (kq & 1) * a.plane + (kq >> 1) * 16;
     }
 
     KZ_STAMP(24);
@@ -292,7 +318,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     }
 
     // LDS address of this lane's fragment row per tile for one tap: a constant row offset in the halo image.
-    // (pitch_prs is a.pitch * PRS behind an optimisation barrier inside the chunk loop: the rows are the same for every
+    // (pitch_prs is the line's bytes behind an optimisation barrier inside the chunk loop: the rows are the same for every
     // chunk, and the compiler would otherwise hoist all 9 x 12 of them out of the loop and spill them)
     auto tap_rows = [&](int tap, int lo, int hi, int pitch_prs, int (&T)[MTW]) {
         const int off = (tap / 3 - 1) * pitch_prs + (tap % 3 - 1) * PRS;
@@ -317,7 +343,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     KZ_STAMP(2);
 #pragma unroll
     for (int i = 0; i < 12; i++)
-        if (SPLIT ? irow0[i] >= 0 : po[SPLIT ? 0 : i] >= 0) *reinterpret_cast<u32x4 *>(lds + irow0[i] * PRS + ls_piece) = v0[i];
+        if (SPLIT ? irow0[i] >= 0 : po[SPLIT ? 0 : i] >= 0) *reinterpret_cast<u32x4 *>(lds + irow0[i] * 16 + ls_piece) = v0[i];
     KZ_STAMP(3);
     for (int chunk = 0; chunk < chunks; chunk++) {
         __syncthreads();  // the chunk is staged
@@ -338,7 +364,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         constexpr int HT = MTW / 2;
         int T[MTW];
         h16x8 bfA[HT], bfB[HT] = {};
-        int pitch_prs = a.pitch * PRS;
+        int pitch_prs = a.line16 * 16;  // bytes from a line to the next
         asm volatile("" : "+s"(pitch_prs));
         tap_rows(0, 0, MTW, pitch_prs, T);
 #pragma unroll
@@ -354,8 +380,8 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 const int wstep = SPLIT ? tap * 2 + (ks == 2 ? 1 : 0) : tap * 2 + ks;  // weight step within the chunk
                 const int stage = wstep % PF;
                 const bool stage_done = SPLIT ? ks != 0 : true;  // this MFMA step is the last one that reads the stage
-                const int ao = SPLIT ? (ks == 1 ? a.plane : 0) : ks * 32;  // where this step's fragments sit in a row
-                const int ao_next = ks == KS - 1 ? 0 : SPLIT ? (ks + 1 == 1 ? a.plane : 0) : (ks + 1) * 32;
+                const int ao = SPLIT ? (ks == 1 ? 32 : 0) : ks * 32;  // where this step's fragments sit in a row (SPLIT: lo behind hi)
+                const int ao_next = ks == KS - 1 ? 0 : SPLIT ? (ks + 1 == 1 ? 32 : 0) : (ks + 1) * 32;
                 // ---- half 1 ----
 #pragma unroll
                 for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i] + ao);
@@ -420,7 +446,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
             KZ_STAMP(6 + (chunk & 3) * 4);
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                if (SPLIT ? erow[i] != 0xffff : po[SPLIT ? 0 : i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * PRS + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
+                if (SPLIT ? erow[i] != 0xffff : po[SPLIT ? 0 : i] >= 0) *reinterpret_cast<uint4 *>(lds + erow[i] * 16 + ls_piece) = wreg[i / NTW][i % NTW];  // never into the halo
 #pragma unroll
             for (int st = 0; st < PF; st++)
 #pragma unroll
@@ -614,17 +640,25 @@ __global__ __launch_bounds__(256, 2) void kz_board_conv_split16(BoardConvDev a) 
 namespace {
 // halo image geometry: boards per workgroup limited by the 24 tiles and by 40 KB per plane (two workgroups per CU)
 struct Geometry {
-    int tpb, bpw, pitch, rpb, plane, rm_off, lds_bytes;
+    int tpb, bpw, pitch, skew16, line16, board16, plane, rm_off, lds_bytes;
 };
 constexpr int RM_BYTES = ROWS * 2 + ROWS * 4;  // image-row table (u16) + the split instance's row-offset table (i32)
+int boards_per_workgroup(int h, int w, int skew16) {
+    const int tpb = (h * w + 15) / 16, line16 = 5 * (w + 1) + skew16, board_bytes = ((h + 2) * line16 + 5) * 16;
+    const int by_tiles = tpb <= MT ? MT / tpb : 0, by_lds = ((LDS_MAX - RM_BYTES) / 2) / board_bytes;
+    return by_tiles < by_lds ? by_tiles : by_lds;
+}
 Geometry geometry(int h, int w) {
     Geometry g{};
     g.tpb = (h * w + 15) / 16;
     g.pitch = w + 1;
-    g.rpb = (h + 2) * g.pitch + 1;
-    const int by_tiles = g.tpb <= MT ? MT / g.tpb : 0, by_lds = ((LDS_MAX - RM_BYTES) / 2 / PRS) / g.rpb;
-    g.bpw = by_tiles < by_lds ? by_tiles : by_lds;
-    g.plane = (g.bpw * g.rpb * PRS + 255) / 256 * 256;
+    // the 11-slot gap per line that keeps tiles across a line end conflict-free (top of the file) — unless it costs this
+    // board size a board per workgroup
+    g.skew16 = boards_per_workgroup(h, w, 11) == boards_per_workgroup(h, w, 0) ? 11 : 0;
+    g.line16 = 5 * g.pitch + g.skew16;
+    g.board16 = (h + 2) * g.line16 + 5;
+    g.bpw = boards_per_workgroup(h, w, g.skew16);
+    g.plane = (g.bpw * g.board16 * 16 + 255) / 256 * 256;
     g.rm_off = 2 * g.plane > ROWS * ORS ? 2 * g.plane : ROWS * ORS;  // the epilogue reuses the image for the output tile
     g.lds_bytes = g.rm_off + RM_BYTES;
     return g;
@@ -720,7 +754,8 @@ void launch_board_conv_any(const BoardConvArgs &t, bool split, hipStream_t strea
     d.tpb = geo.tpb;
     d.bpw = geo.bpw;
     d.pitch = geo.pitch;
-    d.rpb = geo.rpb;
+    d.line16 = geo.line16;
+    d.board16 = geo.board16;
     d.plane = geo.plane;
     d.rm_off = geo.rm_off;
     d.cin = t.cin;
@@ -732,8 +767,9 @@ void launch_board_conv_any(const BoardConvArgs &t, bool split, hipStream_t strea
     (void)hipGetDevice(&dev);
     d.inv_tpb = (65536u + (unsigned)geo.tpb - 1) / (unsigned)geo.tpb;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
-    const unsigned nhb = 2 * (unsigned)geo.pitch + (unsigned)t.h + 1;
-    d.inv_nhb = (65536u + nhb - 1) / nhb;
+    const unsigned nhb = (unsigned)geo.line16 + 5 * ((unsigned)geo.pitch + 1) + 10 * (unsigned)t.h;  // halo slots per board and plane
+    d.inv_nhb = (unsigned)(((1ull << 32) + nhb - 1) / nhb);  // __umulhi(id, inv) == id / nhb for id * nhb < 2^32
+    d.inv_10 = (65536u + 9) / 10;
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_board_conv_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)kz_board_conv_split16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
