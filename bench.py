@@ -486,21 +486,26 @@ def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm, model_kw
 # "pre" = the generators computed the policy indices (move generation + lookups on their threads) and the GPU decodes;
 # "packed" = pre-packed boards and move lists: the channel and PCIe alone (what rounds 1-3 reported as `seam`).
 SEAM_CONFIGS = [
-    dict(name="hip.rs default (KZ_HIP_DECODE=device): move lists built on the executor thread at submit, softmax on the GPU; "
-              "one executor thread", work="real", gpu_threads=1, depth=3, device_decode=1),
+    dict(name="hip.rs default (KZ_HIP_DECODE=device, KZ_HIP_PREP_THREADS=1): encode_input and move lists at submit, shared "
+              "between the executor thread and one helper thread; gather + softmax inside the network's launch; one executor thread",
+         work="real", gpu_threads=1, depth=3, device_decode=1, helpers=1),
+    dict(name="the same without the helper thread (KZ_HIP_PREP_THREADS=0: all host work on the executor thread, as in round 4)",
+         work="real", gpu_threads=1, depth=3, device_decode=1, helpers=0),
     dict(name="KZ_HIP_DECODE=host (the reference's decode_output on the executor thread), one executor thread", work="real",
-         gpu_threads=1, depth=3, device_decode=0),
-    dict(name="KZ_HIP_DECODE=host, gpu_threads_per_device = 4", work="real", gpu_threads=4, depth=2, device_decode=0),
+         gpu_threads=1, depth=3, device_decode=0, helpers=0),
+    dict(name="KZ_HIP_DECODE=host, gpu_threads_per_device = 4", work="real", gpu_threads=4, depth=2, device_decode=0, helpers=0),
     dict(name="policy indices computed by the generators and carried in the job, decode on the GPU, one executor thread",
-         work="pre", gpu_threads=1, depth=3, device_decode=1),
+         work="pre", gpu_threads=1, depth=3, device_decode=1, helpers=0),
     dict(name="channel and PCIe alone (pre-packed boards and move lists: what rounds 1-3 reported)", work="packed",
-         gpu_threads=1, depth=3, device_decode=0),
+         gpu_threads=1, depth=3, device_decode=0, helpers=0),
 ]
 
 
 def bench_executor_exe():
     exe = os.path.join(REPO, "tests", "cpp", "build", "bench_executor")
     srcs = [os.path.join(REPO, "tests", "cpp", n) for n in ("bench_executor.cpp", "bench_chess.hpp")]
+    host = os.path.join(REPO, "kzero_amd", "csrc", "host")
+    srcs += [os.path.join(host, n) for n in sorted(os.listdir(host)) if n.endswith(".hpp")]  # (rebuilt when the mirror changes)
     lib_dir = os.path.join(REPO, "kzero_amd")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(x) for x in srcs):
         os.makedirs(os.path.dirname(exe), exist_ok=True)
@@ -514,7 +519,7 @@ def seam_run(exe, model_path, seconds, cfg, dtype, devices):
     if len(devices) > 1:
         env["KZ_BENCH_FULL_AFFINITY"] = "1"  # (this process bound itself to ONE GPU's NUMA node; the child drives several)
     out = subprocess.run([exe, model_path, str(seconds), str(cfg["gpu_threads"]), "6", "256", "8", dtype, str(cfg["depth"]),
-                          str(cfg["device_decode"]), ",".join(str(d) for d in devices), cfg["work"]],
+                          str(cfg["device_decode"]), ",".join(str(d) for d in devices), cfg["work"], str(cfg.get("helpers", 0))],
                          capture_output=True, text=True, timeout=120, env=env)
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     if not rec["evals_per_s"] > 0:
@@ -527,6 +532,8 @@ def seam_run(exe, model_path, seconds, cfg, dtype, devices):
             # thread shows ~100 % CPU however little work it does)
             "executor_work_util": rec["executor_work_util"], "executor_work_util_max": rec["executor_work_util_max"],
             "executor_cpu_util": rec["executor_cpu_util"], "generator_cpu_util": rec["generator_cpu_util"],
+            "prep_helpers": rec.get("prep_helpers"), "helper_cpu_util": rec.get("helper_cpu_util"),
+            "helper_cpu_s_per_Meval": rec.get("helper_cpu_s_per_Meval"),
             "host_cpu_s_per_Meval": rec["host_cpu_s_per_Meval"], "executor_work_s_per_Meval": rec["executor_work_s_per_Meval"],
             "executor_cpu_s_per_Meval": rec["executor_cpu_s_per_Meval"], "generator_cpu_s_per_Meval": rec["generator_cpu_s_per_Meval"],
             "projection_8gpu": rec["projection_8gpu"], "devices": rec.get("devices"),
@@ -760,7 +767,7 @@ def main():
     if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
         out["seam"] = seam_record(blob, args.seam_seconds)
         # ... and at the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity -> split16 for this network)
-        out["seam_parity"] = seam_record(blob, args.seam_seconds, dtype="f32split16", configs=SEAM_CONFIGS[:2] + SEAM_CONFIGS[3:4])
+        out["seam_parity"] = seam_record(blob, args.seam_seconds, dtype="f32split16", configs=SEAM_CONFIGS[:3] + SEAM_CONFIGS[4:5])
     if world > 1:
         dist.barrier()  # every rank has closed its engines
         if args.is_default_line and not args.no_seam and not args.no_others:

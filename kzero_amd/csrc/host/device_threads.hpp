@@ -30,6 +30,9 @@ struct StartupSettings {
     size_t pipeline_depth = 1;
     // not in the reference: decode_output on the GPU instead of on the executor thread
     bool device_decode = false;
+    // not in the reference: helper threads per executor thread that share a batch's host work (encode_input, move lists)
+    // with it (HipNetwork::set_prep_helpers; hip.rs: KZ_HIP_PREP_THREADS, default 1)
+    size_t prep_helpers = 0;
 };
 
 struct DeviceSizing {
@@ -51,6 +54,8 @@ struct EvalCounters {
     std::atomic<uint64_t> executor_cpu_ns[MAX_EXECUTORS] = {};
     // ... of which inside the engine's wait calls (the HIP runtime polls: spinning, not work)
     std::atomic<uint64_t> executor_wait_ns[MAX_EXECUTORS] = {};
+    // CPU time of the executor thread's prep helpers (StartupSettings::prep_helpers)
+    std::atomic<uint64_t> helper_cpu_ns[MAX_EXECUTORS] = {};
 };
 
 // (has `wait_cpu_ns`: HipNetwork; the tests' fake networks do not)
@@ -58,6 +63,10 @@ template <class T, class = void>
 struct has_wait_cpu_ns : std::false_type {};
 template <class T>
 struct has_wait_cpu_ns<T, std::void_t<decltype(std::declval<const T &>().wait_cpu_ns)>> : std::true_type {};
+template <class T, class = void>
+struct has_prep_helpers : std::false_type {};
+template <class T>
+struct has_prep_helpers<T, std::void_t<decltype(std::declval<T &>().set_prep_helpers(size_t(0)))>> : std::true_type {};
 
 // Net: the network an executor thread builds from a graph, `Net(mapper, graph, max_batch, device, dtype)` with
 // evaluate_batch / submit_batch / wait_batch / set_device_decode / max_in_flight (HipNetwork<B, M>; the tests put a fake
@@ -101,6 +110,7 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
             auto load = [=](Graph g) {
                 Net net(mapper, std::move(g), gpu_batch_size, device, dtype);
                 net.set_device_decode(device_decode);
+                if constexpr (has_prep_helpers<Net>::value) net.set_prep_helpers(startup.prep_helpers);
                 return net;
             };
             auto count = [=](size_t n, const Net &net) {
@@ -110,6 +120,7 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
                     if (local_id < EvalCounters::MAX_EXECUTORS) {
                         counters->executor_cpu_ns[local_id] = thread_cpu_ns();
                         if constexpr (has_wait_cpu_ns<Net>::value) counters->executor_wait_ns[local_id] = net.wait_cpu_ns;
+                        if constexpr (has_prep_helpers<Net>::value) counters->helper_cpu_ns[local_id] = net.helper_cpu_ns();
                     }
                 }
             };

@@ -2,10 +2,16 @@
 // kzero_amd/rust/hip.rs.  Same shape as `CudaNetwork` (rust/kz-core/src/network/cudnn.rs:18-88): encode every board
 // with the mapper, run the engine, decode the outputs.  Talks to the product only through the C ABI.
 #pragma once
+#include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <iterator>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <type_traits>
 
 #include <time.h>
@@ -35,6 +41,71 @@ inline uint64_t thread_cpu_ns() {
 inline void kz_check(int rc) {
     if (rc != 0) throw std::runtime_error(std::string("kzhip: ") + kz_last_error());  // the reference panics
 }
+
+// One persistent helper thread that runs a job handed over by its owner while the owner does its own share of the same
+// work (HipNetwork::prepare: half of a batch's board encoding and move-list building each).  start() hands over, finish()
+// waits and re-throws what the job threw.  Not part of the reference: its executor thread does all of a batch's host work
+// alone (cudnn.rs:55-87), which at 500k evals/s per GPU is most of a core.
+class PrepHelper {
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::exception_ptr err_;
+    std::thread th_;
+
+    void run() {
+        std::unique_lock<std::mutex> l(m_);
+        for (;;) {
+            cv_.wait(l, [&] { return quit_ || job_; });
+            if (quit_) return;
+            std::function<void()> j = std::move(job_);
+            job_ = nullptr;
+            l.unlock();
+            std::exception_ptr err;
+            try {
+                j();
+            } catch (...) {
+                err = std::current_exception();
+            }
+            cpu_ns = thread_cpu_ns();
+            l.lock();
+            err_ = err;
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+
+  public:
+    std::atomic<uint64_t> cpu_ns{0};  // CPU time of the helper thread so far (measurement)
+    PrepHelper() : th_([this] { run(); }) {}
+    PrepHelper(const PrepHelper &) = delete;
+    ~PrepHelper() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void start(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            job_ = std::move(job);
+            busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    void finish() {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return !busy_; });
+        if (err_) {
+            std::exception_ptr e = err_;
+            err_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+};
 
 // the `Arc<Graph>` of the reference: immutable, shared by every executor
 class HipModel {
@@ -73,31 +144,88 @@ class HipNetwork : public Network<B> {
     std::vector<int64_t> move_offsets_[KZ_ENGINE_SLOTS];
     std::vector<int32_t> move_indices_;
 
-    // move_to_index of every available move of the batch, as CSR (common.rs:77-86 up to the gather)
-    void build_move_lists(const B *boards, size_t n, std::vector<int64_t> &offsets) {
-        const size_t policy_len = mapper_.policy_len();
-        offsets.assign(1, 0);
-        move_indices_.clear();
-        for (size_t bi = 0; bi < n; bi++) {
+    // ---- a batch's host work before the launch: encode_input of every board (cudnn.rs:61-64) and, with the decode on the
+    // device, move_to_index of every available move as CSR (common.rs:77-86 up to the gather).  The batch is cut into
+    // 1 + helpers contiguous ranges; this thread takes the first, a PrepHelper each of the others; the ranges meet in the
+    // staging vectors in board order.
+    struct PrepRange {
+        std::vector<float> scalars;
+        std::vector<int64_t> counts;   // moves per board
+        std::vector<int32_t> indices;
+    };
+    std::vector<PrepRange> ranges_ = std::vector<PrepRange>(1);
+    std::vector<std::unique_ptr<PrepHelper>> helpers_;
+
+    void prep_range(const B *boards, size_t lo, size_t hi, bool moves, PrepRange &out) {
+        const size_t bool_count = input_bool_len(mapper_), bits_bytes = (bool_count + 7) / 8, policy_len = mapper_.policy_len();
+        out.scalars.clear();
+        out.counts.clear();
+        out.indices.clear();
+        BitBuffer buffer(bool_count);
+        for (size_t bi = lo; bi < hi; bi++) {
+            buffer.clear();
+            mapper_.encode_input(buffer, out.scalars, boards[bi]);
+            if (buffer.len() != bool_count) throw std::logic_error("mapper wrote the wrong number of bools");
+            std::copy(buffer.storage().begin(), buffer.storage().begin() + bits_bytes, bits_.begin() + bi * bits_bytes);
+            if (!moves) continue;
+            const size_t before = out.indices.size();
+            bool carried = false;
             if constexpr (has_policy_indices<B>::value) {
                 if (const std::vector<int32_t> *idx = boards[bi].policy_indices()) {
                     for (int32_t index : *idx)
                         if (index < 0 || (size_t)index >= policy_len) throw std::out_of_range("policy index out of range");
-                    move_indices_.insert(move_indices_.end(), idx->begin(), idx->end());
-                    offsets.push_back((int64_t)move_indices_.size());
-                    continue;
+                    out.indices.insert(out.indices.end(), idx->begin(), idx->end());
+                    carried = true;
                 }
             }
-            auto moves = boards[bi].available_moves();
-            if (moves)
-                for (const auto &mv : *moves) {
-                    const size_t index = mapper_.move_to_index(boards[bi], mv);
-                    if (index >= policy_len) throw std::out_of_range("move_to_index out of range");
-                    move_indices_.push_back((int32_t)index);
-                }
-            offsets.push_back((int64_t)move_indices_.size());
+            if (!carried) {
+                auto available = boards[bi].available_moves();
+                if (available)
+                    for (const auto &mv : *available) {
+                        const size_t index = mapper_.move_to_index(boards[bi], mv);
+                        if (index >= policy_len) throw std::out_of_range("move_to_index out of range");
+                        out.indices.push_back((int32_t)index);
+                    }
+            }
+            out.counts.push_back((int64_t)(out.indices.size() - before));
         }
     }
+
+    // returns bits_bytes; fills bits_, scalars_in_ and (moves) offsets + move_indices_
+    size_t prepare(const B *boards, size_t n, bool moves, std::vector<int64_t> *offsets) {
+        const size_t parts = std::min(ranges_.size(), std::max<size_t>(1, n / 16));  // (a handful of boards: not worth a hand-over)
+        auto cut = [&](size_t k) { return n * k / parts; };
+        for (size_t k = 1; k < parts; k++)
+            helpers_[k - 1]->start([this, boards, moves, k, lo = cut(k), hi = cut(k + 1)] { prep_range(boards, lo, hi, moves, ranges_[k]); });
+        std::exception_ptr first;
+        try {
+            prep_range(boards, 0, cut(1), moves, ranges_[0]);
+        } catch (...) {
+            first = std::current_exception();
+        }
+        for (size_t k = 1; k < parts; k++) {  // every helper is waited for, whatever happened: the boards are the caller's
+            try {
+                helpers_[k - 1]->finish();
+            } catch (...) {
+                if (!first) first = std::current_exception();
+            }
+        }
+        if (first) std::rethrow_exception(first);
+        scalars_in_.clear();
+        if (moves) {
+            offsets->assign(1, 0);
+            move_indices_.clear();
+        }
+        for (size_t k = 0; k < parts; k++) {
+            const PrepRange &r = ranges_[k];
+            scalars_in_.insert(scalars_in_.end(), r.scalars.begin(), r.scalars.end());
+            if (!moves) continue;
+            move_indices_.insert(move_indices_.end(), r.indices.begin(), r.indices.end());
+            for (int64_t c : r.counts) offsets->push_back(offsets->back() + c);
+        }
+        return (input_bool_len(mapper_) + 7) / 8;
+    }
+
     // values [n,5] (already tanh / softmax) + probabilities parallel to the move lists -> evaluations
     static std::vector<ZeroEvaluation> assemble_decoded(size_t n, const std::vector<int64_t> &offsets, const float *values,
                                                         const float *probs) {
@@ -108,19 +236,6 @@ class HipNetwork : public Network<B> {
             out[bi].policy.assign(probs + offsets[bi], probs + offsets[bi + 1]);
         }
         return out;
-    }
-
-    size_t encode_into_staging(const B *boards, size_t n) {
-        const size_t bool_count = input_bool_len(mapper_), bits_bytes = (bool_count + 7) / 8;
-        scalars_in_.clear();
-        BitBuffer buffer(bool_count);
-        for (size_t bi = 0; bi < n; bi++) {
-            buffer.clear();
-            mapper_.encode_input(buffer, scalars_in_, boards[bi]);
-            if (buffer.len() != bool_count) throw std::logic_error("mapper wrote the wrong number of bools");
-            std::copy(buffer.storage().begin(), buffer.storage().begin() + bits_bytes, bits_.begin() + bi * bits_bytes);
-        }
-        return bits_bytes;
     }
 
   public:
@@ -143,7 +258,8 @@ class HipNetwork : public Network<B> {
     HipNetwork(HipNetwork &&o) noexcept
         : mapper_(o.mapper_), model_(std::move(o.model_)), engine_(o.engine_), max_batch_size_(o.max_batch_size_),
           bits_(std::move(o.bits_)), scalars_in_(std::move(o.scalars_in_)), next_slot_(o.next_slot_),
-          oldest_slot_(o.oldest_slot_), in_flight_(o.in_flight_), device_decode_(o.device_decode_), wait_cpu_ns(o.wait_cpu_ns) {
+          oldest_slot_(o.oldest_slot_), in_flight_(o.in_flight_), device_decode_(o.device_decode_), ranges_(std::move(o.ranges_)),
+          helpers_(std::move(o.helpers_)), wait_cpu_ns(o.wait_cpu_ns) {
         for (int i = 0; i < KZ_ENGINE_SLOTS; i++) {
             pending_boards_[i] = std::move(o.pending_boards_[i]);
             move_offsets_[i] = std::move(o.move_offsets_[i]);
@@ -162,14 +278,28 @@ class HipNetwork : public Network<B> {
         device_decode_ = on;
     }
 
+    // Helper threads for a batch's host work (encode_input, move lists): 0 = all of it on the calling executor thread like
+    // the reference; 1 (hip.rs's default) halves what the executor thread does per batch.  Results are identical.
+    void set_prep_helpers(size_t n) {
+        if (in_flight_ != 0) throw std::logic_error("set_prep_helpers while batches are in flight");
+        helpers_.clear();
+        for (size_t i = 0; i < n; i++) helpers_.push_back(std::make_unique<PrepHelper>());
+        ranges_.assign(n + 1, PrepRange{});
+    }
+    // CPU time the helper threads have used so far (measurement)
+    uint64_t helper_cpu_ns() const {
+        uint64_t t = 0;
+        for (const auto &h : helpers_) t += h->cpu_ns.load();
+        return t;
+    }
+
     // cudnn.rs:55-87
     std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
         if (n > max_batch_size_) throw std::invalid_argument("batch_size <= max_batch_size");  // assert!, :58
         if (n == 0) return {};
         if (in_flight_ != 0) throw std::logic_error("evaluate_batch while submitted batches are in flight");
-        const size_t bits_bytes = encode_into_staging(boards, n);
+        const size_t bits_bytes = prepare(boards, n, device_decode_, &move_offsets_[0]);
         if (device_decode_) {
-            build_move_lists(boards, n, move_offsets_[0]);
             const float *values = nullptr, *probs = nullptr;
             kz_check(kz_engine_submit_packed_decoded(engine_, 0, bits_.data(), bits_bytes, scalars_in_.data(), (int)n,
                                                      move_offsets_[0].data(), move_indices_.data()));
@@ -196,10 +326,9 @@ class HipNetwork : public Network<B> {
     void submit_batch(B *boards, size_t n) {
         if (n == 0 || n > max_batch_size_) throw std::invalid_argument("0 < batch_size <= max_batch_size");
         if (in_flight_ == KZ_ENGINE_SLOTS) throw std::logic_error("every engine slot is in flight");
-        const size_t bits_bytes = encode_into_staging(boards, n);
+        const size_t bits_bytes = prepare(boards, n, device_decode_, &move_offsets_[next_slot_]);
         // the engine copies its inputs to pinned staging before submit returns (include/kz_hip.h)
         if (device_decode_) {
-            build_move_lists(boards, n, move_offsets_[next_slot_]);
             kz_check(kz_engine_submit_packed_decoded(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(),
                                                      (int)n, move_offsets_[next_slot_].data(), move_indices_.data()));
             pending_boards_[next_slot_].clear();  // the move lists are all the decode needs

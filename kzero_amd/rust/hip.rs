@@ -15,7 +15,11 @@
 //!    chess 20x256 f16, ONE executor thread, move generation + a SipHash lookup per move on it): host decode
 //!    257-350k evals/s box to box (the thread is the bottleneck: 3.2-3.9 CPU-s per million evaluations), device decode
 //!    404-505k with the thread working 0.8-0.9 of a core, the GPU alone 482-527k.  `KZ_HIP_DECODE=host` keeps the reference's own `decode_output` call (bit-identical softmax; set
-//!    gpu_threads_per_device >= 4 with it for a 256-channel chess network in f16).
+//!    gpu_threads_per_device >= 4 with it for a 256-channel chess network in f16).  Since round 5 the gather + softmax is
+//!    the last step of the network's own launch (one launch per batch, no copy operations: 532k) and
+//!  * a batch's host work before the launch (`encode_input` of every board, `move_to_index` of every available move) is
+//!    shared with `KZ_HIP_PREP_THREADS` scoped helper threads (default 1: the executor thread does half of it), so that
+//!    one executor thread per GPU keeps up on a slow host core too: `prepare` below.
 //!
 //! NOT compiled in this repository's CI (no cargo in the build image); written against the cited signatures.
 
@@ -232,7 +236,54 @@ pub struct HipNetwork<B: Board, M: BoardMapper<B>> {
     device_decode: bool,
     move_offsets: Vec<i64>,
     move_indices: Vec<i32>,
+    /// `KZ_HIP_PREP_THREADS` (default 1) + 1 ranges of a batch, each prepared by one thread (`prepare`)
+    ranges: Vec<PrepRange>,
     ph: PhantomData<B>,
+}
+
+/// What one thread prepares for its contiguous range of a batch's boards.
+#[derive(Default)]
+struct PrepRange {
+    scalars: Vec<f32>,
+    /// available moves per board
+    counts: Vec<i64>,
+    /// `move_to_index` of every available move, board after board
+    indices: Vec<i32>,
+}
+
+/// `encode_input` of the boards of one range into `bits` (that range's part of the staging) and `out.scalars`, and — with
+/// the decode on the device — `move_to_index` of every available move (what decode_output computes per board,
+/// common.rs:77-81, hoisted in front of the evaluation).
+fn prep_range<B: Board, M: BoardMapper<B>>(mapper: M, boards: &[&B], bits: &mut [u8], with_moves: bool, out: &mut PrepRange) {
+    let bool_count = mapper.input_bool_len();
+    let bits_bytes = (bool_count + 7) / 8;
+    let policy_len = mapper.policy_len();
+    out.scalars.clear();
+    out.counts.clear();
+    out.indices.clear();
+    let mut buffer = BitBuffer::new(bool_count);
+    for (bi, &board) in boards.iter().enumerate() {
+        buffer.clear();
+        // packed encode: exactly what BinaryOutput stores per position (binary_output.rs:210-256)
+        mapper.encode_input(&mut buffer, &mut out.scalars, board);
+        assert_eq!(bool_count, buffer.len());
+        bits[bi * bits_bytes..(bi + 1) * bits_bytes].copy_from_slice(buffer.storage());
+        if !with_moves {
+            continue;
+        }
+        let before = out.indices.len();
+        // `available_moves()` is an InternalIterator behind a Result (Err = the game is over: no moves, an empty
+        // policy — decode_output's `map_or(vec![], ..)`, common.rs:77)
+        if let Ok(moves) = board.available_moves() {
+            let indices = &mut out.indices;
+            moves.for_each(|mv| {
+                let index = mapper.move_to_index(board, mv);
+                assert!(index < policy_len);
+                indices.push(index as i32);
+            });
+        }
+        out.counts.push((out.indices.len() - before) as i64);
+    }
 }
 
 // one engine per executor thread; it is moved into that thread once (executor.rs:320-342)
@@ -274,32 +325,58 @@ impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
             },
             move_offsets: vec![],
             move_indices: vec![],
+            ranges: {
+                let helpers: usize = match std::env::var("KZ_HIP_PREP_THREADS") {
+                    Err(_) => 1,
+                    Ok(v) => v.parse().unwrap_or_else(|_| panic!("KZ_HIP_PREP_THREADS must be a number, got '{}'", v)),
+                };
+                (0..helpers + 1).map(|_| PrepRange::default()).collect()
+            },
             ph: PhantomData,
         }
     }
 
-    /// `move_to_index` of every available move of every board, as CSR lists (what decode_output computes per board,
-    /// common.rs:77-81, hoisted in front of the evaluation): `move_offsets[b]..move_offsets[b + 1]` of `move_indices`.
-    fn build_move_lists(&mut self, boards: &[impl Borrow<B>]) {
+    /// A batch's host work before the launch — `encode_input` of every board (cudnn.rs:61-64) and, with the decode on the
+    /// device, the CSR move lists `move_offsets[b]..move_offsets[b + 1]` of `move_indices` — cut into contiguous ranges:
+    /// this thread prepares the first, a scoped helper thread each of the others (a thread spawn is ~15 us against the
+    /// ~250 us half a chess batch of 256 takes); the ranges meet in the staging vectors in board order.  Returns
+    /// bits_bytes.  Same results as one thread doing it all.
+    fn prepare(&mut self, boards: &[impl Borrow<B>], with_moves: bool) -> usize {
         let mapper = self.mapper;
-        let policy_len = mapper.policy_len();
-        let (offsets, indices) = (&mut self.move_offsets, &mut self.move_indices);
-        offsets.clear();
-        offsets.push(0);
-        indices.clear();
-        for board in boards {
-            let board = board.borrow();
-            // `available_moves()` is an InternalIterator behind a Result (Err = the game is over: no moves, an empty
-            // policy — decode_output's `map_or(vec![], ..)`, common.rs:77)
-            if let Ok(moves) = board.available_moves() {
-                moves.for_each(|mv| {
-                    let index = mapper.move_to_index(board, mv);
-                    assert!(index < policy_len);
-                    indices.push(index as i32);
-                });
+        let bits_bytes = (mapper.input_bool_len() + 7) / 8;
+        // (`impl Borrow<B>` says nothing about threads; `&B` is Send + Sync because `Board` is)
+        let refs: Vec<&B> = boards.iter().map(|b| b.borrow()).collect();
+        let n = refs.len();
+        let parts = self.ranges.len().min((n / 16).max(1)); // a handful of boards: not worth a spawn
+        let cut = |k: usize| n * k / parts;
+        let (first, rest) = self.ranges.split_at_mut(1);
+        let (bits_first, mut bits_rest) = self.bits[..n * bits_bytes].split_at_mut(cut(1) * bits_bytes);
+        std::thread::scope(|scope| {
+            for (k, range) in rest[..parts - 1].iter_mut().enumerate() {
+                let (lo, hi) = (cut(k + 1), cut(k + 2));
+                let (mine, tail) = std::mem::take(&mut bits_rest).split_at_mut((hi - lo) * bits_bytes);
+                bits_rest = tail;
+                let part = &refs[lo..hi];
+                scope.spawn(move || prep_range(mapper, part, mine, with_moves, range));
             }
-            offsets.push(indices.len() as i64);
+            prep_range(mapper, &refs[..cut(1)], bits_first, with_moves, &mut first[0]);
+            // (the scope joins the helpers; a panic in one of them — `move_to_index` asserts — propagates here)
+        });
+        self.scalars_in.clear();
+        self.move_offsets.clear();
+        self.move_offsets.push(0);
+        self.move_indices.clear();
+        for range in &self.ranges[..parts] {
+            self.scalars_in.extend_from_slice(&range.scalars);
+            if with_moves {
+                self.move_indices.extend_from_slice(&range.indices);
+                for &c in &range.counts {
+                    self.move_offsets.push(self.move_offsets.last().unwrap() + c);
+                }
+            }
         }
+        assert_eq!(self.scalars_in.len(), n * mapper.input_scalar_count());
+        bits_bytes
     }
 
     /// values [n, 5] (tanh / softmax already applied on the device) + probabilities parallel to the move lists
@@ -318,31 +395,14 @@ impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
             .collect()
     }
 
-    /// packed encode: exactly what BinaryOutput stores per position (binary_output.rs:210-256)
-    fn encode_into_staging(&mut self, boards: &[impl Borrow<B>]) -> usize {
-        let bool_count = self.mapper.input_bool_len();
-        let bits_bytes = (bool_count + 7) / 8;
-        self.scalars_in.clear();
-        let mut buffer = BitBuffer::new(bool_count);
-        for (bi, board) in boards.iter().enumerate() {
-            buffer.clear();
-            self.mapper.encode_input(&mut buffer, &mut self.scalars_in, board.borrow());
-            assert_eq!(bool_count, buffer.len());
-            self.bits[bi * bits_bytes..(bi + 1) * bits_bytes].copy_from_slice(buffer.storage());
-        }
-        assert_eq!(self.scalars_in.len(), boards.len() * self.mapper.input_scalar_count());
-        bits_bytes
-    }
-
     /// Asynchronous pair for `pipelined_executor_loop` (executor_pipelined.rs): encode, hand the batch to the engine
     /// and return while the GPU works.  At most `KZ_ENGINE_SLOTS` batches in flight.
     pub fn submit_batch(&mut self, boards: Vec<B>) {
         assert!(!boards.is_empty() && boards.len() <= self.max_batch_size);
         assert!(self.pending.len() < KZ_ENGINE_SLOTS, "every engine slot is in flight");
-        let bits_bytes = self.encode_into_staging(&boards);
+        let bits_bytes = self.prepare(&boards, self.device_decode);
         let slot = self.next_slot;
         if self.device_decode {
-            self.build_move_lists(&boards);
             check(unsafe {
                 kz_engine_submit_packed_decoded(
                     self.engine,
@@ -415,10 +475,9 @@ impl<B: Board, M: BoardMapper<B>> Network<B> for HipNetwork<B, M> {
         }
 
         assert!(self.pending.is_empty(), "evaluate_batch while submitted batches are in flight");
-        let bits_bytes = self.encode_into_staging(boards);
+        let bits_bytes = self.prepare(boards, self.device_decode);
 
         if self.device_decode {
-            self.build_move_lists(boards);
             check(unsafe {
                 kz_engine_submit_packed_decoded(
                     self.engine,

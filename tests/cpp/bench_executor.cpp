@@ -4,7 +4,8 @@
 // collector (`real` evals/s, collector.rs:172-191).  Not a test: a measurement of the host side next to bench.py.
 //
 //   bench_executor <model.kzm|onnx> <seconds> <gpu_threads> <generator_threads> [gpu_batch] [search_batch] [dtype] [depth]
-//                  [device_decode] [devices] [work]
+//                  [device_decode] [devices] [work] [prep_helpers]
+//   prep_helpers = helper threads per executor thread sharing a batch's encode_input + move lists with it (hip.rs default 1)
 //   depth = batches each executor thread keeps in flight (1 = batched_executor_loop, 2 = pipelined_executor_loop)
 //   devices = comma-separated device ordinals (default "0"): ONE process, a thread set (executors + generators) per device —
 //             the topology of selfplay_start (rust/kz-selfplay/src/server/server.rs:323-331); gpu_threads and
@@ -121,10 +122,11 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
     std::this_thread::sleep_for(std::chrono::milliseconds(500));
     const size_t nd = a.devices.size(), ne = std::min(st.gpu_threads_per_device, EvalCounters::MAX_EXECUTORS);
     std::vector<uint64_t> r0(nd), p0(nd), g0(n_gen);
-    std::vector<std::vector<uint64_t>> e0(nd, std::vector<uint64_t>(ne)), w0(nd, std::vector<uint64_t>(ne));
+    std::vector<std::vector<uint64_t>> e0(nd, std::vector<uint64_t>(ne)), w0(nd, std::vector<uint64_t>(ne)), h0(nd, std::vector<uint64_t>(ne));
     for (size_t i = 0; i < nd; i++) {
         r0[i] = per_device[i].real, p0[i] = per_device[i].potential;
-        for (size_t k = 0; k < ne; k++) e0[i][k] = per_device[i].executor_cpu_ns[k], w0[i][k] = per_device[i].executor_wait_ns[k];
+        for (size_t k = 0; k < ne; k++)
+            e0[i][k] = per_device[i].executor_cpu_ns[k], w0[i][k] = per_device[i].executor_wait_ns[k], h0[i][k] = per_device[i].helper_cpu_ns[k];
     }
     for (size_t i = 0; i < n_gen; i++) g0[i] = gen_cpu[i];
     const double cpu0 = process_cpu_s();
@@ -139,8 +141,8 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double cpu_s = process_cpu_s() - cpu0;
-    std::string exec_util, exec_work, gen_util, per, devs_json;
-    double exec_cpu_total = 0, exec_max = 0, gen_cpu_total = 0, exec_work_total = 0, exec_work_max = 0;
+    std::string exec_util, exec_work, gen_util, per, devs_json, helper_util;
+    double exec_cpu_total = 0, exec_max = 0, gen_cpu_total = 0, exec_work_total = 0, exec_work_max = 0, helper_total = 0;
     for (size_t i = 0; i < nd; i++)
         for (size_t k = 0; k < ne; k++) {
             const double u = (per_device[i].executor_cpu_ns[k] - e0[i][k]) * 1e-9 / dt;
@@ -155,6 +157,10 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
             exec_util += buf;
             std::snprintf(buf, sizeof buf, "%s%.3f", exec_work.empty() ? "" : ", ", wk);
             exec_work += buf;
+            const double hu = (per_device[i].helper_cpu_ns[k] - h0[i][k]) * 1e-9 / dt;  // all helpers of this executor thread
+            helper_total += hu * dt;
+            std::snprintf(buf, sizeof buf, "%s%.3f", helper_util.empty() ? "" : ", ", hu);
+            helper_util += buf;
         }
     for (size_t i = 0; i < n_gen; i++) {
         const double u = (gen_cpu[i] - g0[i]) * 1e-9 / dt;
@@ -183,7 +189,8 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
                 "\"concurrent_games\": %zu, \"gpu_batch\": %zu, \"search_batch\": %zu, \"pipeline_depth\": %zu, \"device_decode\": %d, "
                 "\"seconds\": %.2f, \"devices\": [%s], \"per_device_evals_per_s\": [%s], \"work\": \"%s\", \"dtype\": \"%s\", "
                 "\"executor_cpu_util\": [%s], \"executor_cpu_util_max\": %.3f, \"executor_work_util\": [%s], "
-                "\"executor_work_util_max\": %.3f, \"generator_cpu_util\": [%s], "
+                "\"executor_work_util_max\": %.3f, \"prep_helpers\": %zu, \"helper_cpu_util\": [%s], \"helper_cpu_s_per_Meval\": %.3f, "
+                "\"generator_cpu_util\": [%s], "
                 "\"host_cpu_s_per_Meval\": %.3f, \"executor_cpu_s_per_Meval\": %.3f, \"executor_work_s_per_Meval\": %.3f, "
                 "\"generator_cpu_s_per_Meval\": %.3f, "
                 "\"projection_8gpu\": {\"evals_per_s\": %.0f, \"cores_needed\": %.1f, \"cores_per_numa_node\": [%s], "
@@ -191,7 +198,7 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
                 evals_s, (double)real / (double)(potential ? potential : 1), st.gpu_threads_per_device, a.generators,
                 sizing.concurrent_games, st.gpu_batch_size, st.search_batch_size, st.pipeline_depth, (int)st.device_decode, dt,
                 devs_json.c_str(), per.c_str(), a.work.c_str(), a.dtype_name.c_str(), exec_util.c_str(), exec_max, exec_work.c_str(),
-                exec_work_max, gen_util.c_str(), cpu_s / mevals, exec_cpu_total / mevals, exec_work_total / mevals, gen_cpu_total / mevals,
+                exec_work_max, st.prep_helpers, helper_util.c_str(), helper_total / mevals, gen_util.c_str(), cpu_s / mevals, exec_cpu_total / mevals, exec_work_total / mevals, gen_cpu_total / mevals,
                 8 * per_dev_rate, 8 * cores_per_device, numa.c_str(),
                 8 * per_dev_rate * (in_bytes + out_bytes) / 1e9, per_dev_rate * (in_bytes + out_bytes) / 1e9);
     std::fflush(stdout);
@@ -205,7 +212,7 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
 int main(int argc, char **argv) {
     if (argc < 5) {
         std::fprintf(stderr, "usage: %s model seconds gpu_threads generator_threads [gpu_batch] [search_batch] [f16|f32|f32split16] "
-                             "[depth] [device_decode] [devices] [packed|real|pre]\n", argv[0]);
+                             "[depth] [device_decode] [devices] [packed|real|pre] [prep_helpers]\n", argv[0]);
         return 2;
     }
     Args a;
@@ -231,6 +238,7 @@ int main(int argc, char **argv) {
         if (a.devices.empty()) a.devices.push_back(0);
     }
     if (argc > 11) a.work = argv[11];
+    if (argc > 12) a.st.prep_helpers = (size_t)atoi(argv[12]);
     // (the executor and generator threads of a device belong next to it: a launcher that pinned this process to one NUMA
     // node for its own GPU passes KZ_BENCH_FULL_AFFINITY=1 when the child drives several devices)
     if (const char *full = getenv("KZ_BENCH_FULL_AFFINITY"); full && full[0] == '1') {

@@ -210,6 +210,38 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < y1.size(); i++) CHECK(close_eval(y1[i], expect[2 + i], 1e-4f));
     }
     {
+        // prep helpers (set_prep_helpers: a batch's encode_input and move lists shared with helper threads): the same
+        // evaluations, bit for bit, with 0, 1 and 3 helpers, host and device decode, blocking and pipelined; 70 boards so
+        // that every range holds several
+        std::vector<PackedBoard> many;
+        for (size_t i = 0; i < 70; i++) many.push_back(boards[(i * 5 + i / 3) % boards.size()]);
+        auto same = [](const std::vector<ZeroEvaluation> &a, const std::vector<ZeroEvaluation> &b) {
+            if (a.size() != b.size()) return false;
+            for (size_t i = 0; i < a.size(); i++)
+                if (!close_eval(a[i], b[i], 0.0f)) return false;
+            return true;
+        };
+        for (bool dev : {false, true}) {
+            Net ref(mapper, model_a, 128, 0, KZ_DTYPE_F32);
+            ref.set_device_decode(dev);
+            const auto want = ref.evaluate_batch(many.data(), many.size());
+            CHECK(want.size() == many.size());
+            for (size_t helpers : {size_t(1), size_t(3)}) {
+                Net net(mapper, model_a, 128, 0, KZ_DTYPE_F32);
+                net.set_device_decode(dev);
+                net.set_prep_helpers(helpers);
+                CHECK(same(net.evaluate_batch(many.data(), many.size()), want));
+                auto copy = many;
+                net.submit_batch(copy.data(), 40);
+                net.submit_batch(copy.data() + 40, copy.size() - 40);
+                auto y0 = net.wait_batch(), y1 = net.wait_batch();
+                y0.insert(y0.end(), y1.begin(), y1.end());
+                CHECK(same(y0, want));
+                CHECK(net.helper_cpu_ns() > 0);
+            }
+        }
+    }
+    {
         auto [pclient, pserver] = job_pair<PackedBoard, ZeroEvaluation>(16);
         auto [gtx, grx] = bounded<std::optional<std::shared_ptr<const HipModel>>>(1);
         std::atomic<long> pevals{0};

@@ -1052,8 +1052,44 @@ static void test_multiplexed_generators() {
     }
 }
 
+// ---- PrepHelper (hip_network.hpp): the helper thread that shares a batch's host work with the executor thread ----
+static void test_prep_helper() {
+    {
+        PrepHelper h;  // destroyed idle, never used
+    }
+    PrepHelper h;
+    std::vector<int> out(1000, 0);
+    for (int round = 0; round < 200; round++) {  // the owner fills one half while the helper fills the other
+        h.start([&out, round] {
+            for (size_t i = 500; i < 1000; i++) out[i] = round + (int)i;
+        });
+        for (size_t i = 0; i < 500; i++) out[i] = round + (int)i;
+        h.finish();
+        bool ok = true;
+        for (size_t i = 0; i < 1000; i++) ok &= out[i] == round + (int)i;
+        CHECK(ok);
+    }
+    h.finish();  // nothing in flight: returns at once
+    // what the job throws comes out of finish(), once; the helper stays usable
+    h.start([] { throw std::out_of_range("move_to_index out of range"); });
+    bool caught = false;
+    try {
+        h.finish();
+    } catch (const std::out_of_range &e) {
+        caught = std::string(e.what()) == "move_to_index out of range";
+    }
+    CHECK(caught);
+    h.finish();
+    int x = 0;
+    h.start([&x] { x = 7; });
+    h.finish();
+    CHECK(x == 7);
+    CHECK(h.cpu_ns.load() > 0);
+}
+
 int main(int argc, char **argv) {
     const std::string golden = argc > 1 ? argv[1] : "tests/golden";
+    std::fputs("prep helper\n", stderr); test_prep_helper();
     std::fputs("bitbuffer\n", stderr); test_bitbuffer();
     std::fputs("mappers\n", stderr); test_mappers();
     std::fputs("decode\n", stderr); test_decode();

@@ -32,7 +32,7 @@ for key in ("seam", "seam_parity", "seam_one_process"):
             print(" ", key, run["config"], "ERROR", run["error"])
             continue
         p = run["projection_8gpu"]
-        print(f"  {key} [{run['config']}] {run['value']:.0f} evals/s fill {run['fill']} executor work util {run['executor_work_util']} (cpu {run['executor_cpu_util']}) "
+        print(f"  {key} [{run['config']}] {run['value']:.0f} evals/s fill {run['fill']} executor work util {run['executor_work_util']} (cpu {run['executor_cpu_util']}) helpers {run.get('helper_cpu_util')} "
               f"generators {run['generator_cpu_util']} host cpu s/Meval {run['host_cpu_s_per_Meval']} | x8: {p['cores_needed']} cores "
               f"of {p['cores_per_numa_node']} per node, {p['pcie_GBps']} GB/s PCIe")
 if "cpu_baseline" in r: print("cpu", r["cpu_baseline"]["value"], "cores", r["cpu_baseline"]["cores"], r["cpu_baseline"].get("error", ""), "| a0:", r["cpu_baseline"].get("a0"))
