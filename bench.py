@@ -600,12 +600,21 @@ def fake_main(args, benchlib, rank, local_rank, world, dist):
         print(err, file=sys.stderr)
         return 3
 
+    # KZ_FAKE_SYSFS=<dir> (with kfd/, pci/, node/, dri/ below it): the NUMA lookup a real rank does before its first HIP
+    # call, on a fake topology (never applied: the test process keeps its affinity)
+    numa = {"bus_id": None, "numa_node": None, "cpus": None, "bound": False}
+    fake_sysfs = os.environ.get("KZ_FAKE_SYSFS")
+    if fake_sysfs:
+        numa = benchlib.bind_to_gpu_numa(device, kfd_root=os.path.join(fake_sysfs, "kfd"), pci_root=os.path.join(fake_sysfs, "pci"),
+                                         node_root=os.path.join(fake_sysfs, "node"), dri_root=os.path.join(fake_sysfs, "dri"), apply=False)
+
     def step(i):
         time.sleep(args.fake_step * 1e-3 * (1 + rank))  # (rank r is r+1 times slower: the per-rank lines must show it)
     own = []
     regions = benchlib.run_timed_regions(step, lambda: None, args.steps, args.warmup, args.repeats, dist, owns=own)
     elapsed = benchlib.median_region(regions)
-    per_rank = benchlib.gather_objects(dist, {"rank": rank, "device": device, "bus_id": seen[rank],
+    per_rank = benchlib.gather_objects(dist, {"rank": rank, "device": device, "bus_id": numa["bus_id"] or seen[rank],
+                                              "numa_node": numa["numa_node"], "numa_bound": numa["bound"], "host_cpus": numa["cpus"],
                                               "evals_s": round(args.steps / benchlib.median_region(own), 3)})
     if rank == 0:
         print(json.dumps({"metric": "fake steps/sec (launcher test)", "value": round(args.steps * world / elapsed, 3),

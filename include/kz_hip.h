@@ -45,6 +45,7 @@ extern "C" {
 #define KZ_POLICY_CONV 1       /* ConvPolicyHead,      post_act.py:54-88 */
 #define KZ_POLICY_ATTENTION 2  /* AttentionPolicyHead, post_act.py:115-141 */
 #define KZ_POLICY_DENSE 3      /* DensePolicyHead,     post_act.py:26-51 */
+#define KZ_POLICY_ARIMAA 4     /* ArimaaPolicyHead,    post_act.py:144-173 (the server's arimaa-split game, server.rs:174) */
 
 typedef struct kz_model kz_model;
 typedef struct kz_engine kz_engine;

@@ -1,4 +1,4 @@
-// mapping.hpp — board -> tensor encoding (rust/kz-core/src/mapping/{mod.rs, bit_buffer.rs, chess.rs, ataxx.rs, go.rs}).
+// mapping.hpp — board -> tensor encoding (rust/kz-core/src/mapping/{mod.rs, bit_buffer.rs, chess.rs, ataxx.rs, go.rs, ttt.rs, sttt.rs}).
 //
 // Game rules live in the ext `board-game` crate on the Rust side; this mirror defines the mappers over plain position
 // records that carry exactly what the mappers read (bitboards, counters, the list of available moves).
@@ -317,6 +317,56 @@ struct AtaxxStdMapper {
         const int fx = tx + ATAXX_FROM_DX_DY[from_index][0], fy = ty + ATAXX_FROM_DX_DY[from_index][1];
         if (fx < 0 || fx >= size || fy < 0 || fy >= size) return std::nullopt;
         return AtaxxMove{AtaxxMove::Jump, fx, fy, tx, ty};
+    }
+};
+
+// --------------------------------------------------------------------------------------------------------------
+// Tic-tac-toe and super tic-tac-toe (ttt.rs:9-59, sttt.rs:7-55): the server's `Game::TTT` / `Game::STTT`
+// (rust/kz-selfplay/src/server/server.rs:114-137).  Tiles in the board-game crate's own coordinate order (`Coord3::all()`
+// / `Coord::all()`: index 0..8 / o 0..80), which is also the policy index of a move.
+// (`Game::ArimaaSplit`'s mapper, arimaa.rs:15-139, is not mirrored: its plane and policy order is that of `Piece::ALL`,
+// `Direction::ALL` and `Square::index` of the ext crate arimaa_engine_step, which is not in the reference tree; the
+// NETWORK side — 38 input planes, ArimaaPolicyHead — is complete: KZ_POLICY_ARIMAA.)
+// --------------------------------------------------------------------------------------------------------------
+template <int N>
+struct TilesPosition {  // N = 9 (ttt) or 81 (sttt)
+    using Move = int;   // Coord3::index() / Coord::o()
+    std::array<uint8_t, N> next{}, other{};  // tile == Some(next_player()) / Some(next_player().other())
+    std::array<uint8_t, N> available{};      // sttt only: is_available_move(c).unwrap_or(false) (all zero on a done board)
+    std::optional<std::vector<int>> moves;
+    std::optional<std::vector<int>> available_moves() const { return moves; }
+};
+using TTTPosition = TilesPosition<9>;
+using STTTPosition = TilesPosition<81>;
+
+struct TTTStdMapper {
+    std::array<size_t, 3> input_bool_shape() const { return {2, 3, 3}; }  // ttt.rs:13-15
+    size_t input_scalar_count() const { return 0; }                       // :17-19
+    size_t policy_len() const { return 9; }                               // :28-30 ([1, 3, 3])
+    void encode_input(BitBuffer &bools, std::vector<float> &, const TTTPosition &b) const {  // :21-24
+        for (int i = 0; i < 9; i++) bools.push(b.next[i] != 0);
+        for (int i = 0; i < 9; i++) bools.push(b.other[i] != 0);
+    }
+    size_t move_to_index(const TTTPosition &, int mv) const { return (size_t)mv; }  // :32-34
+    std::optional<int> index_to_move(const TTTPosition &, size_t index) const {    // :36-39
+        if (index >= 9) throw std::out_of_range("policy index");
+        return (int)index;
+    }
+};
+
+struct STTTStdMapper {
+    std::array<size_t, 3> input_bool_shape() const { return {3, 9, 9}; }  // sttt.rs:11-13
+    size_t input_scalar_count() const { return 0; }                       // :15-17
+    size_t policy_len() const { return 81; }                              // :28-30 ([1, 9, 9])
+    void encode_input(BitBuffer &bools, std::vector<float> &, const STTTPosition &b) const {  // :19-24
+        for (int i = 0; i < 81; i++) bools.push(b.next[i] != 0);
+        for (int i = 0; i < 81; i++) bools.push(b.other[i] != 0);
+        for (int i = 0; i < 81; i++) bools.push(b.available[i] != 0);  // a done board: no available moves
+    }
+    size_t move_to_index(const STTTPosition &, int mv) const { return (size_t)mv; }  // :32-34
+    std::optional<int> index_to_move(const STTTPosition &, size_t index) const {     // :36-39 (asserts index < 256: a u8)
+        if (index >= 256) throw std::out_of_range("policy index");
+        return (int)index;
     }
 };
 

@@ -116,4 +116,72 @@ class RandomSymmetryNetwork : public Network<B> {
     }
 };
 
+// symmetry.rs:150-184: values summed and divided by the symmetry count; every available move's probability averaged over
+// the symmetries (the probability the mapped board's evaluation gives the mapped move)
+template <class B>
+ZeroEvaluation average_evals(const B &board, const B *mapped_boards, const ZeroEvaluation *mapped_evals, int n_sym) {
+    ZeroEvaluation out;
+    const float n = (float)n_sym;
+    for (int k = 0; k < n_sym; k++) {  // fold(default, a + b) / n (:156-160)
+        const ZeroValuesPov &v = mapped_evals[k].values;
+        out.values.value += v.value;
+        out.values.wdl.win += v.wdl.win;
+        out.values.wdl.draw += v.wdl.draw;
+        out.values.wdl.loss += v.wdl.loss;
+        out.values.moves_left += v.moves_left;
+    }
+    out.values.value /= n;
+    out.values.wdl.win /= n;
+    out.values.wdl.draw /= n;
+    out.values.wdl.loss /= n;
+    out.values.moves_left /= n;
+    const size_t policy_len = n_sym ? mapped_evals[0].policy.size() : 0;
+    out.policy.assign(policy_len, 0.0f);
+    if (policy_len > 0) {
+        const auto board_moves = board.available_moves();
+        for (int k = 0; k < n_sym; k++) {
+            const auto mapped_moves = mapped_boards[k].available_moves();
+            for (size_t i = 0; i < board_moves->size(); i++) {
+                const auto mapped_mv = board.map_move(k, (*board_moves)[i]);
+                auto it = std::find(mapped_moves->begin(), mapped_moves->end(), mapped_mv);
+                if (it == mapped_moves->end()) throw std::logic_error("mapped move not available on the mapped board");
+                out.policy[i] += mapped_evals[k].policy[(size_t)(it - mapped_moves->begin())] / n;
+            }
+        }
+    }
+    return out;
+}
+
+// symmetry.rs:70-124: averages values and policy over ALL symmetries of every board; re-batches to the inner network's
+// max_batch_size, so its own is unbounded
+template <class B, class N>
+class AverageSymmetryNetwork : public Network<B> {
+    N inner_;
+
+  public:
+    explicit AverageSymmetryNetwork(N inner) : inner_(std::move(inner)) {}
+    size_t max_batch_size() const override { return (size_t)-1; }  // usize::MAX (:88-92)
+    N &inner() { return inner_; }
+    std::vector<ZeroEvaluation> evaluate_batch(const B *boards, size_t n) override {
+        if (B::symmetry_is_unit()) return inner_.evaluate_batch(boards, n);  // :95-98
+        const int n_sym = B::symmetry_count();
+        std::vector<B> mapped;
+        mapped.reserve(n * (size_t)n_sym);
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < n_sym; k++) mapped.push_back(boards[i].map(k));
+        std::vector<ZeroEvaluation> mapped_evals;
+        mapped_evals.reserve(mapped.size());
+        const size_t chunk = inner_.max_batch_size();
+        for (size_t lo = 0; lo < mapped.size(); lo += chunk) {  // mapped_boards.chunks(inner.max_batch_size()) (:108-113)
+            auto y = inner_.evaluate_batch(mapped.data() + lo, std::min(chunk, mapped.size() - lo));
+            for (auto &e : y) mapped_evals.push_back(std::move(e));
+        }
+        std::vector<ZeroEvaluation> out;
+        out.reserve(n);
+        for (size_t i = 0; i < n; i++)
+            out.push_back(average_evals(boards[i], mapped.data() + i * n_sym, mapped_evals.data() + i * n_sym, n_sym));
+        return out;
+    }
+};
+
 }  // namespace kz::host

@@ -37,6 +37,8 @@ struct DeviceWeights {
     float *sh_w0 = nullptr, *sh_b0 = nullptr, *sh_w1 = nullptr, *sh_b1 = nullptr, *sh_w2 = nullptr, *sh_b2 = nullptr;
     float *sh_w1t = nullptr;  // sh_w1 transposed: [inputs][outputs]
     float *sh_w0x = nullptr;  // [hc + 1][C]: the scalar head's 1x1 filters followed by ConvPolicyHead's extra-move filter
+    // ArimaaPolicyHead's scalar branch (post_act.py:155-162), laid out like the scalar head's
+    float *pa_w0 = nullptr, *pa_b0 = nullptr, *pa_w1 = nullptr, *pa_b1 = nullptr, *pa_w2 = nullptr, *pa_b2 = nullptr, *pa_w1t = nullptr;
     // policy
     DevConv p_conv0;                                   // conv / ataxx_conv / dense hidden conv
     float *p_w1 = nullptr, *p_b1 = nullptr;            // last 1x1 conv of the conv heads
@@ -361,6 +363,19 @@ struct DeviceWeights {
                     }
                 }
                 break;
+            case kz::POLICY_ARIMAA: {
+                // bulk: the conv policy heads' pair of 1x1 convolutions with four planes; the scalar branch: a second ScalarHead
+                if (upload_conv(m.p_conv0, p_conv0)) return 1;
+                if (upload_f32(m.p_conv1.w, &p_w1) || upload_f32(m.p_conv1.b, &p_b1)) return 1;
+                if (upload_f32(m.pa_conv.w, &pa_w0) || upload_f32(m.pa_conv.b, &pa_b0) || upload_f32(m.pa_fc0.w, &pa_w1) ||
+                    upload_f32(m.pa_fc0.b, &pa_b1) || upload_f32(m.pa_fc1.w, &pa_w2) || upload_f32(m.pa_fc1.b, &pa_b2))
+                    return 1;
+                std::vector<float> wt((size_t)m.pa_fc0.in * m.pa_fc0.out);
+                for (int o = 0; o < m.pa_fc0.out; o++)
+                    for (int i = 0; i < m.pa_fc0.in; i++) wt[(size_t)i * m.pa_fc0.out + o] = m.pa_fc0.w[(size_t)o * m.pa_fc0.in + i];
+                if (upload_f32(wt, &pa_w1t)) return 1;
+                break;
+            }
             case kz::POLICY_ATTENTION:
                 if (upload_conv(m.p_bulk, p_bulk) || upload_conv(m.p_under, p_under)) return 1;
                 if (upload(m.flat_to_att.data(), m.flat_to_att.size() * 4, (void **)&flat_to_att)) return 1;

@@ -574,6 +574,26 @@ struct kz_engine {
                 }
                 break;
             }
+            case kz::POLICY_ARIMAA: {
+                // ArimaaPolicyHead (post_act.py:144-173): policy = concat(scalar(common) [1 + 6], flatten(bulk(common)) [4 * hw])
+                const DevConv &c0 = wts->p_conv0;
+                if (conv(c0, x, cp, head0, c0.cout_p, M, 1, nullptr, false, m.h, m.w, hw, hw, 0)) return 1;
+                kz::PolicyConvArgs a{head0, c0.cout_p, batch, hw, m.channels, 4, wts->p_w1, wts->p_b1,
+                                     d_policy + 7, m.policy_len, 0};  // (the four planes start behind the seven scalars)
+                prof.begin("kz_policy_conv", stream);
+                kz::launch_policy_conv(dtype, a, stream);
+                prof.end(stream);
+                // the scalar branch has the ScalarHead's shape: the same kernel, seven outputs into the policy rows
+                kz::ScalarHeadArgs sa{x, cp, batch, hw, m.channels, m.arimaa_hidden_channels, m.arimaa_hidden_size,
+                                      wts->pa_w0, wts->pa_b0, wts->pa_w1, wts->pa_b1, wts->pa_w2, wts->pa_b2, d_policy,
+                                      nullptr, 0, wts->pa_w1t};
+                sa.n_out = 7;
+                sa.out_ld = m.policy_len;
+                prof.begin("kz_scalar_head", stream);
+                kz::launch_scalar_head(dtype, sa, stream);
+                prof.end(stream);
+                break;
+            }
             case kz::POLICY_ATTENTION: {
                 // bulk = conv_bulk(common) on all 64 squares; under = conv_under(common[:, :, 7, None, :]) on the
                 // 8 squares of rank index 7 (post_act.py:128-129): source rows 56..63 of each board
@@ -869,6 +889,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
     const DeviceWeights &w = *e->wts;
     if (!e->fused_heads) switch (m.policy_kind) {
         case kz::POLICY_ATAXX_CONV:
+        case kz::POLICY_ARIMAA:
         case kz::POLICY_CONV: h0 = rows * w.p_conv0.cout_p; break;
         case kz::POLICY_ATTENTION:
             h0 = rows * w.p_bulk.cout_p;

@@ -496,6 +496,7 @@ struct ScalarHeadDev {
     const float *w0x, *pe_bc, *pe_wl, *pe_bl;
     float *policy;
     int policy_len, policy_offset;
+    int n_out, out_ld;
 };
 
 template <typename T>
@@ -574,11 +575,11 @@ __global__ __launch_bounds__(256) void kz_scalar_head(ScalarHeadDev a) {
         }
     }
     __syncthreads();
-    for (int j = wave; j < 5; j += 4) {
+    for (int j = wave; j < a.n_out; j += 4) {
         float acc = 0.0f;
         for (int i = lane; i < a.hs; i += 64) acc += a.w2[j * a.hs + i] * hid[i];
         acc = wave_sum(acc);
-        if (lane == 0) a.out[(size_t)b * 5 + j] = acc + a.b2[j];
+        if (lane == 0) a.out[(size_t)b * a.out_ld + j] = acc + a.b2[j];
     }
     if (a.extra) {  // Linear(hw -> extra) behind the policy planes (sext is complete since the first barrier)
         for (int j = wave; j < a.extra; j += 4) {
@@ -601,7 +602,7 @@ void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream) 
     const bool extra = a.extra > 0 && a.w0x && scalar_head_takes_extra(dtype, a.ldx, a.hc);
     ScalarHeadDev d{a.x, a.ldx, a.batch, a.hw, a.c, a.hc, a.hs, a.w0, a.b0, a.w1, a.b1, a.w2, a.b2, a.out,
                     a.nonfinite_flag, a.epoch, a.w1t, extra ? a.extra : 0, a.w0x, a.pe_bc, a.pe_wl, a.pe_bl, a.policy,
-                    a.policy_len, a.policy_offset};
+                    a.policy_len, a.policy_offset, a.n_out, a.out_ld};
     size_t shmem = sizeof(float) * ((size_t)a.hc * a.hw + a.hs + (extra ? a.hw : 0));
     if (dtype == 0) kz_scalar_head<float><<<a.batch, 256, shmem, stream>>>(d);
     else kz_scalar_head<h16><<<a.batch, 256, shmem, stream>>>(d);

@@ -71,6 +71,10 @@ struct ScalarHeadArgs {
     const float *w0x = nullptr, *pe_bc = nullptr, *pe_wl = nullptr, *pe_bl = nullptr;
     float *policy = nullptr;
     int policy_len = 0, policy_offset = 0;
+    // the last Linear's width and the output's row stride: 5 and 5 for the ScalarHead; ArimaaPolicyHead's scalar branch
+    // (post_act.py:155-162: the same Conv1x1 + ReLU, Flatten, Linear + ReLU, Linear chain with 1 + 6 outputs) runs through
+    // the same kernel with n_out = 7 and out = the policy rows (out_ld = policy_len)
+    int n_out = 5, out_ld = 5;
 };
 bool scalar_head_takes_extra(int dtype, int ldx, int hc);  // the launch below can carry ScalarHeadArgs::extra
 void launch_scalar_head(int dtype, const ScalarHeadArgs &a, hipStream_t stream);

@@ -243,6 +243,13 @@ void finalize_model(Model &m) {
             lin(m.p_fc0);
             lin(m.p_fc1);
             break;
+        case POLICY_ARIMAA:
+            conv(m.p_conv0, hw);
+            conv(m.p_conv1, hw);
+            conv(m.pa_conv, hw);
+            lin(m.pa_fc0);
+            lin(m.pa_fc1);
+            break;
     }
     m.flops_per_eval = 2.0 * macs;
     if (m.param_count == 0) m.param_count = params;
@@ -296,6 +303,7 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
     else if (kind->second == "conv") m->policy_kind = POLICY_CONV;
     else if (kind->second == "attention") m->policy_kind = POLICY_ATTENTION;
     else if (kind->second == "dense") m->policy_kind = POLICY_DENSE;
+    else if (kind->second == "arimaa") m->policy_kind = POLICY_ARIMAA;
     else {
         err = "unknown policy_kind '" + kind->second + "'";
         return nullptr;
@@ -407,6 +415,23 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
             macs += (double)m->policy_len * size;
             break;
         }
+        case POLICY_ARIMAA: {  // ArimaaPolicyHead(game, channels, hidden_channels, hidden_size) (post_act.py:144-173)
+            int hc = m->arimaa_hidden_channels = L.geti_in("policy_arimaa_hidden_channels", 0, 1, 4096, true);
+            int hs = m->arimaa_hidden_size = L.geti_in("policy_arimaa_hidden_size", 0, 1, 1 << 20, true);
+            if (L.ok && m->policy_len != 1 + 6 + 4 * hw) {
+                err = "arimaa head: policy_len != 1 + 6 + 4*h*w";
+                return nullptr;
+            }
+            if (!L.ok) return nullptr;
+            m->policy_conv_channels = 4;
+            m->p_conv0 = L.conv("policy_head.bulk.0", C, C, 1);
+            m->p_conv1 = L.conv("policy_head.bulk.2", 4, C, 1);
+            m->pa_conv = L.conv("policy_head.scalar.0", hc, C, 1);
+            m->pa_fc0 = L.linear("policy_head.scalar.3", hs, hc * hw);
+            m->pa_fc1 = L.linear("policy_head.scalar.5", 7, hs);
+            macs += (double)hw * C * C + (double)hw * 4 * C + (double)hw * hc * C + (double)hs * hc * hw + 7.0 * hs;
+            break;
+        }
     }
     if (!L.ok) return nullptr;
     m->param_count = L.params;
@@ -471,6 +496,11 @@ Model *pad_channels(const Model &m, int cpad) {
             if (m.dense_hidden_channels) o->p_conv0 = widen(m.p_conv0, m.p_conv0.cout, cpad);
             else if (m.dense_hidden_size) o->p_fc0 = widen_flat(m.p_fc0, cpad * hw);
             else o->p_fc1 = widen_flat(m.p_fc1, cpad * hw);
+            break;
+        case POLICY_ARIMAA:
+            o->p_conv0 = widen(m.p_conv0, cpad, cpad);
+            o->p_conv1 = widen(m.p_conv1, m.p_conv1.cout, cpad);
+            o->pa_conv = widen(m.pa_conv, m.pa_conv.cout, cpad);
             break;
     }
     (void)C;

@@ -19,7 +19,7 @@ struct Linear {  // nn.Linear, weights [out][in]
     std::vector<float> w, b;
 };
 
-enum PolicyKind { POLICY_ATAXX_CONV = 0, POLICY_CONV = 1, POLICY_ATTENTION = 2, POLICY_DENSE = 3 };
+enum PolicyKind { POLICY_ATAXX_CONV = 0, POLICY_CONV = 1, POLICY_ATTENTION = 2, POLICY_DENSE = 3, POLICY_ARIMAA = 4 };
 
 struct Model {
     // architecture descriptor
@@ -30,6 +30,7 @@ struct Model {
     PolicyKind policy_kind = POLICY_CONV;
     int policy_conv_channels = 0, policy_extra_moves = 0, policy_query_channels = 0;
     int dense_hidden_channels = 0, dense_hidden_size = 0;
+    int arimaa_hidden_channels = 0, arimaa_hidden_size = 0;  // ArimaaPolicyHead's scalar branch (post_act.py:155-162)
 
     // ResTower (post_act.py:201-211): tower[0] = stem; tower[2i-1], tower[2i] = block i conv A / conv B,
     // each with its BatchNorm folded (W' = s*W, b' = s*b + t).  The tower's final BatchNorm stays a per-channel
@@ -49,6 +50,10 @@ struct Model {
     Conv p_bulk, p_under;        // attention
     std::vector<int32_t> flat_to_att;
     Linear p_fc0, p_fc1;         // dense: optional hidden Linear, final Linear
+    // arimaa (ArimaaPolicyHead, post_act.py:144-173): bulk = p_conv0 (C -> C) + ReLU + p_conv1 (C -> 4), flattened channel-major
+    // BEHIND the scalar branch's 1 + 6 outputs: pa_conv (C -> hc) + ReLU, Flatten, pa_fc0 (hc*hw -> hs) + ReLU, pa_fc1 (hs -> 7)
+    Conv pa_conv;
+    Linear pa_fc0, pa_fc1;
 
     int64_t param_count = 0;
     double flops_per_eval = 0;

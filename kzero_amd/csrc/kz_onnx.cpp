@@ -1003,6 +1003,26 @@ Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err) 
             const OTensor &scale = M.constant(dv.in[1]);
             if (scale.f.size() != 1 || std::fabs(scale.f[0] - std::sqrt((float)Q)) > 1e-4f * std::sqrt((float)Q))
                 fail("attention head: logits must be divided by sqrt(query_channels)");
+        } else if (p->op == "Concat" && p->attr_i("axis", 0) == 1 && p->in.size() == 2 && M.producer(p->in[0], "Gemm") &&
+                   M.producer(p->in[1], "Flatten")) {
+            // ArimaaPolicyHead (post_act.py:144-173): concat([scalar(common), flatten(bulk(common), 1)])
+            //   scalar = Conv1x1(C->hc), ReLU, Flatten, Linear(hc*hw -> hs), ReLU, Linear(hs -> 1 + 6);  bulk = Conv1x1(C->C), ReLU, Conv1x1(C->4)
+            m->policy_kind = POLICY_ARIMAA;
+            const ONode &g2 = M.expect_producer(p->in[0], "Gemm");
+            const ONode &r = M.expect_producer(g2.in[0], "Relu");
+            const ONode &g1 = M.expect_producer(r.in[0], "Gemm");
+            const ONode &fl = M.expect_producer(g1.in[0], "Flatten");
+            if (!M.relu_conv1x1(fl.in[0], t, m->pa_conv)) fail("arimaa head: expected Conv1x1 + ReLU on the tower output");
+            m->pa_fc0 = M.gemm(g1);
+            m->pa_fc1 = M.gemm(g2);
+            conv_stack(p->in[1], m->p_conv0, m->p_conv1);
+            m->policy_conv_channels = m->p_conv1.cout;
+            m->arimaa_hidden_channels = m->pa_conv.cout;
+            m->arimaa_hidden_size = m->pa_fc0.out;
+            if (m->pa_fc0.in != m->pa_conv.cout * hw || m->pa_fc1.in != m->pa_fc0.out || m->pa_fc1.out != 7 || m->p_conv1.cout != 4 ||
+                m->p_conv0.cout != C)
+                fail("arimaa head shapes");
+            m->policy_len = 7 + 4 * hw;
         } else if (p->op == "Concat" && p->attr_i("axis", 0) == 1 && p->in.size() == 2) {
             const ONode *tail = M.producer(p->in[1]);
             if (!tail) fail("policy: dangling Concat input");

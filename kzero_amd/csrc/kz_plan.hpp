@@ -49,6 +49,7 @@ int head_launches(const Model &m, int dtype, bool split16, int cp) {
             break;
         }
         case kz::POLICY_ATTENTION: n += 3; break;
+        case kz::POLICY_ARIMAA: n += 3; break;  // bulk: two 1x1 convolutions; the scalar branch through kz_scalar_head
         case kz::POLICY_DENSE: n += (m.dense_hidden_channels ? 1 : 0) + (m.dense_hidden_size ? 2 : 1); break;
     }
     return n;

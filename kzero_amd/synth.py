@@ -24,6 +24,10 @@ GAMES = {
     "ataxx-6": dict(size=6, n_scalar=1, n_bool=3, policy_len=17 * 36 + 1, p_bool=0.3),
     "go-19": dict(size=19, n_scalar=6, n_bool=7, policy_len=1 + 361, p_bool=0.25),   # go.rs:46-113 (territory on)
     "go-9": dict(size=9, n_scalar=6, n_bool=7, policy_len=1 + 81, p_bool=0.25),
+    # the other games the server dispatches (rust/kz-selfplay/src/server/server.rs:114-185)
+    "ttt": dict(size=3, n_scalar=0, n_bool=2, policy_len=9, p_bool=0.3),              # ttt.rs:13-24
+    "sttt": dict(size=9, n_scalar=0, n_bool=3, policy_len=81, p_bool=0.3),            # sttt.rs:11-26
+    "arimaa-split": dict(size=8, n_scalar=12, n_bool=26, policy_len=1 + 6 + 256, p_bool=0.04),  # arimaa.rs:15-83
 }
 
 
@@ -87,7 +91,8 @@ def _bn(rng, t, prefix, c):
 def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0, query_channels: int = None,
                  n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0,
                  dense_hidden_channels: int = None, dense_hidden_size: int = None, scalar_hidden_channels: int = 4,
-                 final_affine: bool = True, init: str = "uniform") -> bytes:
+                 final_affine: bool = True, init: str = "uniform", arimaa_hidden_channels: int = 2,
+                 arimaa_hidden_size: int = 32) -> bytes:
     """`block_gain` > 1 scales every block's second BatchNorm weight: the residual stream then grows from block to block
     the way a trained network's does (a random-init tower keeps it within a few tens).
     `init`: "uniform" = PyTorch's default for Conv2d / Linear (U(+-1/sqrt(fan_in))); "kaiming_normal" = convolution weights
@@ -99,13 +104,15 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
     _INIT = init
     try:
         return _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
-                             dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine)
+                             dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine,
+                             arimaa_hidden_channels, arimaa_hidden_size)
     finally:
         _INIT = "uniform"
 
 
 def _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
-                  dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine) -> bytes:
+                  dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine,
+                  arimaa_hidden_channels, arimaa_hidden_size) -> bytes:
     g = game_spec(game)
     size, n_scalar = g["size"], g["n_scalar"]
     n_bool = g["n_bool"] if n_bool is None else n_bool
@@ -128,6 +135,9 @@ def _random_model(game, depth, channels, head, seed, query_channels, n_bool, sca
     elif game.startswith("chess-hist-"):
         t["common.tower.0.weight"][:, 6] *= 0.01  # the 50-move counter (chess.rs:54)
         t["common.tower.0.weight"][:, 7:n_scalar] *= 0.5  # 1 + repetitions per board (chess.rs:86-87)
+    elif game == "arimaa-split":
+        t["common.tower.0.weight"][:, 10] *= 0.25  # history_len, move_number: raw counters (arimaa.rs:81-82)
+        t["common.tower.0.weight"][:, 11] *= 0.02
     for i in range(1, depth + 1):
         _conv(rng, t, f"common.tower.{i}.seq.0", C, C, 3)
         _bn(rng, t, f"common.tower.{i}.seq.1", C)
@@ -173,6 +183,17 @@ def _random_model(game, depth, channels, head, seed, query_channels, n_bool, sca
             _linear(rng, t, f"policy_head.seq.{idx}", dense_hidden_size, size_in)
             size_in, idx = dense_hidden_size, idx + 2
         _linear(rng, t, f"policy_head.seq.{idx}", g["policy_len"], size_in)
+    elif head == "arimaa":
+        # ArimaaPolicyHead(game, channels, hidden_channels, hidden_size) (post_act.py:144-173)
+        if g["policy_len"] != 7 + 4 * hw:
+            raise ValueError("the arimaa head needs a game whose policy is 1 + 6 + 4 * squares (arimaa-split)")
+        meta["policy_arimaa_hidden_channels"] = arimaa_hidden_channels
+        meta["policy_arimaa_hidden_size"] = arimaa_hidden_size
+        _conv(rng, t, "policy_head.bulk.0", C, C, 1)
+        _conv(rng, t, "policy_head.bulk.2", 4, C, 1)
+        _conv(rng, t, "policy_head.scalar.0", arimaa_hidden_channels, C, 1)
+        _linear(rng, t, "policy_head.scalar.3", arimaa_hidden_size, arimaa_hidden_channels * hw)
+        _linear(rng, t, "policy_head.scalar.5", 7, arimaa_hidden_size)
     else:
         raise ValueError(f"unsupported synthetic head '{head}'")
     return write_model(meta, t)
@@ -199,6 +220,15 @@ def random_boards(game: str, batch: int, seed: int = 0, n_bool: int = None) -> T
                             *(1 + rng.integers(0, 3, size=batch) for _ in range(n_scalar - 7))], axis=1)
     elif game.startswith("ataxx"):
         scalars = rng.uniform(0, 1, size=(batch, 1))  # moves_since_last_copy / MAX (ataxx.rs:107-109)
+    elif n_scalar == 0:
+        scalars = np.zeros((batch, 0))  # ttt / sttt: no scalar planes (ttt.rs:17-19)
+    elif game == "arimaa-split":
+        # [place, play, pull, push, one-hot steps_taken x4, next == A, next == B, history_len, move_number] (arimaa.rs:63-82)
+        play = rng.integers(0, 2, size=batch)
+        steps = np.eye(4)[rng.integers(0, 4, size=batch)]
+        gold = rng.integers(0, 2, size=batch)
+        scalars = np.concatenate([np.stack([1 - play, play, np.zeros(batch), np.zeros(batch)], axis=1), steps,
+                                  np.stack([gold, 1 - gold, rng.integers(0, 4, size=batch), rng.integers(0, 60, size=batch)], axis=1)], axis=1)
     else:
         black = rng.integers(0, 2, size=batch)
         scalars = np.stack([black, 1 - black, np.zeros(batch), np.zeros(batch), np.full(batch, 7.5 / 15.0),

@@ -37,7 +37,7 @@ from torch import nn
 from lib.games import Game  # noqa: E402  (reference)
 from lib.model.post_act import (  # noqa: E402  (reference)
     PredictionHeads, ResTower, ScalarHead, AtaxxConvPolicyHead, AttentionPolicyHead, ConvPolicyHead,
-    DensePolicyHead, ResBlock,
+    DensePolicyHead, ResBlock, ArimaaPolicyHead,
 )
 
 from kzero_amd.model_file import write_model  # noqa: E402
@@ -75,6 +75,10 @@ def build(game_name, depth, channels, head_kind, input_bool_channels=None, **hea
         head = DensePolicyHead(game, channels, **head_args)
         meta["policy_dense_hidden_channels"] = head_args["hidden_channels"] or 0
         meta["policy_dense_hidden_size"] = head_args["hidden_size"] or 0
+    elif head_kind == "arimaa":
+        head = ArimaaPolicyHead(game, channels, **head_args)
+        meta["policy_arimaa_hidden_channels"] = head_args["hidden_channels"]
+        meta["policy_arimaa_hidden_size"] = head_args["hidden_size"]
     else:
         raise ValueError(head_kind)
     net = PredictionHeads(tower, scalar_head, head)
@@ -251,5 +255,22 @@ def main():
     gen_decode_kat()
 
 
+def main_round5():
+    """The other games the server dispatches (rust/kz-selfplay/src/server/server.rs:114-185), added in round 5 without
+    touching the fixtures above: arimaa-split through ArimaaPolicyHead (post_act.py:144-173; ArimaaSplitMapper: 26 bool +
+    12 scalar planes, policy 1 + 6 + 4*64), ttt (3x3) and sttt (9x9) through DensePolicyHead — their policy_shape is
+    (1, n, n), which ConvPolicyHead's assert (post_act.py:60) refuses."""
+    os.makedirs(OUT, exist_ok=True)
+    gen_net("arimaa_2x32", 11, 3, 0.05, onnx=True,
+            game_name="arimaa-split", depth=2, channels=32, head_kind="arimaa", hidden_channels=2, hidden_size=16)
+    gen_net("ttt_2x16_dense", 12, 4, 0.3, onnx=True,
+            game_name="ttt", depth=2, channels=16, head_kind="dense", hidden_channels=None, hidden_size=None)
+    gen_net("sttt_2x16_dense_h", 13, 3, 0.3, onnx=True,
+            game_name="sttt", depth=2, channels=16, head_kind="dense", hidden_channels=2, hidden_size=24)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "round5":
+        main_round5()
+    else:
+        main()

@@ -61,7 +61,8 @@ typedef struct kzo_net {
     int depth, channels, final_affine;
     int sh_channels, sh_size;
     int policy_len;
-    int policy_kind; /* 0 ataxx_conv, 1 conv, 2 attention, 3 dense */
+    int policy_kind; /* 0 ataxx_conv, 1 conv, 2 attention, 3 dense, 4 arimaa */
+    int arimaa_hidden_channels, arimaa_hidden_size;
     int policy_conv_channels, policy_extra_moves, policy_query_channels;
     int dense_hidden_channels, dense_hidden_size;
     float bn_eps;
@@ -228,6 +229,8 @@ KZO_EXPORT int kzo_load(const void *blob, size_t len, kzo_net **out) {
     net->policy_query_channels = (int)meta_int(net, "policy_query_channels", 0);
     net->dense_hidden_channels = (int)meta_int(net, "policy_dense_hidden_channels", 0);
     net->dense_hidden_size = (int)meta_int(net, "policy_dense_hidden_size", 0);
+    net->arimaa_hidden_channels = (int)meta_int(net, "policy_arimaa_hidden_channels", 0);
+    net->arimaa_hidden_size = (int)meta_int(net, "policy_arimaa_hidden_size", 0);
     const kzo_meta *eps = find_meta(net, "bn_eps");
     net->bn_eps = eps ? (float)(eps->kind == 1 ? eps->f : (double)eps->i) : 1e-5f;
     const kzo_meta *kind = find_meta(net, "policy_kind");
@@ -239,6 +242,7 @@ KZO_EXPORT int kzo_load(const void *blob, size_t len, kzo_net **out) {
     else if (!strcmp(kind->s, "conv")) net->policy_kind = 1;
     else if (!strcmp(kind->s, "attention")) net->policy_kind = 2;
     else if (!strcmp(kind->s, "dense")) net->policy_kind = 3;
+    else if (!strcmp(kind->s, "arimaa")) net->policy_kind = 4;
     else {
         kzo_free(net);
         return fail("unknown policy_kind");
@@ -549,6 +553,30 @@ static int forward_board(const kzo_net *net, const float *input, float *scalars_
                 att[i * 88 + j] = acc / scale;
             }
         for (int i = 0; i < net->policy_len; i++) policy_out[i] = att[flat_to_att[i]];
+    } else if (net->policy_kind == 4) {
+        /* ArimaaPolicyHead (post_act.py:144-173): policy = concat([scalar(common) [1 + 6], flatten(bulk(common), 1) [4*hw]])
+         * bulk = conv1x1 C->C, ReLU, conv1x1 C->4;  scalar = conv1x1 C->hc, ReLU, Flatten, Linear(hc*hw -> hs), ReLU, Linear(hs -> 7) */
+        const int hc = net->arimaa_hidden_channels, hs = net->arimaa_hidden_size;
+        convp b0, b2, s0;
+        if (hc <= 0 || hs <= 0 || 7 + 4 * hw != net->policy_len) { fail("arimaa head: bad descriptor"); goto done; }
+        if (get_conv(net, "policy_head.bulk.0", C, C, 1, &b0)) goto done;
+        if (get_conv(net, "policy_head.bulk.2", 4, C, 1, &b2)) goto done;
+        if (get_conv(net, "policy_head.scalar.0", hc, C, 1, &s0)) goto done;
+        const float *w3 = tensor_f32(net, "policy_head.scalar.3.weight", (uint64_t)hs * hc * hw);
+        const float *b3 = tensor_f32(net, "policy_head.scalar.3.bias", (uint64_t)hs);
+        const float *w5 = tensor_f32(net, "policy_head.scalar.5.weight", (uint64_t)7 * hs);
+        const float *b5 = tensor_f32(net, "policy_head.scalar.5.bias", 7);
+        if (!w3 || !b3 || !w5 || !b5) goto done;
+        conv2d(x, C, h, w, b0.w, b0.b, C, 1, t0);
+        relu(t0, (size_t)C * hw);
+        conv2d(t0, C, h, w, b2.w, b2.b, 4, 1, policy_out + 7);
+        head = malloc(sizeof(float) * ((size_t)hc * hw + (size_t)hs));
+        float *a = head, *hid = head + (size_t)hc * hw;
+        conv2d(x, C, h, w, s0.w, s0.b, hc, 1, a);
+        relu(a, (size_t)hc * hw);
+        linear(a, hc * hw, w3, b3, hs, hid);
+        relu(hid, (size_t)hs);
+        linear(hid, hs, w5, b5, 7, policy_out);
     } else {
         /* DensePolicyHead (post_act.py:26-51): [conv1x1 + ReLU] -> Flatten -> [Linear + ReLU] -> Linear(policy_size) */
         const int hc = net->dense_hidden_channels, hs = net->dense_hidden_size;

@@ -66,7 +66,8 @@ int main(int argc, char **argv) {
         o->depth != k->depth || o->channels != k->channels || o->policy_len != k->policy_len || o->policy_kind != k->policy_kind ||
         o->policy_conv_channels != k->policy_conv_channels || o->policy_extra_moves != k->policy_extra_moves ||
         o->policy_query_channels != k->policy_query_channels || o->dense_hidden_channels != k->dense_hidden_channels ||
-        o->dense_hidden_size != k->dense_hidden_size || o->tower.size() != k->tower.size())
+        o->dense_hidden_size != k->dense_hidden_size || o->arimaa_hidden_channels != k->arimaa_hidden_channels ||
+        o->arimaa_hidden_size != k->arimaa_hidden_size || o->tower.size() != k->tower.size())
         return bad("architecture descriptor");
     std::string msg;
     for (size_t i = 0; i < o->tower.size(); i++)
@@ -85,7 +86,8 @@ int main(int argc, char **argv) {
     if (!same(o->p_conv0, k->p_conv0, "p_conv0", msg) || !same(o->p_conv1, k->p_conv1, "p_conv1", msg) ||
         !same(o->p_extra_conv, k->p_extra_conv, "p_extra_conv", msg) || !same(o->p_extra_fc, k->p_extra_fc, "p_extra_fc", msg) ||
         !same(o->p_bulk, k->p_bulk, "p_bulk", msg) || !same(o->p_under, k->p_under, "p_under", msg) ||
-        !same(o->p_fc0, k->p_fc0, "p_fc0", msg) || !same(o->p_fc1, k->p_fc1, "p_fc1", msg))
+        !same(o->p_fc0, k->p_fc0, "p_fc0", msg) || !same(o->p_fc1, k->p_fc1, "p_fc1", msg) ||
+        !same(o->pa_conv, k->pa_conv, "pa_conv", msg) || !same(o->pa_fc0, k->pa_fc0, "pa_fc0", msg) || !same(o->pa_fc1, k->pa_fc1, "pa_fc1", msg))
         return bad(msg);
     if (o->flat_to_att != k->flat_to_att) return bad("flat_to_att");
     std::printf("models equal\n");

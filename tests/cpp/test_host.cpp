@@ -201,6 +201,52 @@ static void test_mappers() {
         for (size_t i = 0; i < ab.len(); i++) if (ab[i]) on.push_back((int)i);
         CHECK((on == std::vector<int>{6, 42, 49 + 0, 49 + 48, 98 + 24}));
         CHECK(as.size() == 1 && std::fabs(as[0] - 0.3f) < 1e-7f);
+        // TTTStdMapper / STTTStdMapper (ttt.rs:21-24, sttt.rs:19-24): plane order (mover, other[, available]), tiles in the
+        // crate's coordinate order; a move's policy index is its coordinate index; what test_valid_mapping
+        // (rust/kz-core/tests/mapper/mod.rs:13-30) checks: lengths, and every available move round-trips to itself with no
+        // two moves on one index
+        {
+            TTTStdMapper tm;
+            TTTPosition tp;
+            tp.next[0] = tp.next[4] = 1;
+            tp.other[8] = 1;
+            tp.moves = std::vector<int>{1, 2, 3, 5, 6, 7};
+            BitBuffer tb(input_bool_len(tm));
+            std::vector<float> ts;
+            tm.encode_input(tb, ts, tp);
+            CHECK(tb.len() == 18 && ts.empty() && input_full_shape(tm) == (std::array<size_t, 3>{2, 3, 3}));
+            std::vector<int> on;
+            for (size_t i = 0; i < tb.len(); i++) if (tb[i]) on.push_back((int)i);
+            CHECK((on == std::vector<int>{0, 4, 9 + 8}));
+            std::set<size_t> seen;
+            for (int mv : *tp.moves) {
+                const size_t idx = tm.move_to_index(tp, mv);
+                CHECK(idx < tm.policy_len() && seen.insert(idx).second && tm.index_to_move(tp, idx) == mv);
+            }
+            STTTStdMapper sm;
+            STTTPosition sp;
+            sp.next[40] = 1;
+            sp.other[0] = sp.other[80] = 1;
+            for (int i = 36; i < 45; i++) if (i != 40) sp.available[i] = 1;  // the centre macro board
+            sp.moves = std::vector<int>{36, 37, 38, 39, 41, 42, 43, 44};
+            BitBuffer sb(input_bool_len(sm));
+            sm.encode_input(sb, ts, sp);
+            CHECK(sb.len() == 243 && ts.empty() && sm.policy_len() == 81);
+            on.clear();
+            for (size_t i = 0; i < sb.len(); i++) if (sb[i]) on.push_back((int)i);
+            CHECK((on == std::vector<int>{40, 81, 81 + 80, 162 + 36, 162 + 37, 162 + 38, 162 + 39, 162 + 41, 162 + 42, 162 + 43, 162 + 44}));
+            seen.clear();
+            for (int mv : *sp.moves) {
+                const size_t idx = sm.move_to_index(sp, mv);
+                CHECK(idx < sm.policy_len() && seen.insert(idx).second && sm.index_to_move(sp, idx) == mv);
+            }
+            STTTPosition done;  // a finished game: no available plane bits, no moves, an empty policy
+            BitBuffer db(input_bool_len(sm));
+            sm.encode_input(db, ts, done);
+            bool any = false;
+            for (size_t i = 162; i < 243; i++) any |= db[i];
+            CHECK(!any && !done.available_moves().has_value());
+        }
         // Go 5x5 inside 9x9 planes, white (Player::B) to move after a black pass, komi 6.5 for black: planes = stones of
         // the player to move, stones of the other, in-board, ko/illegal, territory (mover, neither, other); scalars =
         // [black to move, white to move, pass_1, pass_2, komi from the mover's side / 15, multi-stone suicide] (go.rs:89-112)
@@ -885,6 +931,38 @@ static void test_symmetry(const std::string &golden_dir) {
     RandomSymmetryNetwork<AtaxxSymBoard, CoordNet> off(CoordNet{}, std::mt19937_64(3), false);  // disabled: passthrough
     auto ev = off.evaluate(b);
     CHECK(ev.policy[0] == (float)AtaxxStdMapper(7).move_to_index((*b.moves)[0]));
+
+    // AverageSymmetryNetwork (symmetry.rs:70-124, average_evals :150-184): entry i = the mean over all eight symmetries of
+    // what the inner network gives the image of move i on the mapped board; values averaged; more mapped boards (5 x 8)
+    // than the inner network's batch (a CoordNet of 16) are re-batched
+    struct SmallNet : CoordNet {
+        size_t calls = 0;
+        size_t max_batch_size() const override { return 16; }
+        std::vector<ZeroEvaluation> evaluate_batch(const AtaxxSymBoard *boards, size_t n) override {
+            calls++;
+            if (n > 16) throw std::invalid_argument("batch above max_batch_size");
+            return CoordNet::evaluate_batch(boards, n);
+        }
+    };
+    AverageSymmetryNetwork<AtaxxSymBoard, SmallNet> avg{SmallNet{}};
+    CHECK(avg.max_batch_size() == (size_t)-1);
+    std::vector<AtaxxSymBoard> five(5, b);
+    five[3].moves = std::nullopt;  // a finished game: an empty policy
+    five[3].tiles_next = 0b111;
+    auto evs = avg.evaluate_batch(five.data(), five.size());
+    CHECK(evs.size() == 5 && avg.inner().calls == 3);  // 40 mapped boards in chunks of 16
+    for (size_t k = 0; k < 5; k++) {
+        if (k == 3) {
+            CHECK(evs[k].policy.empty() && evs[k].values.value == 3);
+            continue;
+        }
+        CHECK(evs[k].values.value == 2 && evs[k].policy.size() == 4);
+        for (size_t i = 0; i < 4; i++) {
+            float want = 0;
+            for (int sym = 0; sym < 8; sym++) want += (float)AtaxxStdMapper(7).move_to_index(ataxx_map_move(7, sym, (*b.moves)[i])) / 8.0f;
+            CHECK(std::fabs(evs[k].policy[i] - want) <= 1e-4f * want);
+        }
+    }
 }
 
 // ---- per-device spawn (server.rs:323-331, server_alphazero.rs:89-121) over several devices, without a GPU: a fake network

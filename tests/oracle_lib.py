@@ -139,7 +139,9 @@ def read_packed(name, n_bool, n_scalar, h, w):
 
 
 GOLDEN_NETS = ["ataxx7_2x16", "ataxx7_4x64", "chess_2x32_att", "chess_2x32_dense_h", "chess_1x32_dense",
-               "go9_2x16_conv", "go9_2x16_conv_terr"]
+               "go9_2x16_conv", "go9_2x16_conv_terr",
+               # round 5: the other games the server dispatches (server.rs:114-185)
+               "arimaa_2x32", "ttt_2x16_dense", "sttt_2x16_dense_h"]
 
 
 def load_blob(name):

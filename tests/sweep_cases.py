@@ -66,6 +66,16 @@ CASES = [
     _c("chess", 3, 256, "dense", dense_hidden_channels=32, scalar_hidden_channels=8, scalar_hidden_size=128),
     _c("go-9", 3, 128, "conv", scalar_hidden_channels=8, scalar_hidden_size=128),
     _c("ataxx-7", 3, 128, "ataxx_conv", final_affine=False),
+    # --- round 5: the other games the server dispatches (rust/kz-selfplay/src/server/server.rs:114-185): arimaa-split
+    #     (ArimaaSplitMapper: 38 input planes, ArimaaPolicyHead, post_act.py:144-173), ttt (3x3) and sttt (9x9) through
+    #     DensePolicyHead ---
+    _c("arimaa-split", 3, 256, "arimaa"),
+    _c("arimaa-split", 3, 128, "arimaa", arimaa_hidden_channels=4, arimaa_hidden_size=64, boards=7),
+    _c("arimaa-split", 1, 96, "arimaa", boards=3),
+    _c("ttt", 3, 64, "dense", boards=7),
+    _c("ttt", 1, 32, "dense", dense_hidden_size=16, boards=3),
+    _c("sttt", 3, 128, "dense", dense_hidden_channels=2),
+    _c("sttt", 3, 64, "dense", dense_hidden_channels=4, dense_hidden_size=32, boards=7),
 ]
 
 # the reference's own shipping configuration (python/main/loop_main_alpha.py:16-30,68-76): Go 9x9, 16 blocks x 128
