@@ -96,11 +96,15 @@ KERNEL_OF_PATH = {
 # source file of each dominant kernel: the committed PMC traffic figure is only reported while this file is unchanged
 KERNEL_SOURCE = {
     "kz_tower_resident_f16": "kz_tower.hip", "kz_tower_resident_f32": "kz_tower_f32.hip",
-    "kz_tower_resident_split": "kz_tower_split.hip", "kz_tower_resident_f16g": "kz_tower_split.hip",
+    "kz_tower_resident_split": "kz_tower_split.hip", "kz_tower_resident_f16g": "kz_tower_f16g.hip",
     "kz_board_conv_f16": "kz_board_conv.hip", "kz_board_conv_split16": "kz_board_conv.hip", "kz_conv_igemm_f16": "kz_kernels.hip", "kz_conv_igemm_f32": "kz_kernels.hip",
 }
-# device code a kernel source pulls in (hashed with it: a traffic record goes stale when either changes)
-KERNEL_DEVICE_HEADERS = {"kz_tower_f32.hip": ["kz_conv_heads.hpp"], "kz_tower_split.hip": ["kz_conv_heads.hpp"]}
+# device code a kernel source pulls in (hashed with it: a traffic record goes stale when either changes).  The (hi, lo) tower
+# and its plain-f16 sibling are one template (kz_tower_pairs.hpp) instantiated by a translation unit each: an edit to one
+# family's instances leaves the other's record alone, an edit to the shared body stales both — as it should
+_PAIRS = ["kz_tower_pairs.hpp", "kz_tower_pairs_shapes.hpp", "kz_conv_heads.hpp", "kz_decode_dev.hpp"]
+KERNEL_DEVICE_HEADERS = {"kz_tower.hip": ["kz_decode_dev.hpp"], "kz_tower_f32.hip": ["kz_conv_heads.hpp", "kz_decode_dev.hpp"],
+                         "kz_tower_split.hip": _PAIRS, "kz_tower_f16g.hip": _PAIRS}
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "hbm_traffic.json")
 
 

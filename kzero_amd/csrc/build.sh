@@ -14,12 +14,12 @@ if [ "$EXP" = "1" ]; then
   OUT=${KZ_OUT:-../libkzhip_exp.so}
   B=${KZ_BUILD_DIR:-build_exp}
   DEFS="-DKZ_EXPERIMENTS"
-  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower4.hip kz_tower_f32.hip kz_tower_split.hip kz_board_conv.hip kz_board_conv2.hip kz_engine.hip"
+  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower4.hip kz_tower_f32.hip kz_tower_split.hip kz_tower_f16g.hip kz_tower_pairs_pack.hip kz_conv1x1_split.hip kz_board_conv.hip kz_board_conv2.hip kz_engine.hip"
 else
   OUT=${KZ_OUT:-../libkzhip.so}
   B=${KZ_BUILD_DIR:-build}
   DEFS=""
-  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower_f32.hip kz_tower_split.hip kz_board_conv.hip kz_engine.hip"
+  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower_f32.hip kz_tower_split.hip kz_tower_f16g.hip kz_tower_pairs_pack.hip kz_conv1x1_split.hip kz_board_conv.hip kz_engine.hip"
 fi
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mcode-object-version=5 -Wall -Wno-unused-result $DEFS ${KZ_EXTRA_FLAGS:-}"
 mkdir -p $B
@@ -30,7 +30,7 @@ objs=()
 for src in $HIP_SRCS; do
   obj=$B/${src%.hip}.o
   objs+=("$obj")
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_kernels.hpp -nt "$obj" ] || [ kz_conv_heads.hpp -nt "$obj" ] || [ kz_decode_dev.hpp -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ] || [ ../../include/kz_hip.h -nt "$obj" ] || { [ "$src" = kz_engine.hip ] && { [ kz_plan.hpp -nt "$obj" ] || [ kz_device_weights.hpp -nt "$obj" ] || [ kz_engine_util.hpp -nt "$obj" ]; }; }; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_kernels.hpp -nt "$obj" ] || [ kz_conv_heads.hpp -nt "$obj" ] || [ kz_decode_dev.hpp -nt "$obj" ] || [ kz_tower_pairs.hpp -nt "$obj" ] || [ kz_tower_pairs_shapes.hpp -nt "$obj" ] || [ kz_tower_pairs_exp32.hpp -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ] || [ ../../include/kz_hip.h -nt "$obj" ] || { [ "$src" = kz_engine.hip ] && { [ kz_plan.hpp -nt "$obj" ] || [ kz_device_weights.hpp -nt "$obj" ] || [ kz_engine_util.hpp -nt "$obj" ]; }; }; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

@@ -81,13 +81,13 @@ struct ChessMove {
     bool operator==(const ChessMove &o) const { return from == o.from && to == o.to && promotion == o.promotion; }
 };
 
-// square_pov / move_pov (chess.rs:417-441): black sees the board with the ranks flipped; its own inverse
+// square_pov (chess.rs:397-406) and move_pov (chess.rs:409-416): black sees the board with the ranks flipped; its own inverse
 inline uint8_t chess_square_pov(bool white_pov, uint8_t sq) { return white_pov ? sq : (uint8_t)((7 - sq / 8) * 8 + sq % 8); }
 inline ChessMove chess_move_pov(bool white_pov, ChessMove mv) {
     return ChessMove{chess_square_pov(white_pov, mv.from), chess_square_pov(white_pov, mv.to), mv.promotion};
 }
 
-// generate_all_flat_moves_pov (chess.rs:459-507) and its inverse FLAT_MOVES_POV (chess.rs:180-195): the 1880 moves from
+// generate_all_flat_moves_pov (chess.rs:439-481) and its inverse, the FLAT_MOVES_POV table (chess.rs:180-195): the 1880 moves from
 // the point of view of the player making them — queen-like moves for every (from, to) in square order, the knight
 // moves, then the promotions from the seventh to the eighth rank, piece-major.
 struct ChessFlatMoves {
@@ -321,7 +321,7 @@ struct AtaxxStdMapper {
 };
 
 // --------------------------------------------------------------------------------------------------------------
-// Tic-tac-toe and super tic-tac-toe (ttt.rs:9-59, sttt.rs:7-55): the server's `Game::TTT` / `Game::STTT`
+// Tic-tac-toe and super tic-tac-toe (ttt.rs:9-55, sttt.rs:7-54): the server's `Game::TTT` / `Game::STTT`
 // (rust/kz-selfplay/src/server/server.rs:114-137).  Tiles in the board-game crate's own coordinate order (`Coord3::all()`
 // / `Coord::all()`: index 0..8 / o 0..80), which is also the policy index of a move.
 // (`Game::ArimaaSplit`'s mapper, arimaa.rs:15-139, is not mirrored: its plane and policy order is that of `Piece::ALL`,

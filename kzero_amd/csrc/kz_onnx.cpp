@@ -892,7 +892,7 @@ Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err) 
             fail("outputs must be ('scalars', 'policy'), or three outputs (value, wdl, policy) in that order (network/common.rs:36-49)");
         const int hw = m->h * m->w;
 
-        // ---- ResTower (post_act.py:201-228) ----
+        // ---- the tower (post_act.py:201-228: ResTower, ResBlock) ----
         auto stems = M.consumers("input", "Conv");
         if (stems.size() != 1 || M.consumers("input").size() != 1) fail("'input' must feed exactly one Conv");
         m->tower.push_back(M.conv(*stems[0], 3));

@@ -100,6 +100,15 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
     p.fused_pairs = p.pairs16 && !nofuse &&
                     kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
                                                          m.channels, m.sh_conv.cout, m.sh_fc0.out, false, p.wide);
+    // the wide tiles hold more boards per workgroup than the fused conv heads' tail takes (four): where the heads fit the
+    // narrow tiles only (128 channels on 5x5: eight boards against four), one launch per batch — zero-copy slots, the decode
+    // inside — is worth more than the wide tiles' smaller weight traffic
+    if (p.wide && !p.fused_pairs && !nofuse &&
+        kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w, m.channels,
+                                             m.sh_conv.cout, m.sh_fc0.out, false, false)) {
+        p.wide = false;
+        p.fused_pairs = true;
+    }
     p.fused32 = p.resident32 && !p.split16 && !nofuse &&
                 kz::tower32_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w, m.channels,
                                             m.sh_conv.cout, m.sh_fc0.out);

@@ -7,7 +7,7 @@
 //! Differences from `CudaNetwork`, all invisible to callers:
 //!  * the mapper's *packed* output (`InputMapper::encode_input`: BitBuffer + scalars, mapping/mod.rs:37) is handed
 //!    over as is; the dense f32 expansion (`encode_input_full`, mapping/mod.rs:40-63) happens on the GPU;
-//!  * no NaN padding to `max_batch_size` (cudnn.rs:65) and no input clone (cudnn.rs:70): only `batch` rows exist;
+//!  * no NaN padding (cudnn.rs:65) up to `max_batch_size` and no input clone (cudnn.rs:70): only `batch` rows exist;
 //!  * `decode_output`'s gather + softmax (common.rs:60-86) runs on the GPU by default (`KZ_HIP_DECODE=device`): the
 //!    executor thread builds the `move_to_index` list of every board when it submits the batch, the GPU returns
 //!    tanh(value), softmax(wdl) and the per-move probabilities — 0.2 KB instead of 7.5 KB per chess evaluation over

@@ -719,7 +719,7 @@ KZO_EXPORT int kzo_decode_output(const float *scalars, const float *policy_logit
  * 3 = bishop, 4 = knight (the order of the flat list's promotion block, chess.rs:489-500).
  * ------------------------------------------------------------------------------------------------------------------- */
 
-/* generate_all_flat_moves_pov (chess.rs:459-507): queen-like moves for every (from, to) in square order, then the
+/* generate_all_flat_moves_pov (chess.rs:439-481): queen-like moves for every (from, to) in square order, then the
  * knight moves, then the promotions from the seventh to the eighth rank, piece-major.  out[i] = {from, to, promotion}. */
 KZO_EXPORT int kzo_chess_flat_moves(int *out /* [1880][3] */) {
     int n = 0;
@@ -749,7 +749,7 @@ KZO_EXPORT int kzo_chess_flat_moves(int *out /* [1880][3] */) {
     return n; /* FLAT_MOVE_COUNT = 1880 (chess.rs:185, asserted :505) */
 }
 
-/* square_pov / move_pov (chess.rs:417-441): black sees the board with the ranks flipped */
+/* square_pov (chess.rs:397-406) and move_pov (chess.rs:409-416): black sees the board with the ranks flipped */
 static int kzo_square_pov(int white_to_move, int sq) { return white_to_move ? sq : (7 - sq / 8) * 8 + sq % 8; }
 
 /* ChessStdMapper::move_to_index (chess.rs:202-210): the position of the POV move in the flat list, or -1 (the

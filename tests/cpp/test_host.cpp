@@ -183,7 +183,7 @@ static void test_mappers() {
         }
     }
     {
-        // Known answers for AtaxxStdMapper::encode_input (ataxx.rs:93-116) and GoStdMapper::encode_input (go.rs:64-113),
+        // Known answers for AtaxxStdMapper::encode_input (ataxx.rs:106-116) and GoStdMapper::encode_input (go.rs:64-113),
         // derived by hand from position strings.  Ataxx 7x7 start "x5o/7/7/7/7/7/o5x x" with one gap at d4: the board-game
         // crate's rank 1 is y = 0, so x (to move) owns a7 = (0,6) and g1 = (6,0), o owns g7 = (6,6) and a1 = (0,0); planes =
         // next player's tiles, other player's tiles, gaps, each over full_mask() in y-major order; scalar = 30 / 100.
@@ -430,7 +430,7 @@ static void test_adapters() {
 //    its conv-policy index and its attention index;
 //  * the (side, move) <-> conv index vectors of rust/kz-core/tests/mapper/chess/pairs.rs (oracle/gen_chess_pairs.py);
 //  * flat_gen (tests/mapper/chess/mod.rs:6-17): 1880 moves, no duplicates;
-//  * test_valid_policy_mapping (tests/mapper/mod.rs:37-72): index -> move -> index round trip for both colours.
+//  * test_valid_policy_mapping and the two checks it runs (tests/mapper/mod.rs:29-82): index -> move -> index round trip for both colours.
 static void test_chess_policy(const std::string &golden) {
     const auto &flat = ChessFlatMoves::get();
     CHECK(flat.index_to_mv.size() == 1880);
