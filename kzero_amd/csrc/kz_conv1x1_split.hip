@@ -14,7 +14,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100;
 
 __device__ __forceinline__ void split4(f32x4 v, h16x4 &hi, h16x4 &lo) {  // hi = f16(v), lo = f16(v - hi)
 #pragma unroll

@@ -169,10 +169,10 @@ struct kz_engine {
         bool decoded = false;  // what is in flight was submitted with a move list
         bool in_launch = false;  // ... and decoded by the network's own launch (the range check reports in h_sout's header)
         size_t move_cap = 0, moves = 0;
-        int64_t *d_moff = nullptr, *h_moff = nullptr;
-        int32_t *d_midx = nullptr, *h_midx = nullptr;
-        float *d_values = nullptr, *h_values = nullptr, *d_probs = nullptr, *h_probs = nullptr;
-        int *d_err = nullptr, *h_err = nullptr;
+        int64_t *h_moff = nullptr;
+        int32_t *h_midx = nullptr;
+        float *h_values = nullptr, *h_probs = nullptr;
+        int *h_err = nullptr;  // [0] softmax sum / move index, [1] range check (kz_kernels.hpp: launch_decode_output)
     } slots[KZ_ENGINE_SLOTS];
     float *d_dense = nullptr, *h_dense = nullptr;
     static constexpr int SOUT_HDR = 4;  // floats in front of the scalars
@@ -1118,24 +1118,21 @@ KZ_API int kz_engine_submit_packed_decoded(kz_engine *e, int slot, const uint8_t
     const size_t total = (size_t)move_offsets[batch];
     if (total && !move_indices) return fail(std::string(fn) + ": null move list");
     HIP_TRY(hipSetDevice(e->device));
-    if (!s.d_moff) {
-        if (e->dmalloc((void **)&s.d_moff, (size_t)(e->max_batch + 1) * 8) || e->hmalloc((void **)&s.h_moff, (size_t)(e->max_batch + 1) * 8) ||
-            e->dmalloc((void **)&s.d_values, (size_t)e->max_batch * 20) || e->hmalloc((void **)&s.h_values, (size_t)e->max_batch * 20) ||
-            e->dmalloc((void **)&s.d_err, 16) || e->hmalloc((void **)&s.h_err, 16))
+    if (!s.h_moff) {  // (pinned only: the decode reads and writes the host staging directly, on every path)
+        if (e->hmalloc((void **)&s.h_moff, (size_t)(e->max_batch + 1) * 8) || e->hmalloc((void **)&s.h_values, (size_t)e->max_batch * 20) ||
+            e->hmalloc((void **)&s.h_err, 16))
             return 1;
     }
     if (total > s.move_cap) {  // the old (smaller) buffers stay on the engine's free list until it is destroyed
         const size_t cap = std::max(total, std::max(s.move_cap * 2, (size_t)e->max_batch * 64));
-        if (e->dmalloc((void **)&s.d_midx, cap * 4) || e->hmalloc((void **)&s.h_midx, cap * 4) ||
-            e->dmalloc((void **)&s.d_probs, cap * 4) || e->hmalloc((void **)&s.h_probs, cap * 4))
-            return 1;
+        if (e->hmalloc((void **)&s.h_midx, cap * 4) || e->hmalloc((void **)&s.h_probs, cap * 4)) return 1;
         s.move_cap = cap;
     }
     for (int b = 0; b < batch; b++) memcpy(s.h_bits + b * bits_bytes, bits + b * bits_stride, bits_bytes);
     if (m.n_scalar) memcpy(s.h_sin, scalars_in, (size_t)batch * m.n_scalar * 4);
     memcpy(s.h_moff, move_offsets, (size_t)(batch + 1) * 8);
     if (total) memcpy(s.h_midx, move_indices, total * 4);
-    *s.h_err = 0;
+    s.h_err[0] = s.h_err[1] = 0;
     struct StreamSwap {
         kz_engine *e;
         hipStream_t saved;
@@ -1157,21 +1154,18 @@ KZ_API int kz_engine_submit_packed_decoded(kz_engine *e, int slot, const uint8_t
         s.moves = total;
         return 0;
     }
+    // heads in launches of their own: the network leaves scalars and logits in device memory, the stand-alone decode kernel
+    // reads the move lists from and writes values / probabilities / flags to the slot's pinned staging directly (every word
+    // once): the two input copies are the only copy operations of the batch
     HIP_TRY(hipMemcpyAsync(s.d_bits, s.h_bits, batch * bits_bytes, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(s.d_sin, s.h_sin, (size_t)batch * m.n_scalar * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(s.d_moff, s.h_moff, (size_t)(batch + 1) * 8, hipMemcpyHostToDevice, e->stream));
-    if (total) HIP_TRY(hipMemcpyAsync(s.d_midx, s.h_midx, total * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemsetAsync(s.d_err, 0, 4, e->stream));
     e->arm(s);
     if (e->forward_packed(s.d_bits, bits_bytes, s.d_sin, batch, s.d_sout + kz_engine::SOUT_HDR, s.d_pol)) return 1;
     e->prof.begin("kz_decode_output", e->stream);
-    kz::launch_decode_output(s.d_sout + kz_engine::SOUT_HDR, s.d_pol, batch, m.policy_len, s.d_moff, s.d_midx, s.d_values,
-                             s.d_probs, s.d_err, reinterpret_cast<const int *>(s.d_sout), s.epoch, e->stream);
+    kz::launch_decode_output(s.d_sout + kz_engine::SOUT_HDR, s.d_pol, batch, m.policy_len, s.h_moff, s.h_midx, s.h_values,
+                             s.h_probs, s.h_err, reinterpret_cast<const int *>(s.d_sout), s.epoch, e->stream);
     e->prof.end(e->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(s.h_values, s.d_values, (size_t)batch * 20, hipMemcpyDeviceToHost, e->stream));
-    if (total) HIP_TRY(hipMemcpyAsync(s.h_probs, s.d_probs, total * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(s.h_err, s.d_err, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipEventRecord(s.done, e->stream));
     s.batch = batch;
     s.decoded = true;
@@ -1195,8 +1189,8 @@ KZ_API int kz_engine_wait_decoded(kz_engine *e, int slot, const float **values_o
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(s.done));
     if (s.in_launch && kz_engine::slot_nonfinite(s)) return fail(kz_engine::nonfinite_message("kz_engine_wait_decoded"));
-    if (*s.h_err & 2) return fail(kz_engine::nonfinite_message("kz_engine_wait_decoded"));
-    if (*s.h_err) return fail("kz_engine_wait_decoded: Softmax input sum must be strictly positive (or a move index is out of range)");
+    if (s.h_err[1]) return fail(kz_engine::nonfinite_message("kz_engine_wait_decoded"));
+    if (s.h_err[0]) return fail("kz_engine_wait_decoded: Softmax input sum must be strictly positive (or a move index is out of range)");
     return 0;
 }
 

@@ -789,84 +789,37 @@ __global__ __launch_bounds__(256) void kz_attention_mfma(AttentionDev a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// F7: decode_output on the device (rust/kz-core/src/network/common.rs:16-100).  One workgroup per board:
+// F7: decode_output on the device (rust/kz-core/src/network/common.rs:16-100) as a launch of its own, for the paths whose
+// heads are separate launches (the one-launch networks end in the same code: kz_decode_dev.hpp).  One WAVE per board, four
+// boards per workgroup:
 //   values = [tanh(s0), softmax(s1..s3), s4]  (:60-74)
 //   probs  = softmax over the logits gathered at the board's available-move indices, in the given order (:77-86)
-// A non-positive or NaN softmax sum (where the reference asserts, :110) raises *error_flag.
+// error_flag[0] = 1: a softmax sum is not strictly positive (where the reference asserts, :110) or a move index is outside
+// the policy; error_flag[1] = 1: *nonfinite_flag == epoch (the range check of ScalarHeadArgs).  Move lists, values,
+// probabilities and the flag words may be pinned host memory: every word is read or written once, flags by plain stores.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kz_decode_output(const float *__restrict__ scalars,
-                                                        const float *__restrict__ logits, int policy_len,
-                                                        const int64_t *__restrict__ move_offsets,
-                                                        const int32_t *__restrict__ move_indices,
-                                                        float *__restrict__ values, float *__restrict__ probs,
-                                                        int *__restrict__ error_flag,
-                                                        const int *__restrict__ nonfinite_flag, int epoch) {
-    __shared__ float red[4];
-    __shared__ float bcast;
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (b == 0 && tid == 0 && nonfinite_flag && *nonfinite_flag == epoch) atomicOr(error_flag, 2);
-    if (tid == 0) {
-        const float *s = scalars + (size_t)b * 5;
-        const float m = fmaxf(s[1], fmaxf(s[2], s[3]));
-        const float e0 = expf(s[1] - m), e1 = expf(s[2] - m), e2 = expf(s[3] - m), sum = e0 + e1 + e2;
-        float *v = values + (size_t)b * 5;
-        v[0] = tanhf(s[0]);
-        v[1] = e0 / sum;
-        v[2] = e1 / sum;
-        v[3] = e2 / sum;
-        v[4] = s[4];
-        if (!(sum > 0.0f)) atomicOr(error_flag, 1);
-    }
-    const int64_t lo = move_offsets[b], hi = move_offsets[b + 1];
-    const int n = (int)(hi - lo);
-    if (n <= 0) return;  // finished game: empty policy (map_or(vec![], ..))
-    const float *lg = logits + (size_t)b * policy_len;
-    float mx = -INFINITY;
-    for (int i = tid; i < n; i += 256) {
-        const int idx = move_indices[lo + i];
-        const float v = (idx >= 0 && idx < policy_len) ? lg[idx] : NAN;  // a bad index poisons the sum -> error flag
-        mx = fmaxf(mx, v);
-        if (v != v) mx = NAN;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float o = __shfl_xor(mx, off, 64);
-        mx = (mx != mx || o != o) ? NAN : fmaxf(mx, o);
-    }
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    if (tid == 0) {
-        float m = red[0];
-        for (int i = 1; i < 4; i++) m = (m != m || red[i] != red[i]) ? NAN : fmaxf(m, red[i]);
-        bcast = m;
-    }
-    __syncthreads();
-    mx = bcast;
-    float sum = 0.0f;
-    for (int i = tid; i < n; i += 256) {
-        const int idx = move_indices[lo + i];
-        const float e = (idx >= 0 && idx < policy_len) ? expf(lg[idx] - mx) : NAN;
-        probs[lo + i] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    __syncthreads();
-    if (lane == 0) red[wave] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        bcast = red[0] + red[1] + red[2] + red[3];
-        if (!(bcast > 0.0f)) atomicOr(error_flag, 1);
-    }
-    __syncthreads();
-    const float inv_sum = bcast;
-    for (int i = tid; i < n; i += 256) probs[lo + i] /= inv_sum;
+namespace {
+#include "kz_decode_dev.hpp"
+constexpr int DECODE_STAGE = 1024;  // floats of LDS staging per wave (a longer move list re-reads its tail)
+}  // namespace
+
+__global__ __launch_bounds__(256) void kz_decode_output(const float *__restrict__ scalars, const float *__restrict__ logits,
+                                                        int batch, DecodeDev d, const int *__restrict__ nonfinite_flag, int epoch) {
+    __shared__ float stage[4][DECODE_STAGE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nonfinite_flag && *nonfinite_flag == epoch)
+        *reinterpret_cast<volatile int *>(d.error_flag + 1) = 1;
+    if (b >= batch) return;
+    const float *lg = logits + (size_t)b * d.policy_len;
+    decode_board_wave(d, b, lane, scalars + (size_t)b * 5, stage[wave], DECODE_STAGE, [&](int idx) { return lg[idx]; });
 }
 
 void launch_decode_output(const float *scalars, const float *logits, int batch, int policy_len,
                           const int64_t *move_offsets, const int32_t *move_indices, float *values, float *probs,
                           int *error_flag, const int *nonfinite_flag, int epoch, hipStream_t stream) {
-    kz_decode_output<<<batch, 256, 0, stream>>>(scalars, logits, policy_len, move_offsets, move_indices, values, probs,
-                                                error_flag, nonfinite_flag, epoch);
+    const DecodeDev d{move_offsets, move_indices, values, probs, error_flag, policy_len};
+    kz_decode_output<<<(batch + 3) / 4, 256, 0, stream>>>(scalars, logits, batch, d, nonfinite_flag, epoch);
 }
 
 void launch_attention(int dtype, const AttentionArgs &a, hipStream_t stream) {

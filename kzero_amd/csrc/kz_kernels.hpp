@@ -115,7 +115,8 @@ void launch_attention(int dtype, const AttentionArgs &a, hipStream_t stream);
 
 // F7 — decode_output (rust/kz-core/src/network/common.rs:16-100) on the device: values [batch][5] = tanh / wdl softmax /
 // moves_left; probs = per-board softmax over the logits at the available-move indices (CSR lists).
-// error_flag: bit 0 = a softmax sum is not strictly positive; bit 1 = *nonfinite_flag == epoch (see ScalarHeadArgs)
+// error_flag: TWO words — [0] = 1: a softmax sum is not strictly positive (or a move index is out of range); [1] = 1:
+// *nonfinite_flag == epoch (see ScalarHeadArgs).  The move lists, values, probs and error_flag may be pinned host memory
 void launch_decode_output(const float *scalars, const float *logits, int batch, int policy_len,
                           const int64_t *move_offsets, const int32_t *move_indices, float *values, float *probs,
                           int *error_flag, const int *nonfinite_flag, int epoch, hipStream_t stream);

@@ -513,6 +513,64 @@ def test_config_c1_default_shim_entry_decoded_on_all_slots(dev, chess_full, ches
     assert np.array_equal(s3, s_own) and np.array_equal(p3, p_own)
 
 
+@pytest.mark.parametrize("game,depth,channels,head,dtype,path", [
+    ("ataxx-7", 2, 128, "ataxx_conv", capi.KZ_DTYPE_F32, "tower_resident_f32+heads"),
+    ("ataxx-7", 2, 128, "ataxx_conv", capi.KZ_DTYPE_F32_SPLIT16, "tower_resident_split16+heads"),
+    ("ataxx-7", 2, 128, "ataxx_conv", capi.KZ_DTYPE_F16, "tower_resident_f16g+heads"),
+    ("go-9", 2, 128, "conv", capi.KZ_DTYPE_F16, "tower_resident_f16g+heads"),
+    ("go-9", 2, 128, "conv", capi.KZ_DTYPE_F32_SPLIT16, "tower_resident_split16+heads"),
+    ("go-9", 2, 256, "conv", capi.KZ_DTYPE_F32_SPLIT16, "board_conv_split16"),
+    ("ataxx-5", 2, 128, "ataxx_conv", capi.KZ_DTYPE_F16, "tower_resident_f16g+heads"),
+    ("chess", 2, 256, "attention", capi.KZ_DTYPE_F16, "tower_resident_f16+heads"),
+    ("chess", 2, 256, "attention", capi.KZ_DTYPE_F32_SPLIT16, "tower_resident_split16+heads"),
+    ("go-19", 1, 64, "conv", capi.KZ_DTYPE_F16, "board_conv_f16"),           # (heads are separate launches: the stand-alone decode kernel)
+    ("chess", 2, 128, "dense", capi.KZ_DTYPE_F16, "tower_resident_f16g"),
+])
+def test_decode_inside_the_launch_on_every_one_launch_path(dev, game, depth, channels, head, dtype, path):
+    """decode_output (common.rs:16-100) as the last step of every "...+heads" launch (and, for the paths whose heads are
+    separate launches, through kz_decode_output): submit_packed_decoded on all four slots against the oracle's decode_output
+    of the engine's own logits — ragged batches (the last workgroup partly empty), move lists from none (a finished game)
+    to every index of the policy twice over (longer than a wave: the 64-lane loops wrap many times), boards in another
+    order on every slot."""
+    blob = synth.random_model(game, depth, channels, head, seed=51)
+    net = O.OracleNet(blob)
+    n = 23
+    bits, scalars_in = synth.random_boards(game, n, seed=52)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 256 if path == "board_conv_f16" else 32, dtype)
+    assert eng.tower_path == path
+    s_own, p_own = eng.eval_packed(bits, scalars_in)
+    rng = np.random.default_rng(53)
+    P = net.policy_len
+    slots = []
+    for k in range(capi.KZ_ENGINE_SLOTS):
+        order = rng.permutation(n)[:n - 2 * k]  # 23, 21, 19, 17 boards
+        moves = [rng.permutation(P)[:int(c)].astype(np.int32) for c in rng.integers(1, min(P, 90), size=len(order))]
+        moves[1] = np.zeros(0, np.int32)                                   # a finished game
+        moves[2] = np.concatenate([rng.permutation(P), rng.permutation(P)]).astype(np.int32)  # 2 P moves, every index twice
+        moves[-1] = np.arange(P, dtype=np.int32)                           # the last board of a ragged batch
+        slots.append((order, moves, eng.submit_packed_decoded(k, bits[order], scalars_in[order], moves)))
+    for k in (1, 3, 0, 2):
+        order, moves, off = slots[k]
+        v, probs = eng.wait_decoded(k, off)
+        v_ref, probs_ref = O.decode_output(s_own[order], p_own[order], moves)
+        np.testing.assert_allclose(v, v_ref, rtol=0, atol=3e-6)
+        for b in range(len(order)):
+            assert probs[b].shape == moves[b].shape
+            np.testing.assert_allclose(probs[b], probs_ref[b], rtol=2e-5, atol=1e-7)
+    # an index out of range on the LAST board of a batch, then the engine again
+    order, moves, _ = slots[0]
+    bad = [m.copy() for m in moves]
+    bad[-1][5] = P + 3
+    off = eng.submit_packed_decoded(1, bits[order], scalars_in[order], bad)
+    with pytest.raises(capi.KzError, match="strictly positive"):
+        eng.wait_decoded(1, off)
+    v, probs = eng.wait_decoded(1, eng.submit_packed_decoded(1, bits[order], scalars_in[order], moves))
+    v_ref, _ = O.decode_output(s_own[order], p_own[order], moves)
+    np.testing.assert_allclose(v, v_ref, rtol=0, atol=3e-6)
+    s2, p2 = eng.eval_packed(bits, scalars_in)
+    assert np.array_equal(s2, s_own) and np.array_equal(p2, p_own)
+
+
 G8_PICK = np.arange(0, 512, 32)  # 16 boards spread over the batch (rounds 2-3: 8)
 
 
@@ -1057,7 +1115,8 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     ("go-9", 2, 128, "conv", (3, 11), 64),                    # 81 pixels: six tiles, heads in the launch
     ("go-9", 2, 128, "conv", (1, 2, 3, 11, 256), 256),        # two 9x9 boards in eleven tiles
     ("ataxx-7", 2, 128, "ataxx_conv", (1, 3, 4, 5, 9, 512), 512),  # four 7x7 boards in thirteen tiles
-    ("ataxx-5", 2, 128, "ataxx_conv", (1, 7, 8, 9, 17, 1024), 1024),  # eight 5x5 boards in thirteen tiles
+    ("ataxx-5", 2, 128, "ataxx_conv", (1, 7, 8, 9, 17, 1024), 1024),  # four 5x5 boards in seven tiles with the heads inside
+                                                                      # (eight in thirteen would leave the heads outside: round 5)
     ("chess", 2, 192, "attention", (1, 3, 40, 256), 256),     # 192 channels: two 8x8 boards per workgroup as well
     ("go-9", 2, 192, "conv", (1, 2, 3, 256), 256),            # ... two 9x9 boards in eleven tiles
     ("ataxx-7", 2, 192, "ataxx_conv", (1, 4, 5, 384), 384),   # ... three 7x7 boards in ten tiles
@@ -1077,7 +1136,7 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
         assert not eng.tower_path.startswith("tower_resident_f16g")
         return
     # at 128 channels an engine whose max_batch still gives 128 workgroups takes twice the boards per workgroup (round 4)
-    wide_boards = {("chess", 128, 256): 2, ("go-9", 128, 256): 2, ("ataxx-7", 128, 512): 4, ("ataxx-5", 128, 1024): 8,
+    wide_boards = {("chess", 128, 256): 2, ("go-9", 128, 256): 2, ("ataxx-7", 128, 512): 4,
                    ("chess", 192, 256): 2, ("go-9", 192, 256): 2, ("ataxx-7", 192, 384): 3}.get((game, channels, max_batch))
     if channels in (128, 192):
         narrow = {"chess": 1, "go-9": 1, "ataxx-7": 2, "ataxx-5": 4}[game]
@@ -1087,7 +1146,8 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
             assert eng.launch_geometry(9) == ((9 + narrow - 1) // narrow, narrow)
     # conv-policy networks at 128 channels (256 on <= 64 squares) carry their heads in the launch since round 3: the tail of
     # the exact-f32 launch with its two small convolutions as f16 MFMAs on the f16 images (round 4; any number of tiles)
-    # (at most four boards per workgroup in the tail: eight 5x5 boards run their heads as separate launches)
+    # (at most four boards per workgroup in the tail: where the wide tiles would hold more — eight 5x5 boards — the selector
+    # keeps the narrow tiles and the heads inside, kz_plan.hpp)
     fused = head in ("ataxx_conv", "conv") and channels == 128 and (wide_boards or 1) <= 4
     assert eng.tower_path == ("tower_resident_f16g+heads" if fused else "tower_resident_f16g")
     tower_only = eng
