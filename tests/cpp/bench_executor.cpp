@@ -202,6 +202,14 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
                 8 * per_dev_rate, 8 * cores_per_device, numa.c_str(),
                 8 * per_dev_rate * (in_bytes + out_bytes) / 1e9, per_dev_rate * (in_bytes + out_bytes) / 1e9);
     std::fflush(stdout);
+    if (const char *clean = getenv("KZ_BENCH_CLEAN_EXIT"); clean && clean[0] == '1') {
+        // under a profiler (tools/profile_r5.sh: rocprofv3 writes its kernel trace when the process ends NORMALLY): every
+        // generator leaves its loop at its next reply, the job channels disconnect, the executors evaluate what is left and
+        // exit, the engines are destroyed
+        for (auto &g : gens) g.join();
+        for (auto &dev : devs) dev->join();
+        return 0;
+    }
     // generators block in recv(); the process exit tears everything down (the reference server has no clean stop
     // either: commander.rs:63-64)
     std::_Exit(0);
