@@ -298,6 +298,8 @@ class Workload:
                      for _ in self.engines]
         self.stride = self.bits.shape[1]
         self.inflight = {}
+        self.inflight_dec = set()
+        self.moves = None
         self.tower_path = self.engines[0].tower_path
         self.kernel = KERNEL_OF_PATH[self.tower_path]
         # host-pointer loop: on the fused path an engine's two slots own a stream each, so ONE executor thread keeps
@@ -318,10 +320,29 @@ class Workload:
             self.host_engines[e].wait_view(slot, self.inflight.pop((e, slot)))
         self.inflight[(e, slot)] = self.host_engines[e].submit_packed(slot, self.bits, self.scalars_in)
 
+    def step_host_decoded(self, i):
+        # the entry points the Rust shim uses by default: packed boards + the CSR lists of move_to_index of the available moves
+        # in, decoded values + one probability per move out (kz_engine_submit_packed_decoded / kz_engine_wait_decoded)
+        if self.moves is None:
+            rng = self.np.random.default_rng(7)
+            counts = rng.integers(20, 51, size=self.B)  # ~35 legal moves per position
+            self.moves = (self.np.concatenate([[0], self.np.cumsum(counts)]).astype(self.np.int64),
+                          self.np.ascontiguousarray(self.np.concatenate([rng.permutation(self.info.policy_len)[:c] for c in counts]).astype(self.np.int32)))
+        n, S = len(self.host_engines), self.capi.KZ_ENGINE_SLOTS
+        e, slot = i % n, (i // n) % S
+        if (e, slot) in self.inflight_dec:
+            self.host_engines[e].wait_decoded_view(slot)
+            self.inflight_dec.discard((e, slot))
+        self.host_engines[e].submit_packed_decoded_csr(slot, self.bits, self.scalars_in, self.moves[0], self.moves[1])
+        self.inflight_dec.add((e, slot))
+
     def sync(self):
         for (e, slot), n in list(self.inflight.items()):
             self.host_engines[e].wait_view(slot, n)
         self.inflight.clear()
+        for (e, slot) in list(self.inflight_dec):
+            self.host_engines[e].wait_decoded_view(slot)
+        self.inflight_dec.clear()
         for e in self.engines:
             e.synchronize()
         self.capi.check(self.capi.load().kz_device_synchronize(self.device))
@@ -713,6 +734,22 @@ def main():
                 "kernel_avg_launch_ms": round(h_ms / max(h_n, 1), 5),
                 "chip_frac": round(h_value / world * info.flops_per_eval / 1e12 / (157.3 if args.dtype == "f32" else 2500.0), 4)}
 
+    # ---- timed regions 3 (`pcie_inclusive.decoded`): the boundary the Rust shim uses by default — move lists in, decoded
+    # values and legal-move probabilities out (0.2 KB instead of 7.5 KB per chess evaluation over PCIe) ----
+    if host is not None and w.info.input_scalar_channels >= 0:
+        try:
+            w.condition(w.step_host_decoded, min(args.prewarm, 0.1))
+            d_regions = benchlib.run_timed_regions(w.step_host_decoded, w.sync, args.steps, args.warmup, args.repeats, dist)
+            d_values = [benchlib.whole_job_value(args.steps, B, world, t) for t in d_regions]
+            d_value = benchlib.whole_job_value(args.steps, B, world, benchlib.median_region(d_regions))
+            host["decoded"] = {"value": round(d_value, 1), "value_min": round(min(d_values), 1), "value_max": round(max(d_values), 1),
+                               "of_resident": round(d_value / value, 4), "regions": len(d_regions),
+                               "entry_points": "kz_engine_submit_packed_decoded -> kz_engine_wait_decoded (hip.rs's default): "
+                                               "20-50 legal moves per board, decode_output inside the launch on the one-launch paths",
+                               "d2h_bytes_per_eval": int(20 + 4 * 35), "h2d_bytes_per_eval": int(w.stride + 4 * w.info.input_scalar_channels + 8 + 4 * 35)}
+        except Exception as ex:  # noqa: BLE001 (an additional record: its failure must not cost the line)
+            host["decoded"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
     # every rank's own line (a slow rank — NUMA, thermals, a bad link — must be visible next to the aggregate)
     per_rank = benchlib.gather_objects(dist, {
         "rank": rank, "device": device, "bus_id": devices_seen[rank], "numa_node": numa["numa_node"],
@@ -745,6 +782,8 @@ def main():
         # what the reference's evaluate_batch boundary delivers (host boards in, host results out): compare THIS with the
         # reference's `real` evals/s; the measurement contract keeps it out of `value` (inputs resident in HBM)
         "value_host_boundary": host["value"] if host else None,
+        # ... and through the boundary the Rust shim uses by default (move lists in, decoded values + legal-move probabilities out)
+        "value_host_boundary_decoded": (host or {}).get("decoded", {}).get("value"),
         "schema": "r5: value = median region; roofline.achieved/frac = the chip's (all concurrent launches; since r4), "
                   "launch_achieved/launch_frac = one launch's (what frac meant in r1-r3)",
         "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, packed boards resident in HBM",
@@ -777,6 +816,12 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 out["others"].append({"workload": "chess-20x256", "dtype": "f16", "weights": label,
                                       "error": f"{type(ex).__name__}: {ex}"[:300]})
+    if "others" in out:  # the two numbers a reader needs side by side: the f16 headline and the <= 1e-4 path of the same network
+        par = [o for o in out["others"] if o.get("workload") == "chess-20x256" and o.get("dtype") == "f32split16" and "value" in o]
+        if par:
+            out["value_parity_default"] = par[0]["value"]
+            out["config"]["parity_default"] = ("KZ_DTYPE_F32_SPLIT16 (<= 1e-4 against the oracle; what the Rust binding runs unless "
+                                               f"KZ_HIP_DTYPE=f16): {par[0]['value']} evals/s, frac {par[0]['roofline']['frac']}")
     if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
         out["seam"] = seam_record(blob, args.seam_seconds)
         # ... and at the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity -> split16 for this network)

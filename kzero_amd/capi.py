@@ -272,6 +272,18 @@ class Engine:
                                                      idx.ctypes.data))
         return offsets
 
+    def submit_packed_decoded_csr(self, slot: int, bits: np.ndarray, scalars_in: np.ndarray, offsets: np.ndarray, idx: np.ndarray):
+        """The same with the CSR move lists already built (contiguous uint8 / float32 / int64 / int32 arrays): what a timed
+        loop calls."""
+        check(load().kz_engine_submit_packed_decoded(self._h, slot, bits.ctypes.data, bits.shape[1], scalars_in.ctypes.data,
+                                                     bits.shape[0], offsets.ctypes.data, idx.ctypes.data))
+
+    def wait_decoded_view(self, slot: int):
+        """kz_engine_wait_decoded without copies: the two pointers into the slot's pinned staging."""
+        pv, pp = C.c_void_p(), C.c_void_p()
+        check(load().kz_engine_wait_decoded(self._h, slot, C.byref(pv), C.byref(pp)))
+        return pv.value, pp.value
+
     def wait_decoded(self, slot: int, offsets: np.ndarray):
         """values [batch,5] and one probability array per board: copies of the slot's pinned staging."""
         pv, pp = C.c_void_p(), C.c_void_p()

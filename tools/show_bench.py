@@ -14,7 +14,8 @@ def roof(x):
 print("value", r["value"], f"[{r.get('value_min')} .. {r.get('value_max')}] over {r.get('regions')} regions of {r['steps']} steps;",
       "host boundary", r.get("value_host_boundary"), f"(frac {r['roofline'].get('host_boundary_frac')});", roof(r))
 if "pcie_inclusive" in r:
-    h = r["pcie_inclusive"]; print("pcie_inclusive", h["value"], f"[{h.get('value_min')} .. {h.get('value_max')}]", "of_resident", h["of_resident"], "engines", h.get("engines_per_gpu"))
+    h = r["pcie_inclusive"]; print("pcie_inclusive", h["value"], f"[{h.get('value_min')} .. {h.get('value_max')}]", "of_resident", h["of_resident"], "engines", h.get("engines_per_gpu"), "| decoded entry:", h.get("decoded"))
+if "value_parity_default" in r: print("parity default (split16, <= 1e-4):", r["value_parity_default"])
 for o in r.get("others", []):
     if "error" in o:
         print(" ", o["workload"], o["dtype"], "ERROR", o["error"])
