@@ -254,7 +254,7 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
     except Exception as ex:  # noqa: BLE001
         a0 = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     return {"value": round(n / dt, 3), "unit": "evals/s", "cores": cores, "kind": "port", "a0": a0,
-            "sample": f"{n} boards of the same synthetic batch, oracle/kz_oracle.c f32 NCHW direct conv, "
+            "sample": f"{n} boards of the same synthetic batch, oracle/kz_oracle.c f32 NCHW direct conv (zero-padded planes, nine taps and two output channels per pass), "
                       f"OpenMP over boards on {cores} threads = the container's CPU quota (cgroup cpu.max; the affinity mask "
                       f"allows {affinity}, the machine reports {os.cpu_count()}: a whole socket is not this process's to "
                       f"use), {dt:.1f} s; single-thread {1.0 / one:.3f} evals/s"}
