@@ -603,6 +603,13 @@ def select_device(benchlib, dist, rank, local_rank, world, ndev, bus_id_of):
     """The device this rank drives and every rank's PCI bus id, or (None, message): LOCAL_RANK among the visible GPUs, or
     the single visible GPU of a rank whose launcher masked the others; the ranks must report `world` distinct bus ids."""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if os.environ.get("KZ_BENCH_ALLOW_SHARED_GPU") == "1" and ndev < local_world:
+        # REHEARSAL ONLY (tools/first_node.sh --rehearse on a one-GPU box): the real multi-rank path — gloo control plane, real
+        # engines, per-rank lines, the one-process seam — with several ranks on ONE GPU.  The line says shared_gpu and is no
+        # scaling measurement.
+        device = local_rank % ndev
+        seen = benchlib.gather_strings(dist, bus_id_of(device))
+        return device, seen, None
     device, why = benchlib.pick_device(ndev, local_rank, local_world)
     # every rank takes part in the gather, also one that has no device: nobody may be left waiting in a collective
     seen = benchlib.gather_strings(dist, bus_id_of(device) if device is not None else f"none:{rank}")
@@ -796,6 +803,9 @@ def main():
         "per_rank": per_rank,
         "roofline": roof,
     }
+    if len(set(devices_seen)) < world:  # (only reachable with KZ_BENCH_ALLOW_SHARED_GPU=1)
+        out["shared_gpu"] = True
+        out["data"] = "synthetic; REHEARSAL: %d ranks share %d GPU(s) — not a scaling measurement" % (world, len(set(devices_seen)))
     if host:
         out["pcie_inclusive"] = host
     blob, bits, scalars_in = w.blob, w.bits, w.scalars_in
@@ -832,7 +842,9 @@ def main():
             # the topology the reference and the Rust drop-in use: ONE process, a thread set per device
             # (rust/kz-selfplay/src/server/server.rs:323-331) over exactly the GPUs the ranks of this run drove
             drove = [r["device"] for r in per_rank]
-            if ndev >= world and len(set(drove)) == world:
+            if out.get("shared_gpu"):
+                out["seam_one_process"] = {"skipped": "rehearsal on a shared GPU: one process would drive the same device twice"}
+            elif ndev >= world and len(set(drove)) == world:
                 rec = seam_record(blob, args.seam_seconds, devices=drove, configs=SEAM_CONFIGS[:1])
                 rec["metric"] = rec.get("metric", "seam") + f", one process over devices {drove}"
                 out["seam_one_process"] = rec

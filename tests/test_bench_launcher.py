@@ -177,3 +177,30 @@ def test_numa_binding_from_sysfs(tmp_path):
     assert benchlib.pick_device(8, 3, 8) == (3, None) and benchlib.pick_device(1, 3, 8) == (0, None)
     assert benchlib.pick_device(2, 3, 8)[0] is None
     assert benchlib.check_distinct(["a", "b"], 2) is None and "1 distinct" in benchlib.check_distinct(["a", "a"], 2)
+
+
+@pytest.mark.timeout(180)
+def test_shared_gpu_rehearsal_needs_the_explicit_override():
+    """Two ranks that see ONE (fake) GPU: refused (exit 3) — unless KZ_BENCH_ALLOW_SHARED_GPU=1 asks for the rehearsal of the
+    multi-rank path on a one-GPU box (tools/first_node.sh REHEARSE=2; the real line then says shared_gpu)."""
+    import socket
+
+    def run(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(2):
+            env = dict(_clean_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2",
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KZ_FAKE_NDEV="1", **extra)
+            procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2",
+                                           "--fake-step", "5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=170) for p in procs]
+        return [p.returncode for p in procs], outs
+
+    rcs, outs = run({})
+    assert rcs == [3, 3] and "distinct GPU" in outs[0][1]
+    rcs, outs = run({"KZ_BENCH_ALLOW_SHARED_GPU": "1"})
+    assert rcs == [0, 0], outs
+    rec = json.loads(outs[0][0])
+    assert rec["n_gpus"] == 2 and [r["device"] for r in rec["per_rank"]] == [0, 0] and rec["regions"] == 2

@@ -3,6 +3,8 @@
 # failure is cheapest to read, each step's output kept under gpurun_out/first_node/.  Run on the box from the repo root:
 #
 #   tools/first_node.sh              two-device parity test, bench.py --gpus 1 / 2 / 4 / 8 (as many as the box has), summary
+#   REHEARSE=2 tools/first_node.sh   on a ONE-GPU box: the REAL multi-rank path (gloo control plane, real engines, per-rank lines)
+#                                    with 2 ranks sharing the GPU (KZ_BENCH_ALLOW_SHARED_GPU=1); the lines say shared_gpu
 #   FAKE=1 tools/first_node.sh       CPU dry run of the same script (tests/test_first_node.py): bench.py --fake-step on
 #                                    KZ_FAKE_NDEV=8 fake GPUs, optionally over a fake sysfs tree (KZ_FAKE_SYSFS) for the NUMA
 #                                    binding; no pytest -m gpu
@@ -33,6 +35,11 @@ else
   else
     echo "first_node: one GPU visible: nothing here has not run before (the N = 1 line follows)"
   fi
+fi
+if [ "${REHEARSE:-0}" -gt "$NDEV" ] && [ "$FAKE" != "1" ]; then
+  export KZ_BENCH_ALLOW_SHARED_GPU=1
+  echo "first_node: REHEARSAL — up to $REHEARSE ranks on $NDEV GPU(s)"
+  NDEV=$REHEARSE
 fi
 echo "first_node: $NDEV device(s)"
 
