@@ -7,7 +7,9 @@
 //
 //   test_two_devices <model.kzm> [dtype f16|f32|f32split16] [gpu_batch]
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <optional>
 #include <random>
 #include <string>
 
@@ -38,8 +40,21 @@ static Flat run_requests(DeviceExecutors<PackedBoard, PackedMapper> &dev, const 
         pending.push_back(dev.eval_client.map(std::move(x)));
     }
     Flat out;
+    // Two executor threads share the device's job channel and each evaluates when it holds JobCount(gpu_batch / search_batch)
+    // jobs (server_alphazero.rs:48): a FINITE set of requests can end with both holding a partial batch — in the server the
+    // generators never stop, here filler requests keep arriving until every counted reply is in (the first version of this
+    // test waited without them and deadlocked now and then: found by the one-GPU rehearsal of round 5)
+    std::vector<Receiver<std::vector<ZeroEvaluation>>> fillers;
     for (auto &p : pending) {
-        auto y = p.recv();
+        std::optional<std::vector<ZeroEvaluation>> y;
+        for (;;) {
+            TryRecvError err = TryRecvError::Empty;
+            y = p.try_recv(err);
+            if (y || err == TryRecvError::Disconnected) break;
+            std::vector<PackedBoard> x(pool.begin(), pool.begin() + (long)per);
+            fillers.push_back(dev.eval_client.map(std::move(x)));
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
         if (!y) {
             CHECK(!"reply channel closed");
             break;
@@ -62,10 +77,15 @@ int main(int argc, char **argv) {
         return 2;
     }
     int ndev = 0;
-    if (kz_device_count(&ndev) != 0 || ndev < 2) {
+    // KZ_TWO_DEVICES_REHEARSE=1 on a one-GPU box: both thread sets on device 0 — everything of the topology but the second
+    // piece of hardware (two job channels, 2 x 2 executor threads with their own engines, one shared graph, concurrent drive)
+    const char *rehearse_env = getenv("KZ_TWO_DEVICES_REHEARSE");
+    const bool rehearse = rehearse_env && rehearse_env[0] == '1';
+    if (kz_device_count(&ndev) != 0 || ndev < (rehearse ? 1 : 2)) {
         std::printf("skip: %d GPU(s) visible, the two-device topology needs 2\n", ndev);
         return 77;
     }
+    const int second = ndev >= 2 ? 1 : 0;
     const std::string dtype_name = argc > 2 ? argv[2] : "f16";
     const int dtype = dtype_name == "f32" ? KZ_DTYPE_F32 : dtype_name == "f32split16" ? KZ_DTYPE_F32_SPLIT16 : KZ_DTYPE_F16;
     StartupSettings st;
@@ -98,7 +118,7 @@ int main(int argc, char **argv) {
         auto one = spawn_all_devices<PackedBoard, PackedMapper>({0}, st, mapper, dtype, &c);
         one[0]->send_graph(model);
         alone = run_requests(*one[0], pool, requests, per);
-        CHECK(c.real == requests * per);
+        CHECK(c.real >= requests * per);  // (+ the filler requests)
         for (auto &d : one) d->join();
     }
     CHECK(alone.values.size() > requests * per * 5);
@@ -106,8 +126,8 @@ int main(int argc, char **argv) {
     // devices 0 and 1, one process: both driven at the same time from two generator threads
     {
         std::unique_ptr<EvalCounters[]> per_device(new EvalCounters[2]);
-        auto both = spawn_all_devices<PackedBoard, PackedMapper>({0, 1}, st, mapper, dtype, nullptr, per_device.get());
-        CHECK(both.size() == 2 && both[0]->device == 0 && both[1]->device == 1);
+        auto both = spawn_all_devices<PackedBoard, PackedMapper>({0, second}, st, mapper, dtype, nullptr, per_device.get());
+        CHECK(both.size() == 2 && both[0]->device == 0 && both[1]->device == second);
         for (auto &d : both) d->send_graph(model);
         Flat got[2];
         std::thread t0([&] { got[0] = run_requests(*both[0], pool, requests, per); });
@@ -115,7 +135,7 @@ int main(int argc, char **argv) {
         t0.join();
         t1.join();
         for (int d = 0; d < 2; d++) {
-            CHECK(per_device[d].real == requests * per);
+            CHECK(per_device[d].real >= requests * per);
             CHECK(got[d].values.size() == alone.values.size());
             CHECK(got[d].values.size() == alone.values.size() &&
                   std::memcmp(got[d].values.data(), alone.values.data(), alone.values.size() * sizeof(float)) == 0);
@@ -135,6 +155,6 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "%d check(s) failed\n", g_failed);
         return 1;
     }
-    std::printf("two-device tests ok (%s)\n", dtype_name.c_str());
+    std::printf("two-device tests ok (%s%s)\n", dtype_name.c_str(), second ? "" : "; REHEARSAL: both thread sets on device 0");
     return 0;
 }

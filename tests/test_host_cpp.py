@@ -86,6 +86,25 @@ def test_two_devices_in_one_process(tmp_path):
         assert "two-device tests ok" in out.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_thread_sets_in_one_process_rehearsal(tmp_path):
+    """The same program on a ONE-GPU box with both thread sets on device 0 (KZ_TWO_DEVICES_REHEARSE=1): two job channels,
+    2 x 2 pipelined executor threads with their own engines, one shared graph, both driven at once, a graph swap — bitwise
+    what one thread set gives alone.  Everything of the two-device topology but the second piece of hardware."""
+    from kzero_amd import synth
+    lib = os.path.join(REPO, "kzero_amd")
+    exe = _build("test_two_devices.cpp", "test_two_devices", [f"-L{lib}", "-lkzhip", f"-Wl,-rpath,{lib}"])
+    big = tmp_path / "chess_2x256.kzm"
+    big.write_bytes(synth.random_model("chess", 2, 256, "attention", seed=5))
+    for model, dtype in [(str(big), "f16"), (str(big), "f32split16"), (os.path.join(GOLDEN, "go9_2x16_conv.kzm"), "f32"),
+                         (os.path.join(GOLDEN, "ataxx7_4x64.kzm"), "f16")]:
+        out = subprocess.run([exe, model, dtype], capture_output=True, text=True, timeout=200,
+                             env={**os.environ, "KZ_TWO_DEVICES_REHEARSE": "1"})
+        assert out.returncode == 0, f"{model} {dtype}: " + out.stdout + out.stderr
+        assert "two-device tests ok" in out.stdout
+
+
 def test_two_device_test_compiles_and_skips_without_two_gpus():
     """CPU side of the above: the program builds against the C ABI alone and reports 'skip' (exit code 77) where fewer
     than two GPUs are visible."""
