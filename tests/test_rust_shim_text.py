@@ -133,3 +133,57 @@ def test_integration_md_lists_every_edited_reference_line():
                  "server.rs:306", "server_alphazero.rs:7", "server_alphazero.rs:35", "server_muzero.rs:26",
                  "type Device", "KZ_HIP_DTYPE", "Legacy three-output graphs are taken"):
         assert cite in text, f"INTEGRATION.md does not mention {cite}"
+
+
+def _strip_rust(text):
+    """Rust source without comments, string / char literals and lifetimes: what is left must have balanced delimiters."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if text.startswith("//", i):
+            i = text.find("\n", i) if "\n" in text[i:] else n
+        elif text.startswith("/*", i):
+            depth, i = 1, i + 2
+            while i < n and depth:
+                if text.startswith("/*", i):
+                    depth, i = depth + 1, i + 2
+                elif text.startswith("*/", i):
+                    depth, i = depth - 1, i + 2
+                else:
+                    i += 1
+        elif c == '"':
+            i += 1
+            while i < n and text[i] != '"':
+                i += 2 if text[i] == "\\" else 1
+            i += 1
+        elif c == "'":
+            m = re.match(r"'(\\.|[^\\'])'", text[i:])  # a char literal; otherwise a lifetime ('static, 's)
+            i += m.end() if m else 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def test_rust_sources_are_lexically_well_formed():
+    """No compiler here, so at least: every delimiter of the three Rust files closes in the right order (comments, string
+    and char literals and lifetimes aside), and no statement-level typo like a doubled `;;` or an `fn` without a body slipped in."""
+    rust_dir = os.path.join(REPO, "kzero_amd", "rust")
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for name in sorted(os.listdir(rust_dir)):
+        if not name.endswith(".rs"):
+            continue
+        code = _strip_rust(open(os.path.join(rust_dir, name)).read())
+        stack = []
+        for pos, c in enumerate(code):
+            if c in "([{":
+                stack.append((c, pos))
+            elif c in ")]}":
+                assert stack and stack[-1][0] == pairs[c], f"{name}: unbalanced '{c}' near ...{code[max(0, pos - 60):pos + 1]!r}"
+                stack.pop()
+        assert not stack, f"{name}: unclosed '{stack[-1][0]}' near ...{code[stack[-1][1]:stack[-1][1] + 60]!r}"
+        assert ";;" not in code, name
+        for m in re.finditer(r"\bfn\s+\w+[^;{]*([;{])", code):  # a fn outside a trait / extern block has a body
+            if m.group(1) == ";":
+                before = code[:m.start()]
+                assert before.rfind('extern') > before.rfind("}\n\n") or "trait" in before[before.rfind("\n\n"):], f"{name}: fn without a body: {m.group(0)[:60]}"
