@@ -867,6 +867,7 @@ struct CoordNet : Network<AtaxxSymBoard> {  // policy weight of a move depends o
         std::vector<ZeroEvaluation> out(n);
         for (size_t i = 0; i < n; i++) {
             out[i].values.value = (float)__builtin_popcountll(boards[i].tiles_next);
+            if (!boards[i].moves) continue;  // a finished game: an empty policy
             for (const auto &mv : *boards[i].moves)
                 out[i].policy.push_back((float)AtaxxStdMapper(boards[i].size).move_to_index(mv));
         }
