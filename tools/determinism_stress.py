@@ -46,4 +46,23 @@ for game, depth, ch, head, batch, dtype, reps in CASES:
             n_bad += 1
     print(f"{game} {depth}x{ch} { {capi.KZ_DTYPE_F16: 'f16', capi.KZ_DTYPE_F32: 'f32', capi.KZ_DTYPE_F32_SPLIT16: 'f32split16'}[dtype] } path={engines[0].tower_path}: {n_bad} of {reps} differ")
     bad += n_bad
+    # round 5: the decoded entry points on all four slots at once (decode_output inside the launch on the one-launch paths,
+    # the stand-alone kernel on pinned staging otherwise): the same values and probabilities from every slot, every time
+    rng = np.random.default_rng(11)
+    plen = engines[0].model.info.policy_len
+    moves = [rng.permutation(plen)[:int(c)].astype(np.int32) for c in rng.integers(0, min(plen, 70), size=batch)]
+    ref = None
+    d_bad = 0
+    for r in range(max(4, reps // 10)):
+        eng = engines[r % 2]
+        offs = [eng.submit_packed_decoded(k, bits, sc, moves) for k in range(capi.KZ_ENGINE_SLOTS)]
+        for k in range(capi.KZ_ENGINE_SLOTS):
+            v, probs = eng.wait_decoded(k, offs[k])
+            flat = np.concatenate([v.ravel()] + [q for q in probs])
+            if ref is None:
+                ref = flat
+            elif not np.array_equal(flat, ref, equal_nan=True):
+                d_bad += 1
+    print(f"    decoded entry, 4 slots x {max(4, reps // 10)} rounds: {d_bad} differ")
+    bad += d_bad
 sys.exit(1 if bad else 0)
