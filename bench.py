@@ -366,8 +366,35 @@ class Workload:
             step(i)
         self.sync()
         k = self.kernel_time()
+        self.small = self.small_kernels()
         self.profiling(False)
         return k
+
+    def small_kernels(self):
+        """The HBM-bound kernels around a per-layer tower (board encode in front, head kernels behind — the BN / ReLU tails
+        themselves are fused into the convolutions' epilogues): average launch time and achieved GB/s against the 8 TB/s HBM
+        peak, from the same HIP events as the dominant kernel.  Algorithmic bytes: what the kernel must read and write."""
+        info, B = self.info, self.B
+        hw, C = info.board_h * info.board_w, info.tower_channels
+        esz = 2 if self.dtype_name == "f16" else 4
+        cin_rows = 64 if self.tower_path == "board_conv_f16" and info.input_channels <= 64 else -(-info.input_channels // 32) * 32
+        act = B * hw * C * esz
+        byt = {"kz_encode_packed": B * (self.stride + 4 * info.input_scalar_channels) + B * hw * cin_rows * esz,
+               "kz_scalar_head": act + 4 * (4 * C + 32 * 4 * hw + 5 * 32) + B * 5 * 4,
+               "kz_conv1x1_split": act + C * C * 2 + B * info.policy_len * 4,
+               "kz_policy_conv": B * hw * C * esz + B * info.policy_len * 4,
+               "kz_policy_extra": act + B * 4, "kz_split_rows": 2 * act}
+        out = []
+        for name, nbytes in byt.items():
+            ms = n = 0
+            for e in self.engines:
+                m, k = e.kernel_time(name)
+                ms, n = ms + m, n + k
+            if n:
+                us = ms / n * 1e3
+                out.append({"kernel": name, "launches": n, "avg_launch_us": round(us, 2), "algorithmic_bytes": int(nbytes),
+                            "achieved_GBps": round(nbytes / (us * 1e-6) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (us * 1e-6) / 8e12, 4)})
+        return out
 
     def kernel_time(self):
         ms, n = 0.0, 0
@@ -499,7 +526,8 @@ def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm, model_kw
                 "value": round(value, 1), "unit": "evals/s", "batch": w.B, "steps": steps,
                 "ms_per_step": round(dt / steps * 1e3, 4), "engines_per_gpu": len(w.engines), "tower_path": w.tower_path,
                 "flop_per_eval": w.info.flops_per_eval,
-                "roofline": w.roofline(k_ms, k_n, min(steps, 50) if w.per_layer else steps, value)}
+                "roofline": w.roofline(k_ms, k_n, min(steps, 50) if w.per_layer else steps, value),
+                **({"hbm_bound_kernels": w.small} if getattr(w, "small", None) else {})}
     finally:
         w.close()
 
