@@ -63,6 +63,8 @@ WORKLOADS = {
                          engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x384 ResNet b=256"),
     "chess-20x64": dict(game="chess", depth=20, channels=64, head="attention", batch=256, steps=4000,
                         engines={"f16": 3, "f32": 2, "f32split16": 3}, label="Chess 20x64 ResNet b=256"),
+    "chess-20x128": dict(game="chess", depth=20, channels=128, head="attention", batch=1024, steps=1000,
+                         engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x128 ResNet b=1024"),
     "chess-20x320": dict(game="chess", depth=20, channels=320, head="attention", batch=256, steps=1000,
                          engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x320 ResNet b=256"),
     "chess-20x512": dict(game="chess", depth=20, channels=512, head="attention", batch=256, steps=500,

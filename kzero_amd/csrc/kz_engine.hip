@@ -959,7 +959,7 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     int per = 0, wgs = 0;
     if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
     else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16,
-                                                         e->wide && kz::tower_split_wide_supported(m.h, m.w, m.channels, batch));  // (per launch)
+                                                         e->wide ? batch : 0);  // (per launch: the widest level this batch fills the chip with)
     else if (e->resident32) per = e->t32_dense3 ? 3 : kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);
     if (per) wgs = (batch + per - 1) / per;
     else if (e->path == "board_conv_split16") wgs = kz::board_conv_workgroups(batch, m.h, m.w, m.channels);

@@ -240,7 +240,7 @@ void launch_tower32(const Tower32Args &a, hipStream_t stream);
 // (f32 in/out), `weights` = tower_split_pack_weights stream: 9 * ceil(c_in / 32) stem k-steps, then 9*C/32 per tower
 // convolution ----
 bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool split);
-int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, bool wide = false);
+int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, int wide_batch = 0);  // wide_batch: the launch's batch when the engine takes the wide tiles
 // plain f16, 128 channels: twice the boards per workgroup (Tower32Args::wide) when max_batch still gives >= 128 workgroups
 bool tower_split_wide_supported(int h, int w, int channels, int max_batch);
 size_t tower_split_stem_elems(int channels, int c_in, bool split);              // f16 elements of the 9 * ceil(c_in / 32) stem k-steps
@@ -260,7 +260,7 @@ void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const floa
 // two small convolutions as f16 MFMAs on the f16 images: Heads::small_w = tower_split_pack_small_weights16; wide: with
 // Tower32Args::wide)
 bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs,
-                                      bool split, bool wide = false);
+                                      bool split, int wide_batch = 0);
 size_t tower_split_small_weight16_elems(int channels);  // f16 elements
 void tower_split_pack_small_weights16(const float *sh_w0, int hc, const float *pe_wc /* or null */, const float *p_w1, int pc,
                                       int channels, uint16_t *dst);

@@ -99,13 +99,13 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
     p.wide = p.pairs16 && kz::tower_split_wide_supported(m.h, m.w, m.channels, max_batch);
     p.fused_pairs = p.pairs16 && !nofuse &&
                     kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w,
-                                                         m.channels, m.sh_conv.cout, m.sh_fc0.out, false, p.wide);
+                                                         m.channels, m.sh_conv.cout, m.sh_fc0.out, false, p.wide ? max_batch : 0);
     // the wide tiles hold more boards per workgroup than the fused conv heads' tail takes (four): where the heads fit the
     // narrow tiles only (128 channels on 5x5: eight boards against four), one launch per batch — zero-copy slots, the decode
     // inside — is worth more than the wide tiles' smaller weight traffic
     if (p.wide && !p.fused_pairs && !nofuse &&
         kz::tower_split_conv_heads_supported((int)m.policy_kind, m.policy_extra_moves, m.policy_conv_channels, m.h, m.w, m.channels,
-                                             m.sh_conv.cout, m.sh_fc0.out, false, false)) {
+                                             m.sh_conv.cout, m.sh_fc0.out, false, 0)) {
         p.wide = false;
         p.fused_pairs = true;
     }

@@ -21,6 +21,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
         else if (nt == 8) launch<128, 8, false, 2>(d, grid, stream);
         else if (nt == 11) launch<128, 11, false, 2>(d, grid, stream);
         else if (nt == 13) launch<128, 13, false, 2>(d, grid, stream);
+        else if (nt == 16) launch<128, 16, false, 2>(d, grid, stream);
         else launch<128, 6, false, 2>(d, grid, stream);
         return;
     }
@@ -45,6 +46,7 @@ void launch_tower_pairs(const Tower32Args &t, bool split, hipStream_t stream) {
     else if (t.channels == 128 && nt == 8) launch<128, 8, false>(d, grid, stream);
     else if (t.channels == 128 && nt == 11) launch<128, 11, false>(d, grid, stream);
     else if (t.channels == 128 && nt == 13) launch<128, 13, false>(d, grid, stream);
+    else if (t.channels == 128 && nt == 16) launch<128, 16, false>(d, grid, stream);
     else if (t.channels == 128) launch<128, 6, false>(d, grid, stream);
     else if (nt == 4) launch<64, 4, false>(d, grid, stream);
     else if (nt == 7) launch<64, 7, false>(d, grid, stream);

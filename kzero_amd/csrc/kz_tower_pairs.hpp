@@ -793,7 +793,8 @@ void launch(const SplitDev &d, int grid, hipStream_t stream) {
     // (the conv heads' tail: the split launch wants the two images as f32 rows; the plain-f16 launch the tail's scratch,
     // F16_TAIL_SCRATCH_BYTES, behind its own images)
     constexpr int F32_IMAGES = (16 + 2 * NT * 16) * (C * 4 + 16), OWN = Geo<C, NT, SPLIT>::LDS_BYTES;
-    constexpr int LDS = HEADS != 2 ? OWN : !SPLIT ? OWN + (int)F16_TAIL_SCRATCH_BYTES : F32_IMAGES > OWN ? F32_IMAGES : OWN;
+    static_assert(OWN == pairs_own_lds_bytes(C, NT, SPLIT), "the host's restatement of the LDS geometry");
+    constexpr int LDS = HEADS != 2 ? OWN : !SPLIT ? OWN + pairs_f16_tail_scratch_bytes(C, NT) : F32_IMAGES > OWN ? F32_IMAGES : OWN;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (!((done_mask >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute((const void *)kz_tower_resident_split<C, NT, SPLIT, HEADS>,
@@ -829,8 +830,8 @@ inline SplitDev make_split_dev(const Tower32Args &t, bool split, int &nt, int &g
     d.stem_chunks = (t.c_in + 31) / 32;
     // (an engine that takes the wide tiles still launches the narrow ones for a batch too small to fill 128 wide workgroups:
     // the same weight stream, twice the workgroups, half the time per workgroup)
-    const bool wide = !split && t.wide && tower_split_wide_supported(t.h, t.w, t.channels, t.batch);
-    nt = wide ? split_wide_tiles_for(d.hw, t.channels) : split_tiles_for(d.hw, t.channels, split);
+    nt = !split && t.wide ? split_wide_tiles_for(d.hw, t.channels, t.batch) : 0;  // (the widest level this batch fills the chip with)
+    if (!nt) nt = split_tiles_for(d.hw, t.channels, split);
     d.nb = nt * 16 / d.hw;
     d.inv_w = (65536u + (unsigned)t.w - 1) / (unsigned)t.w;
     d.inv_hw = (65536u + (unsigned)d.hw - 1) / (unsigned)d.hw;

@@ -22,17 +22,15 @@ bool tower_split_supported(int h, int w, int channels, int depth, int c_in, bool
     return depth >= 1 && c_in >= 1 && (c_in + 31) / 32 <= channels / 32 && h >= 2 && w >= 2 && w <= 32 && nt != 0;
 }
 
-int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, bool wide) {
-    const int nt = wide ? split_wide_tiles_for(h * w, channels) : split_tiles_for(h * w, channels, split);
+int tower_split_boards_per_workgroup(int h, int w, int channels, bool split, int wide_batch) {
+    int nt = !split && wide_batch ? split_wide_tiles_for(h * w, channels, wide_batch) : 0;
+    if (!nt) nt = split_tiles_for(h * w, channels, split);
     return nt ? nt * 16 / (h * w) : 0;
 }
 
 // whether a plain-f16 engine of this shape takes the wide tiles: at least 128 workgroups at max_batch
 bool tower_split_wide_supported(int h, int w, int channels, int max_batch) {
-    const int nt = split_wide_tiles_for(h * w, channels);
-    if (!nt || !split_tiles_for(h * w, channels, false)) return false;
-    const int per = nt * 16 / (h * w);
-    return (max_batch + per - 1) / per >= 128;
+    return split_tiles_for(h * w, channels, false) != 0 && split_wide_tiles_for(h * w, channels, max_batch) != 0;
 }
 
 size_t tower_split_stem_elems(int channels, int c_in, bool split) {  // f16 elements of the stem's k-steps
@@ -160,14 +158,18 @@ void tower_split_pack_heads(const float *w_bulk, const float *b_bulk, const floa
 
 // ---- conv policy heads in the split launch: the shapes of the exact-f32 launch's fused heads at 128 / 256 channels ----
 bool tower_split_conv_heads_supported(int policy_kind, int extra_moves, int pc, int h, int w, int channels, int hc, int hs,
-                                      bool split, bool wide) {
+                                      bool split, int wide_batch) {
     if (channels != 128 && channels != 256) return false;
-    const int nt = !split && wide ? split_wide_tiles_for(h * w, channels) : split_tiles_for(h * w, channels, split);
+    // (wide_batch: the engine's max_batch when it takes the wide tiles — a launch with a smaller batch takes a narrower level,
+    // whose fewer boards need less of the tail's scratch)
+    int nt = !split && wide_batch ? split_wide_tiles_for(h * w, channels, wide_batch) : 0;
+    if (!nt) nt = split_tiles_for(h * w, channels, split);
     // instances: <256, 4> and <128, 4 / 6 / 7> (plain f16: <128, 8 / 11 / 13> too).  Split arithmetic: the f32 row images of the
     // tail must fit the LDS next to nothing else; plain f16: the tail's scratch behind the launch's own images.
     if (nt == 0 || (channels == 256 && nt != 4)) return false;
     if (split && (size_t)(16 + 2 * nt * 16) * (channels * 4 + 16) > (size_t)160 * 1024) return false;
-    return conv_heads_fit(nt, policy_kind, extra_moves, pc, h, w, channels, hc, hs, split ? 0 : F16_TAIL_SCRATCH_BYTES);
+    return conv_heads_fit(nt, policy_kind, extra_moves, pc, h, w, channels, hc, hs,
+                          split ? 0 : (size_t)pairs_f16_tail_scratch_bytes(channels, nt));
 }
 
 size_t tower_split_conv_heads_weight_elems(int channels, bool split) { return (size_t)(channels / 32) * (split ? 2 : 1) * channels * 32; }  // one pass

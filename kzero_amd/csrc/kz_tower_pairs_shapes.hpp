@@ -45,11 +45,42 @@ int split_tiles_for(int hw, int channels, bool split) {
 // 1.70M (1024), Ataxx 7x7 x 128 (20 blocks) at batch 1024 2.04M -> 2.27M — but only with enough workgroups to fill the chip (Ataxx at
 // batch 256: 64 workgroups, 2.02M -> 1.69M), and not at 64 channels (latency-bound: 4.44M -> 3.97M at batch 256) or 192
 // (no difference).  No fused conv heads at these sizes (the tail's f32 row images do not fit the LDS).
-int split_wide_tiles_for(int hw, int channels) {
+// Round 5: a third level at 128 channels — THREE 9x9 or FOUR 8x8 boards in sixteen tiles (243 / 256 of 256 rows are boards,
+// 152 KB of LDS) when the batch still gives 128 such workgroups.  The widest level that fills the chip at `batch` is taken.
+int split_wide_tiles_for(int hw, int channels, int batch) {
     // (192 channels: measured late in round 4, chess x 192 at batch 256 / 1024 711k -> 805k / 653k -> 807k evals/s with two boards
     // — its counters read 0.52 busy at 2.06 GHz with one board: neither the matrix cores' limit nor a full clock; three 7x7
     // boards in ten tiles there, four do not fit the LDS)
-    if (channels == 192) return hw == 64 ? 8 : hw == 81 ? 11 : hw == 49 ? 10 : 0;
-    if (channels != 128) return 0;
-    return hw == 64 ? 8 : hw == 81 ? 11 : (hw == 49 || hw == 25) ? 13 : 0;
+    int levels[2] = {0, 0};
+    if (channels == 192) levels[0] = hw == 64 ? 8 : hw == 81 ? 11 : hw == 49 ? 10 : 0;
+    else if (channels == 128) {
+        if (hw == 64 || hw == 81) {
+            levels[0] = 16;
+            levels[1] = hw == 64 ? 8 : 11;
+        } else {
+            levels[0] = (hw == 49 || hw == 25) ? 13 : 0;
+        }
+    }
+    for (int nt : levels) {
+        if (!nt) continue;
+        const int per = nt * 16 / hw;
+        // enough workgroups to fill the chip: 128 for the two-board levels (round 4's A/Bs); the sixteen-tile level wants two
+        // per CU — same-box, Go 9x9 16x128 at batch 2048: 1.554M -> 1.653M evals/s with 683 workgroups of three boards, but
+        // chess x 128 at batch 1024: 1.640M -> 1.590M with 256 workgroups of four (profiles/r5/ab_tiles16.txt)
+        if ((batch + per - 1) / per >= (nt == 16 ? 512 : 128)) return nt;
+    }
+    return 0;
+}
+
+// LDS bytes of the launch's own images (Geo<C, NT, SPLIT>::LDS_BYTES, restated for the host: kz_tower_pairs.hpp asserts the two
+// agree) and what is left of a CU's 160 KB behind them for the conv heads' tail of the plain-f16 launch
+constexpr int pairs_own_lds_bytes(int channels, int nt, bool split) {
+    const bool two = channels % 256 != 0;
+    const int rs = two ? channels + 16 : channels * 2 + 16, img = nt * 16 * rs;
+    const int rounded = (2 * img + 16 * rs + 255) / 256 * 256;
+    return (split ? 2 : 1) * (two ? 2 * rounded : rounded);
+}
+constexpr int pairs_f16_tail_scratch_bytes(int channels, int nt) {
+    const int room = 160 * 1024 - pairs_own_lds_bytes(channels, nt, false);
+    return room < (int)F16_TAIL_SCRATCH_BYTES ? room : (int)F16_TAIL_SCRATCH_BYTES;
 }

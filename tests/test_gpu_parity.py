@@ -1114,6 +1114,8 @@ def test_split16_tower_vs_oracle(dev, game, depth, channels, head, batches):
     ("chess", 2, 128, "attention", (1, 3, 40, 256), 256),     # ... two (eight tiles) when that still makes 128 workgroups
     ("go-9", 2, 128, "conv", (3, 11), 64),                    # 81 pixels: six tiles, heads in the launch
     ("go-9", 2, 128, "conv", (1, 2, 3, 11, 256), 256),        # two 9x9 boards in eleven tiles
+    ("go-9", 2, 128, "conv", (2, 300, 1537, 2048), 2048),     # round 5: THREE 9x9 boards in sixteen tiles (683 workgroups at 2048)
+    ("chess", 2, 128, "attention", (5, 1024, 2048), 2048),    # ... four 8x8 boards in sixteen tiles
     ("ataxx-7", 2, 128, "ataxx_conv", (1, 3, 4, 5, 9, 512), 512),  # four 7x7 boards in thirteen tiles
     ("ataxx-5", 2, 128, "ataxx_conv", (1, 7, 8, 9, 17, 1024), 1024),  # four 5x5 boards in seven tiles with the heads inside
                                                                       # (eight in thirteen would leave the heads outside: round 5)
@@ -1136,7 +1138,7 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
         assert not eng.tower_path.startswith("tower_resident_f16g")
         return
     # at 128 channels an engine whose max_batch still gives 128 workgroups takes twice the boards per workgroup (round 4)
-    wide_boards = {("chess", 128, 256): 2, ("go-9", 128, 256): 2, ("ataxx-7", 128, 512): 4,
+    wide_boards = {("chess", 128, 256): 2, ("go-9", 128, 256): 2, ("ataxx-7", 128, 512): 4, ("go-9", 128, 2048): 3, ("chess", 128, 2048): 4,
                    ("chess", 192, 256): 2, ("go-9", 192, 256): 2, ("ataxx-7", 192, 384): 3}.get((game, channels, max_batch))
     if channels in (128, 192):
         narrow = {"chess": 1, "go-9": 1, "ataxx-7": 2, "ataxx-5": 4}[game]
@@ -1144,6 +1146,8 @@ def test_resident_f16g_tower(dev, game, depth, channels, head, batches, max_batc
         assert eng.launch_geometry(max_batch) == ((max_batch + per - 1) // per, per)
         if wide_boards:  # a batch too small for 128 wide workgroups is launched with the narrow tiles (same weights)
             assert eng.launch_geometry(9) == ((9 + narrow - 1) // narrow, narrow)
+        if max_batch == 2048:  # ... and one too small for 512 sixteen-tile workgroups with the two-board level
+            assert eng.launch_geometry(300) == (150, 2) and eng.launch_geometry(1024) == (512, 2)
     # conv-policy networks at 128 channels (256 on <= 64 squares) carry their heads in the launch since round 3: the tail of
     # the exact-f32 launch with its two small convolutions as f16 MFMAs on the f16 images (round 4; any number of tiles)
     # (at most four boards per workgroup in the tail: where the wide tiles would hold more — eight 5x5 boards — the selector

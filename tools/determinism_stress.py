@@ -31,7 +31,9 @@ CASES = [("chess", 20, 256, "attention", 256, capi.KZ_DTYPE_F16, 200),
          ("go-9", 4, 128, "conv", 1023, capi.KZ_DTYPE_F16, 150),     # two boards per workgroup, heads inside (f16 tail)
          ("go-9", 4, 128, "conv", 77, capi.KZ_DTYPE_F16, 150),       # the same engine shape, narrow launch
          ("go-13", 4, 128, "conv", 255, capi.KZ_DTYPE_F16, 100),     # one 13x13 board in eleven tiles
-         ("go-13", 2, 192, "conv", 255, capi.KZ_DTYPE_F16, 100)]
+         ("go-13", 2, 192, "conv", 255, capi.KZ_DTYPE_F16, 100),
+         ("go-9", 4, 128, "conv", 2047, capi.KZ_DTYPE_F16, 100),     # round 5: three boards per workgroup (sixteen tiles), ragged
+         ("chess", 4, 128, "attention", 2045, capi.KZ_DTYPE_F16, 100)]  # ... four 8x8 boards
 KW = {("go-9", 1025): dict(scalar_hidden_channels=8, scalar_hidden_size=128)}
 bad = 0
 for game, depth, ch, head, batch, dtype, reps in CASES:
