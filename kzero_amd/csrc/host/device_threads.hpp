@@ -56,6 +56,8 @@ struct EvalCounters {
     std::atomic<uint64_t> executor_wait_ns[MAX_EXECUTORS] = {};
     // CPU time of the executor thread's prep helpers (StartupSettings::prep_helpers)
     std::atomic<uint64_t> helper_cpu_ns[MAX_EXECUTORS] = {};
+    // executor thread 0's work by phase: own share of the preparation, merge, the engine's submit call, building the evaluations
+    std::atomic<uint64_t> phase_ns[4] = {};
 };
 
 // (has `wait_cpu_ns`: HipNetwork; the tests' fake networks do not)
@@ -120,7 +122,15 @@ std::unique_ptr<DeviceExecutors<B, M, Net, GraphT>> spawn_device_executors(int d
                     if (local_id < EvalCounters::MAX_EXECUTORS) {
                         counters->executor_cpu_ns[local_id] = thread_cpu_ns();
                         if constexpr (has_wait_cpu_ns<Net>::value) counters->executor_wait_ns[local_id] = net.wait_cpu_ns;
-                        if constexpr (has_prep_helpers<Net>::value) counters->helper_cpu_ns[local_id] = net.helper_cpu_ns();
+                        if constexpr (has_prep_helpers<Net>::value) {
+                            counters->helper_cpu_ns[local_id] = net.helper_cpu_ns();
+                            if (local_id == 0) {
+                                counters->phase_ns[0] = net.prep_own_cpu_ns;
+                                counters->phase_ns[1] = net.merge_cpu_ns;
+                                counters->phase_ns[2] = net.submit_cpu_ns;
+                                counters->phase_ns[3] = net.assemble_cpu_ns;
+                            }
+                        }
                     }
                 }
             };

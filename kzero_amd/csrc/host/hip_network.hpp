@@ -198,11 +198,13 @@ class HipNetwork : public Network<B> {
         for (size_t k = 1; k < parts; k++)
             helpers_[k - 1]->start([this, boards, moves, k, lo = cut(k), hi = cut(k + 1)] { prep_range(boards, lo, hi, moves, ranges_[k]); });
         std::exception_ptr first;
+        const uint64_t t0 = thread_cpu_ns();
         try {
             prep_range(boards, 0, cut(1), moves, ranges_[0]);
         } catch (...) {
             first = std::current_exception();
         }
+        prep_own_cpu_ns += thread_cpu_ns() - t0;
         for (size_t k = 1; k < parts; k++) {  // every helper is waited for, whatever happened: the boards are the caller's
             try {
                 helpers_[k - 1]->finish();
@@ -211,6 +213,7 @@ class HipNetwork : public Network<B> {
             }
         }
         if (first) std::rethrow_exception(first);
+        const uint64_t t1 = thread_cpu_ns();
         scalars_in_.clear();
         if (moves) {
             offsets->assign(1, 0);
@@ -223,6 +226,7 @@ class HipNetwork : public Network<B> {
             move_indices_.insert(move_indices_.end(), r.indices.begin(), r.indices.end());
             for (int64_t c : r.counts) offsets->push_back(offsets->back() + c);
         }
+        merge_cpu_ns += thread_cpu_ns() - t1;
         return (input_bool_len(mapper_) + 7) / 8;
     }
 
@@ -242,6 +246,9 @@ class HipNetwork : public Network<B> {
     // CPU time this thread has spent inside kz_engine_wait* so far: the HIP runtime polls the event, so an executor
     // thread shows ~100 % CPU however little work it does; (thread CPU - this) is its work
     uint64_t wait_cpu_ns = 0;
+    // ... and where the rest goes (measurement, tests/cpp/bench_executor.cpp): this thread's share of a batch's preparation, the
+    // merge of the ranges, the engine's submit call (copies into pinned staging + the launch), building the evaluations
+    uint64_t prep_own_cpu_ns = 0, merge_cpu_ns = 0, submit_cpu_ns = 0, assemble_cpu_ns = 0;
     // cudnn.rs:29-43 (check_graph_shapes: common.rs:165-198)
     HipNetwork(M mapper, std::shared_ptr<const HipModel> model, size_t max_batch_size, int device, int dtype)
         : mapper_(mapper), model_(std::move(model)), max_batch_size_(max_batch_size) {
@@ -329,8 +336,10 @@ class HipNetwork : public Network<B> {
         const size_t bits_bytes = prepare(boards, n, device_decode_, &move_offsets_[next_slot_]);
         // the engine copies its inputs to pinned staging before submit returns (include/kz_hip.h)
         if (device_decode_) {
+            const uint64_t s0 = thread_cpu_ns();
             kz_check(kz_engine_submit_packed_decoded(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(),
                                                      (int)n, move_offsets_[next_slot_].data(), move_indices_.data()));
+            submit_cpu_ns += thread_cpu_ns() - s0;
             pending_boards_[next_slot_].clear();  // the move lists are all the decode needs
         } else {
             kz_check(kz_engine_submit_packed(engine_, next_slot_, bits_.data(), bits_bytes, scalars_in_.data(), (int)n));
@@ -350,8 +359,11 @@ class HipNetwork : public Network<B> {
             const float *values = nullptr, *probs = nullptr;
             const uint64_t w0 = thread_cpu_ns();
             kz_check(kz_engine_wait_decoded(engine_, slot, &values, &probs));
-            wait_cpu_ns += thread_cpu_ns() - w0;
-            return assemble_decoded(move_offsets_[slot].size() - 1, move_offsets_[slot], values, probs);
+            const uint64_t w1 = thread_cpu_ns();
+            wait_cpu_ns += w1 - w0;
+            auto out = assemble_decoded(move_offsets_[slot].size() - 1, move_offsets_[slot], values, probs);
+            assemble_cpu_ns += thread_cpu_ns() - w1;
+            return out;
         }
         // decode straight from the engine's pinned staging (valid until the next submit on this slot)
         const float *scalars = nullptr, *policy = nullptr;

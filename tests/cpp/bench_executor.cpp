@@ -129,6 +129,8 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
             e0[i][k] = per_device[i].executor_cpu_ns[k], w0[i][k] = per_device[i].executor_wait_ns[k], h0[i][k] = per_device[i].helper_cpu_ns[k];
     }
     for (size_t i = 0; i < n_gen; i++) g0[i] = gen_cpu[i];
+    uint64_t ph0[4];
+    for (int k = 0; k < 4; k++) ph0[k] = per_device[0].phase_ns[k];
     const double cpu0 = process_cpu_s();
     const auto t0 = std::chrono::steady_clock::now();
     std::this_thread::sleep_for(std::chrono::duration<double>(a.seconds));
@@ -178,6 +180,12 @@ int run(const Args &a, std::shared_ptr<const HipModel> model, M mapper, MakeRequ
         devs_json += buf;
     }
     const double evals_s = real / dt, mevals = (real ? real : 1) / 1e6;  // (a stalled run prints 0 evals/s, not inf)
+    {  // device 0, executor thread 0: microseconds of work per batch by phase (the rest of its work: job collection, reply fan-out)
+        const double batches = (double)(r1[0] - r0[0]) / (double)st.gpu_batch_size / (double)ne;
+        std::fprintf(stderr, "executor 0 per batch: prepare(own) %.1f us, merge %.1f us, submit %.1f us, assemble %.1f us\n",
+                     (per_device[0].phase_ns[0] - ph0[0]) * 1e-3 / batches, (per_device[0].phase_ns[1] - ph0[1]) * 1e-3 / batches,
+                     (per_device[0].phase_ns[2] - ph0[2]) * 1e-3 / batches, (per_device[0].phase_ns[3] - ph0[3]) * 1e-3 / batches);
+    }
     // ---- projection to one node of eight GPUs at this per-device rate: host cores (the whole process's CPU seconds per
     // second: executors, generators' request handling, the HIP runtime's own threads) and PCIe bytes ----
     const double per_dev_rate = evals_s / nd, cores_per_device = cpu_s / dt / nd;
