@@ -169,7 +169,11 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // while the other multiplies: the pair falls into complementary phases.
     {
         const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);  // HW_REG_LDS_ALLOC.LDS_BASE
-        if (lds_base == 0) __builtin_amdgcn_s_setprio(3);
+#ifndef KZ_BC_PRIO_MODE
+#define KZ_BC_PRIO_MODE 0  // diagnostic builds (tools/ab_go.sh): 1 = memory phases high / k-loops low for BOTH workgroups,
+#endif                     // 2 = the opposite, 3 = no priorities at all
+        if (KZ_BC_PRIO_MODE == 0 && lds_base == 0) __builtin_amdgcn_s_setprio(3);
+        if (KZ_BC_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(3);
     }
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nquarter = slot % a.nq, group = (slot / a.nq) * 8 + xcd;
@@ -347,6 +351,8 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     KZ_STAMP(3);
     for (int chunk = 0; chunk < chunks; chunk++) {
         __syncthreads();  // the chunk is staged
+        if (KZ_BC_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(0);
+        if (KZ_BC_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(3);
         KZ_STAMP(4 + (chunk & 3) * 4);
         // what the ring's dying stages fetch during the last PF k-steps of this chunk: the next chunk's image pieces, or
         // (last chunk) the residual's, or nothing
@@ -435,6 +441,8 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 if (stage_done) g++;
             }
         }
+        if (KZ_BC_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(3);
+        if (KZ_BC_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
         KZ_STAMP(5 + (chunk & 3) * 4);
         if (!last_chunk) {
             // ---- the next chunk's 12 pieces sit in the ring registers (piece 4 j + nt in stage j): into the image once
