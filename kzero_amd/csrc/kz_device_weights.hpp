@@ -184,6 +184,8 @@ struct DeviceWeights {
     int stem_cin_p = 0;  // != 0: the stem goes through the board-tile kernel and wants encoded rows of this many channels
     bool stem_split = false;  // split16 per layer: the stem too goes through kz_board_conv_split16 (<= 32 input planes)
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
+    // AttentionTower (kz_att_tower.hip): the model's own matrices in f32
+    float *att_expand = nullptr, *att_embedding = nullptr, *att_layers = nullptr;
     int *bc_rowmap = nullptr;  // (experiment build: kz_board_conv2_f16's tile-row map and halo-row list)
     unsigned short *bc_halo = nullptr;
     int bc_n_halo = 0;
@@ -204,7 +206,17 @@ struct DeviceWeights {
         }
         if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
 
-        if ((split16 && !use_board_split) || pairs16) {
+        if (m.tower_kind == kz::TOWER_ATTENTION) {
+            std::vector<float> all;
+            all.reserve(kz::att_tower_layer_elems(C, m.att_heads, m.att_dk, m.att_dv, m.att_dff) * m.att_layers.size());
+            for (auto &l : m.att_layers) {
+                all.insert(all.end(), l.qkv.begin(), l.qkv.end());
+                all.insert(all.end(), l.out.begin(), l.out.end());
+                all.insert(all.end(), l.ff0.begin(), l.ff0.end());
+                all.insert(all.end(), l.ff1.begin(), l.ff1.end());
+            }
+            if (upload_f32(m.att_expand, &att_expand) || upload_f32(m.att_embedding, &att_embedding) || upload_f32(all, &att_layers)) return 1;
+        } else if ((split16 && !use_board_split) || pairs16) {
             // f16 fragments — (hi, lo) pairs for split16 — in fragment order: 9 * ceil(c_in / 32) stem k-steps, then 9*C/32 per convolution
             // (+ the attention heads' five passes and bias rows when the split launch carries the heads)
             const bool conv_heads = (split16 && fused_split && m.policy_kind != kz::POLICY_ATTENTION) || (pairs16 && fused_pairs);  // (Ataxx, Go 9x9)

@@ -92,7 +92,7 @@ namespace {
 // for 128 / 256 channels only and the f32 matrix rate makes the zero work expensive).
 std::shared_ptr<Model> effective_model(const kz_model *model, int dtype_in, int max_batch) {
     const Model &m = *model->m;
-    if (dtype_in == KZ_DTYPE_F32 || m.channels % 64 == 0 || m.channels > 512 || m.depth < 1 || env_on("KZ_FORCE_GENERIC") ||
+    if (dtype_in == KZ_DTYPE_F32 || m.tower_kind != kz::TOWER_RES || m.channels % 64 == 0 || m.channels > 512 || m.depth < 1 || env_on("KZ_FORCE_GENERIC") ||
         env_on("KZ_KEEP_ACTIVATIONS"))
         return model->m;
     std::shared_ptr<Model> wide;
@@ -136,6 +136,7 @@ struct kz_engine {
         return 0;
     }
     std::vector<void *> allocs, pinned;
+    bool att_tower = false;  // AttentionTower network: kz_att_tower.hip runs the tower
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
     bool bsplit = false;  // split16 per layer through kz_board_conv_split16 (Go-size boards)
     bool wide = false;    // the plain-f16 one-launch tower with twice the boards per workgroup (PathPlan::wide)
@@ -389,6 +390,20 @@ struct kz_engine {
                   const kz::DecodeArgs *dec = nullptr) {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
+        if (att_tower) {  // AttentionTower: encoded planes in x_in -> tower output rows in act[0], one launch
+            kz::AttTowerArgs t{};
+            t.x0 = x_in; t.ldx0 = cin_p; t.in_f16 = dtype == KZ_DTYPE_F16; t.c_in = m.c_in;
+            t.expand = wts->att_expand; t.embedding = wts->att_embedding; t.layers = wts->att_layers;
+            t.y = act[0]; t.ldy = cp; t.out_f16 = dtype == KZ_DTYPE_F16;
+            t.batch = batch; t.h = m.h; t.w = m.w; t.depth = m.depth; t.d_model = m.channels; t.heads = m.att_heads;
+            t.d_k = m.att_dk; t.d_v = m.att_dv; t.d_ff = m.att_dff; t.alpha = m.att_alpha; t.eps = m.ln_eps;
+            prof.begin("kz_att_tower_f32", stream);
+            kz::launch_att_tower(t, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            tower_out = 0;
+            return 0;
+        }
         if (resident) {
             kz::TowerArgs t{};
             if (packed) {
@@ -799,6 +814,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         std::string why;
         if (!plan_path(m, max_batch, split16 ? KZ_DTYPE_F32_SPLIT16 : dtype, plan, why)) return fail("kz_engine_create: " + why);
     }
+    e->att_tower = plan.att_tower;
     e->resident = plan.resident;
     e->fused_heads = plan.fused_heads;
     e->keep = plan.keep;
@@ -881,7 +897,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 #ifdef KZ_EXPERIMENTS
     if (e->nb4 && e->dmalloc(&e->xres, kz::tower4_scratch_bytes(max_batch))) return 1;
 #endif
-    const int nact = (e->resident || e->resident32 || e->pairs16) ? 1 : 3;
+    const int nact = (e->resident || e->resident32 || e->pairs16 || e->att_tower) ? 1 : 3;
     for (int i = 0; i < nact; i++)
         if (e->dmalloc(&e->act[i], rows * e->cp * e->esz)) return 1;
     // head temporaries

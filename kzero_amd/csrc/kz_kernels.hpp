@@ -172,6 +172,22 @@ void board_conv2_pack_weights(const float *oihw, int cout, int cin, uint16_t *ds
 void board_conv2_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo);
 void launch_board_conv2(const BoardConvArgs &a, hipStream_t stream);
 
+// ---- AttentionTower (python/lib/model/attention.py:8-136) in exact f32, one workgroup per board, one launch per batch
+// (kz_att_tower.hip).  Reads the encoded planes, writes the tower output rows the head kernels read. ----
+struct AttTowerArgs {
+    const void *x0;       // encoded input [batch*h*w][ldx0], f32 or f16 (channels beyond c_in are zero)
+    int ldx0, in_f16, c_in;
+    const float *expand, *embedding;  // expand.weight [d_model][c_in], embedding [h*w][d_model]
+    const float *layers;  // per encoder layer: project_qkv | project_out | ff.0 | ff.2 weights as the model stores them
+    void *y;              // [batch*h*w][ldy], f32 or f16
+    int ldy, out_f16;
+    int batch, h, w, depth, d_model, heads, d_k, d_v, d_ff;
+    float alpha, eps;
+};
+bool att_tower_supported(int h, int w, int c_in, int d_model, int heads, int d_k, int d_v, int d_ff, int depth);
+size_t att_tower_layer_elems(int d_model, int heads, int d_k, int d_v, int d_ff);
+void launch_att_tower(const AttTowerArgs &t, hipStream_t stream);
+
 // ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----
 // Requirements: f32, channels 256 with h*w <= 64, or channels 128 with h*w <= 96; depth >= 1.
 struct Tower32Args {

@@ -206,6 +206,13 @@ struct Loader {
 
 // parameter count and direct-convolution FLOPs (2 per MAC, heads included: BASELINE.md §2) from the folded model;
 // used for models that do not come from a KZMODEL1 container
+// multiply-adds of AttentionTower.forward for one board: expand, and per layer the four Linear layers and the two batched
+// matrix products of the attention (attention.py:106-129)
+double attention_tower_macs(const Model &m) {
+    const double n = (double)m.h * m.w, D = m.channels, H = m.att_heads, dk = m.att_dk, dv = m.att_dv, dff = m.att_dff;
+    return n * m.c_in * D + m.depth * (n * D * H * (2 * dk + dv) + H * n * n * (dk + dv) + n * H * dv * D + 2 * n * D * dff);
+}
+
 void finalize_model(Model &m) {
     const int C = m.channels, hw = m.h * m.w;
     double macs = 0;
@@ -221,7 +228,13 @@ void finalize_model(Model &m) {
         params += (int64_t)l.w.size() + (int64_t)l.b.size();
     };
     for (auto &c : m.tower) conv(c, hw);
-    params += 2 * C;  // final BN as an affine
+    if (m.tower_kind == TOWER_ATTENTION) {
+        macs += attention_tower_macs(m);
+        params += (int64_t)m.att_expand.size() + (int64_t)m.att_embedding.size();
+        for (auto &l : m.att_layers) params += (int64_t)(l.qkv.size() + l.out.size() + l.ff0.size() + l.ff1.size());
+    } else {
+        params += 2 * C;  // final BN as an affine
+    }
     conv(m.sh_conv, hw);
     lin(m.sh_fc0);
     lin(m.sh_fc1);
@@ -312,6 +325,39 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
     const int C = m->channels, hw = m->h * m->w;
     double macs = 0;
 
+    auto tk = c.strings.find("tower_kind");
+    if (tk != c.strings.end() && tk->second == "attention") {
+        // AttentionTower (python/lib/model/attention.py:8-45) under its state_dict names
+        m->tower_kind = TOWER_ATTENTION;
+        const int H = m->att_heads = L.geti_in("att_heads", 0, 1, 256, true);
+        const int dk = m->att_dk = L.geti_in("att_d_k", 0, 1, 4096, true);
+        const int dv = m->att_dv = L.geti_in("att_d_v", 0, 1, 4096, true);
+        const int dff = m->att_dff = L.geti_in("att_d_ff", 0, 1, 1 << 16, true);
+        if (!L.ok) return nullptr;
+        if ((int64_t)H * (2 * dk + dv) > (1 << 16) || m->depth < 1) {
+            err = "bad attention tower descriptor";
+            return nullptr;
+        }
+        m->att_alpha = c.floats.count("att_alpha") ? (float)c.floats.at("att_alpha") : (float)std::pow(2.0 * m->depth, 0.25);
+        if (c.floats.count("ln_eps")) m->ln_eps = (float)c.floats.at("ln_eps");
+        m->att_expand = L.f32("common.expand.weight", (uint64_t)C * m->c_in);
+        m->att_embedding = L.f32("common.embedding", (uint64_t)hw * C);
+        for (int i = 0; i < m->depth; i++) {
+            const std::string p = "common.encoders." + std::to_string(i) + ".";
+            AttLayer l;
+            l.qkv = L.f32(p + "project_qkv.weight", (uint64_t)H * (2 * dk + dv) * C);
+            l.out = L.f32(p + "project_out.weight", (uint64_t)C * H * dv);
+            l.ff0 = L.f32(p + "ff.0.weight", (uint64_t)dff * C);
+            l.ff1 = L.f32(p + "ff.2.weight", (uint64_t)C * dff);
+            m->att_layers.push_back(std::move(l));
+        }
+        m->final_scale.assign(C, 1.0f);
+        m->final_shift.assign(C, 0.0f);
+        macs += attention_tower_macs(*m);
+    } else if (tk != c.strings.end() && tk->second != "res") {
+        err = "unknown tower_kind '" + tk->second + "'";
+        return nullptr;
+    } else {
     // ResTower: stem conv (no BN, no ReLU, post_act.py:205), ResBlocks (:214-228), final BN (:207)
     m->tower.push_back(L.conv("common.tower.0", C, m->c_in, 3));
     macs += (double)hw * C * m->c_in * 9;
@@ -329,6 +375,7 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
         macs += 2.0 * hw * C * C * 9;
     }
     L.bn_affine("common.tower." + std::to_string(m->depth + 1), C, final_affine, eps, m->final_scale, m->final_shift);
+    }
 
     // ScalarHead (post_act.py:10-23)
     m->sh_conv = L.conv("scalar_head.seq.0", sh_c, C, 1);
@@ -470,7 +517,7 @@ Linear widen_flat(const Linear &l, int in_p) {
 }  // namespace
 
 Model *pad_channels(const Model &m, int cpad) {
-    if (cpad <= m.channels) return nullptr;
+    if (cpad <= m.channels || m.tower_kind != TOWER_RES) return nullptr;  // (LayerNorm runs over d_model: it cannot be widened)
     std::unique_ptr<Model> o(new Model(m));
     const int C = m.channels, hw = m.h * m.w;
     o->channels = cpad;

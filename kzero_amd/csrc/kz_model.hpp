@@ -19,6 +19,17 @@ struct Linear {  // nn.Linear, weights [out][in]
     std::vector<float> w, b;
 };
 
+enum TowerKind { TOWER_RES = 0, TOWER_ATTENTION = 1 };
+
+// One EncoderLayer of AttentionTower (python/lib/model/attention.py:48-136): four bias-free Linear layers, two LayerNorms
+// without parameters
+struct AttLayer {
+    std::vector<float> qkv;  // project_qkv.weight [heads * (2 d_k + d_v)][d_model]: per head q | k | v rows
+    std::vector<float> out;  // project_out.weight [d_model][heads * d_v]
+    std::vector<float> ff0;  // ff.0.weight [d_ff][d_model]
+    std::vector<float> ff1;  // ff.2.weight [d_model][d_ff]
+};
+
 enum PolicyKind { POLICY_ATAXX_CONV = 0, POLICY_CONV = 1, POLICY_ATTENTION = 2, POLICY_DENSE = 3, POLICY_ARIMAA = 4 };
 
 struct Model {
@@ -38,6 +49,16 @@ struct Model {
     // backwards; the executor fuses it into the last conv's epilogue.
     std::vector<Conv> tower;
     std::vector<float> final_scale, final_shift;
+
+    // AttentionTower (python/lib/model/attention.py:8-45; the tower python/main/supervised_main_alpha.py:72 trains) instead of
+    // the ResTower: every square a token of `channels` = d_model features, `depth` encoder layers.  expand [d_model][c_in]
+    // (bias-free Linear over the input planes), embedding [h*w][d_model] added per square; DeepNorm residuals
+    // LayerNorm(x * alpha + f(x)) with alpha = (2 depth)^(1/4) (:22, :126, :129).  final_scale / final_shift stay (1, 0).
+    TowerKind tower_kind = TOWER_RES;
+    int att_heads = 0, att_dk = 0, att_dv = 0, att_dff = 0;
+    float att_alpha = 1.0f, ln_eps = 1e-5f;
+    std::vector<float> att_expand, att_embedding;
+    std::vector<AttLayer> att_layers;
 
     // ScalarHead (post_act.py:10-23)
     Conv sh_conv;

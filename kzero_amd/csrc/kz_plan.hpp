@@ -17,7 +17,10 @@
 //                      else channels % 64 == 0                    -> board_conv_split16      (one launch per layer)
 //                      else                                       -> refused (kz_model_supports_dtype says 0)
 // ------------------------------------------------------------------------------------------------
+//   AttentionTower (attention.py) instead of the ResTower, f32 and f16 -> attention_tower_f32 (one launch for the tower,
+//                      exact f32 arithmetic; f16 engines read and write f16 rows); f32split16 refused
 struct PathPlan {
+    bool att_tower = false;  // Model::tower_kind == TOWER_ATTENTION: kz_att_tower.hip
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, bsplit = false, pairs16 = false;
     bool fused32 = false, fused_split = false, fused_pairs = false, board_conv = false, keep = false;
     bool wide = false;  // tower_resident_f16g with twice the boards per workgroup (kz::tower_split_wide_supported)
@@ -62,6 +65,21 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
     const int cp = round_up(m.channels, 32);
     const bool force = env_on("KZ_FORCE_GENERIC"), nofuse = env_on("KZ_NO_FUSED_HEADS"), noboard = env_on("KZ_NO_BOARD_CONV");
     p = PathPlan();
+    if (m.tower_kind == kz::TOWER_ATTENTION) {
+        if (split16) {
+            why = "KZ_DTYPE_F32_SPLIT16 has no attention-tower kernel: an AttentionTower network runs as KZ_DTYPE_F32 (exact) or KZ_DTYPE_F16";
+            return false;
+        }
+        if (!kz::att_tower_supported(m.h, m.w, m.c_in, m.channels, m.att_heads, m.att_dk, m.att_dv, m.att_dff, m.depth)) {
+            why = "attention tower: the token matrix of one board (squares x (d_model + the larger of one head's q, k, v plus all "
+                  "heads' outputs, and d_ff)) does not fit the 160 KB of LDS of one workgroup, or the board has more than 384 squares";
+            return false;
+        }
+        p.att_tower = true;
+        p.path = "attention_tower_f32";
+        p.launches = 2 + head_launches(m, dtype, false, cp);  // encode, the tower, the heads
+        return true;
+    }
     p.resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth, m.c_in) && !force;
     p.fused_heads = p.resident && !nofuse &&
                     kz::tower_heads_supported((int)m.policy_kind, m.policy_query_channels, m.policy_len, m.sh_conv.cout, m.sh_fc0.out);

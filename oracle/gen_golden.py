@@ -39,18 +39,18 @@ from lib.model.post_act import (  # noqa: E402  (reference)
     PredictionHeads, ResTower, ScalarHead, AtaxxConvPolicyHead, AttentionPolicyHead, ConvPolicyHead,
     DensePolicyHead, ResBlock, ArimaaPolicyHead,
 )
+from lib.model.attention import AttentionTower  # noqa: E402  (reference)
 
 from kzero_amd.model_file import write_model  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 
 
-def build(game_name, depth, channels, head_kind, input_bool_channels=None, **head_args):
+def build(game_name, depth, channels, head_kind, input_bool_channels=None, attention=None, **head_args):
     game = Game.find(game_name)
     n_scalar = game.input_scalar_channels
     n_bool = game.input_bool_channels if input_bool_channels is None else input_bool_channels
     c_in = n_scalar + n_bool
-    tower = ResTower(depth, c_in, channels)
     scalar_head = ScalarHead(game.board_size, channels, 4, 32)
     meta = {
         "game": game.name,
@@ -61,6 +61,16 @@ def build(game_name, depth, channels, head_kind, input_bool_channels=None, **hea
         "policy_kind": head_kind, "policy_len": game.policy_size,
         "bn_eps": 1e-5,
     }
+    if attention is None:
+        tower = ResTower(depth, c_in, channels)
+    else:
+        # the tower python/main/supervised_main_alpha.py:72 trains: AttentionTower(board_size, input_channels, depth,
+        # d_model, heads, d_k, d_v, d_ff, dropout) (python/lib/model/attention.py:8-45); channels = d_model
+        heads, d_k, d_v, d_ff = attention
+        tower = AttentionTower(game.board_size, c_in, depth, channels, heads, d_k, d_v, d_ff, 0.1)
+        meta.update({"tower_kind": "attention", "att_heads": heads, "att_d_k": d_k, "att_d_v": d_v, "att_d_ff": d_ff,
+                     "att_alpha": float((2 * depth) ** (1 / 4)), "ln_eps": 1e-5})
+        del meta["tower_final_affine"]
     if head_kind == "ataxx_conv":
         head = AtaxxConvPolicyHead(game, channels)
         meta["policy_conv_channels"] = game.policy_conv_channels
@@ -181,7 +191,10 @@ def gen_net(name, seed, batch, p_bool, layers=False, onnx=False, **kw):
             return f
 
         handles = []
-        for i, m in enumerate(net.common.tower):
+        for i, m in enumerate(getattr(net.common, "encoders", [])):  # (n, b, d_model) -> [b][n][d_model]
+            handles.append(m.register_forward_hook(
+                lambda _m, _i, o, label=f"encoder.{i}": acts.__setitem__(label, o.detach().permute(1, 0, 2).contiguous().numpy())))
+        for i, m in enumerate(getattr(net.common, "tower", [])):
             handles.append(m.register_forward_hook(hook(f"tower.{i}")))
             if isinstance(m, ResBlock):
                 handles.append(m.seq[2].register_forward_hook(hook(f"tower.{i}.mid")))
@@ -269,8 +282,23 @@ def main_round5():
             game_name="sttt", depth=2, channels=16, head_kind="dense", hidden_channels=2, hidden_size=24)
 
 
+def main_attention():
+    """PredictionHeads(AttentionTower, ScalarHead, head): the network python/main/supervised_main_alpha.py:69-77 builds
+    (there: depth 16, d_model 256, 8 heads, d_k = d_v = 16, d_ff 256 on chess).  Small instances, one with a sequence
+    length that is not a multiple of 16 (Ataxx 7x7: 49 squares) and d_k != d_v."""
+    os.makedirs(OUT, exist_ok=True)
+    gen_net("chess_att2x64", 21, 3, 0.05, layers=True, onnx=True,
+            game_name="chess", depth=2, channels=64, head_kind="attention", query_channels=16, attention=(4, 16, 16, 96))
+    gen_net("ataxx7_att2x32", 22, 3, 0.3,
+            game_name="ataxx-7", depth=2, channels=32, head_kind="ataxx_conv", attention=(2, 8, 12, 48))
+    gen_net("chess_att3x256", 23, 2, 0.05,
+            game_name="chess", depth=3, channels=256, head_kind="attention", query_channels=32, attention=(8, 16, 16, 256))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "round5":
         main_round5()
+    elif len(sys.argv) > 1 and sys.argv[1] == "attention":
+        main_attention()
     else:
         main()

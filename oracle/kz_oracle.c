@@ -59,6 +59,9 @@ typedef struct kzo_net {
 
     int h, w, n_scalar, n_bool, c_in;
     int depth, channels, final_affine;
+    int tower_kind; /* 0 ResTower (post_act.py:201-211), 1 AttentionTower (attention.py:8-45) */
+    int att_heads, att_dk, att_dv, att_dff;
+    float att_alpha, ln_eps;
     int sh_channels, sh_size;
     int policy_len;
     int policy_kind; /* 0 ataxx_conv, 1 conv, 2 attention, 3 dense, 4 arimaa */
@@ -233,6 +236,25 @@ KZO_EXPORT int kzo_load(const void *blob, size_t len, kzo_net **out) {
     net->arimaa_hidden_size = (int)meta_int(net, "policy_arimaa_hidden_size", 0);
     const kzo_meta *eps = find_meta(net, "bn_eps");
     net->bn_eps = eps ? (float)(eps->kind == 1 ? eps->f : (double)eps->i) : 1e-5f;
+    const kzo_meta *tk = find_meta(net, "tower_kind");
+    net->tower_kind = 0;
+    if (tk && tk->kind == 2 && !strcmp(tk->s, "attention")) {
+        net->tower_kind = 1;
+        net->att_heads = (int)meta_int(net, "att_heads", 0);
+        net->att_dk = (int)meta_int(net, "att_d_k", 0);
+        net->att_dv = (int)meta_int(net, "att_d_v", 0);
+        net->att_dff = (int)meta_int(net, "att_d_ff", 0);
+        const kzo_meta *al = find_meta(net, "att_alpha"), *le = find_meta(net, "ln_eps");
+        net->att_alpha = al ? (float)(al->kind == 1 ? al->f : (double)al->i) : 1.0f;
+        net->ln_eps = le && le->kind == 1 ? (float)le->f : 1e-5f;
+        if (net->att_heads <= 0 || net->att_dk <= 0 || net->att_dv <= 0 || net->att_dff <= 0) {
+            kzo_free(net);
+            return fail("bad attention tower descriptor");
+        }
+    } else if (tk && !(tk->kind == 2 && !strcmp(tk->s, "res"))) {
+        kzo_free(net);
+        return fail("unknown tower_kind");
+    }
     const kzo_meta *kind = find_meta(net, "policy_kind");
     if (!kind || kind->kind != 2) {
         kzo_free(net);
@@ -469,6 +491,119 @@ static int get_bn(const kzo_net *net, const char *prefix, int c, int affine, bnp
     return (bn->mean && bn->var) ? 0 : -1;
 }
 
+/* y[r][o] = sum_i x[r][i] * wt[o][i]: nn.Linear(bias=False) on `rows` rows */
+static void linear_rows(const float *x, int rows, int in, const float *wt, int out, float *y) {
+    for (int r = 0; r < rows; r++)
+        for (int o = 0; o < out; o++) {
+            float acc = 0.0f;
+            for (int i = 0; i < in; i++) acc += x[(size_t)r * in + i] * wt[(size_t)o * in + i];
+            y[(size_t)r * out + o] = acc;
+        }
+}
+
+/* nn.LayerNorm(d, elementwise_affine=False) over each row: (x - mean) / sqrt(biased var + eps) */
+static void layernorm_rows(float *x, int rows, int d, float eps) {
+    for (int r = 0; r < rows; r++) {
+        float *v = x + (size_t)r * d;
+        float mean = 0.0f, var = 0.0f;
+        for (int i = 0; i < d; i++) mean += v[i];
+        mean /= (float)d;
+        for (int i = 0; i < d; i++) var += (v[i] - mean) * (v[i] - mean);
+        var /= (float)d;
+        const float inv = 1.0f / sqrtf(var + eps);
+        for (int i = 0; i < d; i++) v[i] = (v[i] - mean) * inv;
+    }
+}
+
+/* AttentionTower.forward (python/lib/model/attention.py:32-45) for one board: input [c_in][hw] -> x_out [d_model][hw].
+ * Every square is a token; the encoder layers are EncoderLayer.forward_with_weights (:97-133) in eval mode (dropout = id). */
+static int attention_tower(const kzo_net *net, const float *input, float *x_out, int board, kzo_trace_fn trace, void *user) {
+    const int n = net->h * net->w, D = net->channels, H = net->att_heads, dk = net->att_dk, dv = net->att_dv;
+    const int dff = net->att_dff, dkqv = 2 * dk + dv, cin = net->c_in;
+    const float alpha = net->att_alpha;
+    char name[128];
+    int rc = -1;
+    const float *expand = tensor_f32(net, "common.expand.weight", (uint64_t)D * cin);
+    const float *embedding = tensor_f32(net, "common.embedding", (uint64_t)n * D);
+    if (!expand || !embedding) return -1;
+    float *cur = malloc(sizeof(float) * (size_t)n * D);
+    float *qkv = malloc(sizeof(float) * (size_t)n * H * dkqv);
+    float *att = malloc(sizeof(float) * (size_t)n * H * dv);
+    float *tmp = malloc(sizeof(float) * (size_t)n * (D > dff ? D : dff));
+    float *mid = malloc(sizeof(float) * (size_t)n * D);
+    float *wrow = malloc(sizeof(float) * (size_t)n);
+
+    /* "b c h w -> (h w) b c", expand (Linear, no bias) + embedding (:35-40) */
+    for (int p = 0; p < n; p++)
+        for (int c = 0; c < D; c++) {
+            float acc = 0.0f;
+            for (int i = 0; i < cin; i++) acc += input[(size_t)i * n + p] * expand[(size_t)c * cin + i];
+            cur[(size_t)p * D + c] = acc + embedding[(size_t)p * D + c];
+        }
+
+    for (int l = 0; l < net->depth; l++) {
+        snprintf(name, sizeof name, "common.encoders.%d.project_qkv.weight", l);
+        const float *wqkv = tensor_f32(net, name, (uint64_t)H * dkqv * D);
+        snprintf(name, sizeof name, "common.encoders.%d.project_out.weight", l);
+        const float *wout = tensor_f32(net, name, (uint64_t)D * H * dv);
+        snprintf(name, sizeof name, "common.encoders.%d.ff.0.weight", l);
+        const float *wf0 = tensor_f32(net, name, (uint64_t)dff * D);
+        snprintf(name, sizeof name, "common.encoders.%d.ff.2.weight", l);
+        const float *wf2 = tensor_f32(net, name, (uint64_t)D * dff);
+        if (!wqkv || !wout || !wf0 || !wf2) goto done;
+
+        /* qkv = project_qkv(input).view(n, b * heads, d_kqv) (:106): token p's row holds, head after head, q | k | v */
+        linear_rows(cur, n, D, wqkv, H * dkqv, qkv);
+        for (int hh = 0; hh < H; hh++) {
+            for (int pq = 0; pq < n; pq++) {
+                const float *q = qkv + (size_t)pq * H * dkqv + (size_t)hh * dkqv;
+                /* logits = q k^T with no scale factor (:117-118), softmax over the keys (:119) */
+                float mx = -INFINITY;
+                for (int pk = 0; pk < n; pk++) {
+                    const float *k = qkv + (size_t)pk * H * dkqv + (size_t)hh * dkqv + dk;
+                    float acc = 0.0f;
+                    for (int j = 0; j < dk; j++) acc += q[j] * k[j];
+                    wrow[pk] = acc;
+                    if (acc > mx) mx = acc;
+                }
+                float sum = 0.0f;
+                for (int pk = 0; pk < n; pk++) {
+                    wrow[pk] = expf(wrow[pk] - mx);
+                    sum += wrow[pk];
+                }
+                /* att_raw = weights v (:122), heads side by side in the token's row (:124) */
+                for (int j = 0; j < dv; j++) {
+                    float acc = 0.0f;
+                    for (int pk = 0; pk < n; pk++)
+                        acc += (wrow[pk] / sum) * qkv[(size_t)pk * H * dkqv + (size_t)hh * dkqv + 2 * dk + j];
+                    att[(size_t)pq * H * dv + (size_t)hh * dv + j] = acc;
+                }
+            }
+        }
+        /* att_result = norm_att(input * alpha + project_out(att)) (:125-126) */
+        linear_rows(att, n, H * dv, wout, D, tmp);
+        for (int i = 0; i < n * D; i++) mid[i] = cur[i] * alpha + tmp[i];
+        layernorm_rows(mid, n, D, net->ln_eps);
+        /* ff_result = norm_ff(att_result * alpha + ff(att_result)) (:128-129), ff = Linear, ReLU, Linear without biases (:74-78) */
+        linear_rows(mid, n, D, wf0, dff, tmp);
+        relu(tmp, (size_t)n * dff);
+        linear_rows(tmp, n, dff, wf2, D, cur);
+        for (int i = 0; i < n * D; i++) cur[i] = mid[i] * alpha + cur[i];
+        layernorm_rows(cur, n, D, net->ln_eps);
+        if (trace) {
+            snprintf(name, sizeof name, "encoder.%d", l);
+            trace(name, cur, n * D, board, user);
+        }
+    }
+    /* "(h w) b c -> b c h w" (:43-44) */
+    for (int p = 0; p < n; p++)
+        for (int c = 0; c < D; c++) x_out[(size_t)c * n + p] = cur[(size_t)p * D + c];
+    rc = 0;
+done:
+    free(cur); free(qkv); free(att); free(tmp); free(mid); free(wrow);
+    return rc;
+}
+
 /* One board through PredictionHeads.forward (post_act.py:194-198). Returns 0 or -1. */
 static int forward_board(const kzo_net *net, const float *input, float *scalars_out, float *policy_out, int board,
                          kzo_trace_fn trace, void *user) {
@@ -480,6 +615,10 @@ static int forward_board(const kzo_net *net, const float *input, float *scalars_
     float *t1 = malloc(sizeof(float) * (size_t)C * hw);
     float *head = NULL;
 
+    if (net->tower_kind == 1) {
+        if (attention_tower(net, input, x, board, trace, user)) goto done;
+        goto heads;
+    }
     /* ResTower (post_act.py:201-211): stem conv with no BN and no ReLU (:205) */
     convp stem;
     if (get_conv(net, "common.tower.0", C, net->c_in, 3, &stem)) goto done;
@@ -528,6 +667,7 @@ static int forward_board(const kzo_net *net, const float *input, float *scalars_
         }
     }
 
+heads:
     /* ScalarHead (post_act.py:10-23): conv1x1 -> ReLU -> Flatten (channel-major) -> Linear -> ReLU -> Linear(5) */
     {
         const int hc = net->sh_channels, hs = net->sh_size;

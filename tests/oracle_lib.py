@@ -141,7 +141,9 @@ def read_packed(name, n_bool, n_scalar, h, w):
 GOLDEN_NETS = ["ataxx7_2x16", "ataxx7_4x64", "chess_2x32_att", "chess_2x32_dense_h", "chess_1x32_dense",
                "go9_2x16_conv", "go9_2x16_conv_terr",
                # round 5: the other games the server dispatches (server.rs:114-185)
-               "arimaa_2x32", "ttt_2x16_dense", "sttt_2x16_dense_h"]
+               "arimaa_2x32", "ttt_2x16_dense", "sttt_2x16_dense_h",
+               # PredictionHeads(AttentionTower, ...) (python/lib/model/attention.py; supervised_main_alpha.py:69-77)
+               "chess_att2x64", "ataxx7_att2x32", "chess_att3x256"]
 
 
 def load_blob(name):

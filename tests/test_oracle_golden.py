@@ -31,8 +31,8 @@ def test_forward_threads_identical():
     assert np.array_equal(s1, s4) and np.array_equal(p1, p4)
 
 
-def test_per_layer_activations():
-    name = "ataxx7_2x16"
+@pytest.mark.parametrize("name", ["ataxx7_2x16", "chess_att2x64"])
+def test_per_layer_activations(name):
     net = O.OracleNet(O.load_blob(name))
     x, _, _ = O.read_io(name, "planes", net.c_in, net.h, net.w, net.policy_len)
     _, _, acts = net.forward_trace(x)
