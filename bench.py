@@ -71,6 +71,11 @@ WORKLOADS = {
                          engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Chess 20x512 ResNet b=256"),
     "go9-20x256": dict(game="go-9", depth=20, channels=256, head="conv", batch=256, steps=1000,
                        engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Go 9x9 20x256 ResNet b=256"),
+    # the network python/main/supervised_main_alpha.py:69-77 trains on chess: AttentionTower(8, 21, depth 16, d_model 256,
+    # 8 heads, d_k = d_v = 16, d_ff 256) under the ScalarHead and the AttentionPolicyHead (0.594 GFLOP per eval)
+    "chess-att16x256": dict(game="chess", depth=16, channels=256, head="attention", batch=256, steps=1000,
+                            engines={"f16": 2, "f32": 2}, model_kw=dict(attention=(8, 16, 16, 256)),
+                            label="Chess AttentionTower 16x256 (8 heads) b=256 (supervised_main_alpha.py)"),
     "go13-20x128": dict(game="go-13", depth=20, channels=128, head="conv", batch=256, steps=1000,
                         engines={"f16": 2, "f32": 2, "f32split16": 2}, label="Go 13x13 20x128 ResNet b=256"),
 }
@@ -92,6 +97,7 @@ KERNEL_OF_PATH = {
     "tower_resident_split16": "kz_tower_resident_split", "tower_resident_split16+heads": "kz_tower_resident_split",
     "tower_resident_f16g": "kz_tower_resident_f16g", "tower_resident_f16g+heads": "kz_tower_resident_f16g",
     "board_conv_f16": "kz_board_conv_f16",
+    "attention_tower_f16": "kz_att_tower_f16", "attention_tower_f32": "kz_att_tower_f32",
     "board_conv_split16": "kz_board_conv_split16",
     "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32",
 }
@@ -100,6 +106,7 @@ KERNEL_SOURCE = {
     "kz_tower_resident_f16": "kz_tower.hip", "kz_tower_resident_f32": "kz_tower_f32.hip",
     "kz_tower_resident_split": "kz_tower_split.hip", "kz_tower_resident_f16g": "kz_tower_f16g.hip",
     "kz_board_conv_f16": "kz_board_conv.hip", "kz_board_conv_split16": "kz_board_conv.hip", "kz_conv_igemm_f16": "kz_kernels.hip", "kz_conv_igemm_f32": "kz_kernels.hip",
+    "kz_att_tower_f16": "kz_att_tower_f16.hip", "kz_att_tower_f32": "kz_att_tower.hip",
 }
 # device code a kernel source pulls in (hashed with it: a traffic record goes stale when either changes).  The (hi, lo) tower
 # and its plain-f16 sibling are one template (kz_tower_pairs.hpp) instantiated by a translation unit each: an edit to one
@@ -289,7 +296,8 @@ class Workload:
         wl = WORKLOADS[name]
         self.wl = wl
         dtype = {"f16": capi.KZ_DTYPE_F16, "f32": capi.KZ_DTYPE_F32, "f32split16": capi.KZ_DTYPE_F32_SPLIT16}[dtype_name]
-        self.blob = synth.random_model(wl["game"], wl["depth"], wl["channels"], wl["head"], seed=0, **(model_kw or {}))
+        self.blob = synth.random_model(wl["game"], wl["depth"], wl["channels"], wl["head"], seed=0,
+                                       **{**wl.get("model_kw", {}), **(model_kw or {})})
         self.model = capi.Model(blob=self.blob)
         self.info = self.model.info
         self.bits, self.scalars_in = synth.random_boards(wl["game"], batch, seed=seed)
@@ -360,7 +368,7 @@ class Workload:
         """One launch per layer (85 per Go batch): HIP events around every launch cost such a path 1.7 % of its rate
         (Go-19: 36.2k against 36.8k evals/s), so its K timed steps run without them and the dominant kernel's average
         launch duration comes from an instrumented pass of the same steps right behind the timed region."""
-        return not self.tower_path.startswith("tower_resident")
+        return not self.tower_path.startswith(("tower_resident", "attention_tower"))
 
     def instrumented_pass(self, step, steps):
         self.profiling(True)
@@ -433,6 +441,10 @@ class Workload:
         p = self.tower_path
         if p.endswith("+heads"):
             return info.flops_per_eval * B  # one launch = tower + heads for one batch
+        if p.startswith("attention_tower"):  # one launch = the AttentionTower of one batch: all but the heads' FLOP
+            heads = 2.0 * (hw * 4 * C + 32 * 4 * hw + 5 * 32)  # ScalarHead(board, C, 4, 32)
+            return (info.flops_per_eval - heads) * B if info.policy_kind != 2 else \
+                (info.flops_per_eval - heads - 2.0 * (64 * 2 * C * C + 8 * 3 * C * C + 64 * 88 * C)) * B
         if p.startswith("tower_resident"):
             return tower * B  # one launch = the whole tower for one batch
         if p in ("board_conv_f16", "board_conv_split16"):
@@ -450,6 +462,10 @@ class Workload:
         io = B * (self.stride + 4 * info.input_scalar_channels + 4 * (5 + info.policy_len))
         if p.endswith("+heads"):
             return int(info.param_count * wbytes + io)
+        if p.startswith("attention_tower"):  # its weights (all but the heads'), the encoded planes in, the tower output out
+            head_params = 4 * C + 4 + 32 * 4 * hw + 32 + 5 * 32 + 5 + (2 * C * C + 2 * C + 3 * C * C + 3 * C if info.policy_kind == 2 else 0)
+            act = B * hw * (wbytes if self.dtype_name == "f16" else 4)
+            return int((info.param_count - head_params) * wbytes + act * (-(-info.input_channels // 32) * 32 + C))
         tower_params = 9 * C * (info.input_channels + 2 * info.tower_depth * C)
         if p.startswith("tower_resident"):
             act = B * hw * C * (4 if self.dtype_name != "f16" else 2)  # the tower output written for the head kernels

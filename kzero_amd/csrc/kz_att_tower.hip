@@ -25,8 +25,11 @@ struct AttGeo {
     int n, D, H, dk, dv, dff, c_in;
     int ldx, ldq, lda, ldt, ldi, np;  // row strides (floats) of X, QKV, ATT, TMP, IN; np = n rounded up to 64 (a wave's weights row)
     int off_r, off_w;                 // float offsets of the overlaid region and of the weight tile
+    int ff_rows;                      // tokens per pass of the feed-forward pair (all n where the hidden layer fits the region)
     size_t lds_floats;
 };
+
+constexpr size_t AT_MAX_LDS = 160 * 1024;
 
 __host__ __device__ inline int at_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -39,9 +42,13 @@ __host__ __device__ inline AttGeo att_geo(int n, int c_in, int D, int H, int dk,
     g.ldt = at_round_up(dff, 4) + 4;
     g.ldi = at_round_up(c_in, 4) + 4;
     g.np = at_round_up(n, 64);
-    const int attention = n * g.ldq + n * g.lda + AT_WAVES * g.np, ff = n * g.ldt, in = n * g.ldi;
-    const int r = attention > ff ? (attention > in ? attention : in) : (ff > in ? ff : in);
+    const int attention = n * g.ldq + n * g.lda + AT_WAVES * g.np, in = n * g.ldi;
     g.off_r = n * g.ldx;
+    // the feed-forward pair is token-wise: where [n][d_ff] does not fit beside X, it runs over as many tokens at a time as do
+    const long budget = (long)(AT_MAX_LDS / 4) - g.off_r - 64 * AT_WT_LD - 4;
+    g.ff_rows = budget / g.ldt >= n ? n : (int)(budget / g.ldt > 0 ? budget / g.ldt : 0);
+    const int ff = g.ff_rows * g.ldt;
+    const int r = attention > ff ? (attention > in ? attention : in) : (ff > in ? ff : in);
     g.off_w = g.off_r + at_round_up(r, 4);
     g.lds_floats = (size_t)g.off_w + 64 * AT_WT_LD;
     return g;
@@ -239,10 +246,14 @@ __global__ __launch_bounds__(AT_THREADS) void kz_att_tower_f32(AttTowerDev a) {
             layernorm_rows(X, g.ldx, n, D, a.eps);
             __syncthreads();
             // ff_result = norm_ff(att_result * alpha + ff(att_result)) (:128-129); ff = Linear, ReLU, Linear (:74-78)
-            gemm_rows(X, g.ldx, n, D, wf0, dff, wst, [&](int r, int c, float v) { TMP[r * g.ldt + c] = fmaxf(v, 0.0f); });
-            __syncthreads();
-            gemm_rows(TMP, g.ldt, n, dff, wf1, D, wst, [&](int r, int c, float v) { X[r * g.ldx + c] = fmaf(X[r * g.ldx + c], a.alpha, v); });
-            __syncthreads();
+            for (int r0 = 0; r0 < n; r0 += g.ff_rows) {
+                const int nr = min(g.ff_rows, n - r0);
+                float *Xr = X + r0 * g.ldx;
+                gemm_rows(Xr, g.ldx, nr, D, wf0, dff, wst, [&](int r, int c, float v) { TMP[r * g.ldt + c] = fmaxf(v, 0.0f); });
+                __syncthreads();
+                gemm_rows(TMP, g.ldt, nr, dff, wf1, D, wst, [&](int r, int c, float v) { Xr[r * g.ldx + c] = fmaf(Xr[r * g.ldx + c], a.alpha, v); });
+                __syncthreads();
+            }
             layernorm_rows(X, g.ldx, n, D, a.eps);
             __syncthreads();
         }
@@ -257,15 +268,14 @@ __global__ __launch_bounds__(AT_THREADS) void kz_att_tower_f32(AttTowerDev a) {
     }
 }
 
-constexpr size_t AT_MAX_LDS = 160 * 1024;
-
 }  // namespace
 
 bool att_tower_supported(int h, int w, int c_in, int d_model, int heads, int d_k, int d_v, int d_ff, int depth) {
     const int n = h * w;
     if (n < 1 || n > 64 * AT_KMAX || depth < 1 || c_in < 1 || d_model < 1 || heads < 1 || d_k < 1 || d_v < 1 || d_ff < 1) return false;
     if ((size_t)n * (d_model + d_ff + heads * (2 * d_k + d_v)) > ((size_t)1 << 24)) return false;  // (before any product can overflow)
-    return att_geo(n, c_in, d_model, heads, d_k, d_v, d_ff).lds_floats * 4 <= AT_MAX_LDS;
+    const AttGeo g = att_geo(n, c_in, d_model, heads, d_k, d_v, d_ff);
+    return g.lds_floats * 4 <= AT_MAX_LDS && g.ff_rows >= (n < 16 ? n : 16);
 }
 
 size_t att_tower_layer_elems(int d_model, int heads, int d_k, int d_v, int d_ff) {

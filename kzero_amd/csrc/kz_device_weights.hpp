@@ -186,6 +186,8 @@ struct DeviceWeights {
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
     // AttentionTower (kz_att_tower.hip): the model's own matrices in f32
     float *att_expand = nullptr, *att_embedding = nullptr, *att_layers = nullptr;
+    bool att_f16 = false;  // (set before build) the f16 launch's fragment streams instead of att_expand / att_layers
+    void *att16_expand = nullptr, *att16_layers = nullptr;
     int *bc_rowmap = nullptr;  // (experiment build: kz_board_conv2_f16's tile-row map and halo-row list)
     unsigned short *bc_halo = nullptr;
     int bc_n_halo = 0;
@@ -206,7 +208,19 @@ struct DeviceWeights {
         }
         if (upload_f32(ps, &post_scale) || upload_f32(pt, &post_shift)) return 1;
 
-        if (m.tower_kind == kz::TOWER_ATTENTION) {
+        if (m.tower_kind == kz::TOWER_ATTENTION && att_f16) {
+            const int cin_p = round_up(m.c_in, 32);
+            std::vector<uint16_t> ex(kz::att_tower16_expand_elems(C, cin_p));
+            kz::att_tower16_pack_expand(m.att_expand.data(), C, m.c_in, cin_p, ex.data());
+            const size_t per = kz::att_tower16_layer_elems(C, m.att_dff);
+            std::vector<uint16_t> all(per * m.att_layers.size());
+            for (size_t l = 0; l < m.att_layers.size(); l++)
+                kz::att_tower16_pack_layer(m.att_layers[l].qkv.data(), m.att_layers[l].out.data(), m.att_layers[l].ff0.data(),
+                                           m.att_layers[l].ff1.data(), C, m.att_dff, all.data() + per * l);
+            if (upload(ex.data(), ex.size() * 2, &att16_expand) || upload(all.data(), all.size() * 2, &att16_layers) ||
+                upload_f32(m.att_embedding, &att_embedding))
+                return 1;
+        } else if (m.tower_kind == kz::TOWER_ATTENTION) {
             std::vector<float> all;
             all.reserve(kz::att_tower_layer_elems(C, m.att_heads, m.att_dk, m.att_dv, m.att_dff) * m.att_layers.size());
             for (auto &l : m.att_layers) {

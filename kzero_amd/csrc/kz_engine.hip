@@ -137,6 +137,7 @@ struct kz_engine {
     }
     std::vector<void *> allocs, pinned;
     bool att_tower = false;  // AttentionTower network: kz_att_tower.hip runs the tower
+    bool att_f16 = false;    // ... kz_att_tower_f16.hip does
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
     bool bsplit = false;  // split16 per layer through kz_board_conv_split16 (Go-size boards)
     bool wide = false;    // the plain-f16 one-launch tower with twice the boards per workgroup (PathPlan::wide)
@@ -390,6 +391,18 @@ struct kz_engine {
                   const kz::DecodeArgs *dec = nullptr) {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
+        if (att_f16) {  // AttentionTower on the f16 matrix cores
+            kz::AttTower16Args t{};
+            t.x0 = x_in; t.cin_p = cin_p; t.w_expand = wts->att16_expand; t.embedding = wts->att_embedding;
+            t.w_layers = wts->att16_layers; t.y = act[0]; t.batch = batch; t.depth = m.depth; t.d_model = m.channels;
+            t.d_ff = m.att_dff; t.alpha = m.att_alpha; t.eps = m.ln_eps;
+            prof.begin("kz_att_tower_f16", stream);
+            kz::launch_att_tower16(t, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            tower_out = 0;
+            return 0;
+        }
         if (att_tower) {  // AttentionTower: encoded planes in x_in -> tower output rows in act[0], one launch
             kz::AttTowerArgs t{};
             t.x0 = x_in; t.ldx0 = cin_p; t.in_f16 = dtype == KZ_DTYPE_F16; t.c_in = m.c_in;
@@ -815,6 +828,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         if (!plan_path(m, max_batch, split16 ? KZ_DTYPE_F32_SPLIT16 : dtype, plan, why)) return fail("kz_engine_create: " + why);
     }
     e->att_tower = plan.att_tower;
+    e->att_f16 = plan.att_f16;
     e->resident = plan.resident;
     e->fused_heads = plan.fused_heads;
     e->keep = plan.keep;
@@ -855,7 +869,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         const char *c2 = getenv("KZ_BOARD_CONV2");  // (the opt-in board-conv organisation has its own weight packing)
         variant = c2 && c2[0] == '1' ? 400 : 0;
 #endif
-        auto key = std::make_tuple(e->model.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + variant,
+        auto key = std::make_tuple(e->model.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + (e->att_f16 ? 800 : 0) + variant,
                                    e->resident || e->resident32,
                                    e->fused_heads || e->fused_split || e->fused_pairs, board_conv);
         auto it = g_cache.find(key);
@@ -868,6 +882,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->use_board_split = e->bsplit;
             w->fused_split = e->fused_split;
             w->fused_pairs = e->fused_pairs;
+            w->att_f16 = e->att_f16;
             if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16, e->pairs16)) return 1;
             g_cache[key] = w;
             e->wts = w;
@@ -973,7 +988,8 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     if ((batch < 0 || batch > e->max_batch ? fail("kz_engine_launch_geometry: batch out of range") : 0)) return 1;
     const Model &m = *e->model;
     int per = 0, wgs = 0;
-    if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
+    if (e->att_tower) per = 1;  // a workgroup is a board
+    else if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
     else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16,
                                                          e->wide ? batch : 0);  // (per launch: the widest level this batch fills the chip with)
     else if (e->resident32) per = e->t32_dense3 ? 3 : kz::tower32_boards_per_workgroup(m.h, m.w, m.channels);

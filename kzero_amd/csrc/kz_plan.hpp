@@ -17,10 +17,14 @@
 //                      else channels % 64 == 0                    -> board_conv_split16      (one launch per layer)
 //                      else                                       -> refused (kz_model_supports_dtype says 0)
 // ------------------------------------------------------------------------------------------------
-//   AttentionTower (attention.py) instead of the ResTower, f32 and f16 -> attention_tower_f32 (one launch for the tower,
-//                      exact f32 arithmetic; f16 engines read and write f16 rows); f32split16 refused
+//   AttentionTower (attention.py) instead of the ResTower:
+//     dtype f16, 8x8, 8 heads of d_k = d_v = 16, d_model 128 / 256  -> attention_tower_f16 (one launch for the tower)
+//     else (f32, or f16 on another shape)                           -> attention_tower_f32 (one launch, exact f32 arithmetic;
+//                                                                      f16 engines read and write f16 rows)
+//     f32split16                                                    -> refused
 struct PathPlan {
     bool att_tower = false;  // Model::tower_kind == TOWER_ATTENTION: kz_att_tower.hip
+    bool att_f16 = false;    // ... on the f16 matrix cores: kz_att_tower_f16.hip
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, bsplit = false, pairs16 = false;
     bool fused32 = false, fused_split = false, fused_pairs = false, board_conv = false, keep = false;
     bool wide = false;  // tower_resident_f16g with twice the boards per workgroup (kz::tower_split_wide_supported)
@@ -71,12 +75,14 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
             return false;
         }
         if (!kz::att_tower_supported(m.h, m.w, m.c_in, m.channels, m.att_heads, m.att_dk, m.att_dv, m.att_dff, m.depth)) {
-            why = "attention tower: the token matrix of one board (squares x (d_model + the larger of one head's q, k, v plus all "
-                  "heads' outputs, and d_ff)) does not fit the 160 KB of LDS of one workgroup, or the board has more than 384 squares";
+            why = "attention tower: the token matrix of one board (squares x d_model) with one head's q, k, v and all heads' "
+                  "outputs beside it does not fit the 160 KB of LDS of one workgroup, or the board has more than 384 squares";
             return false;
         }
         p.att_tower = true;
-        p.path = "attention_tower_f32";
+        p.att_f16 = dtype == KZ_DTYPE_F16 && !force &&
+                    kz::att_tower16_supported(m.h, m.w, m.c_in, m.channels, m.att_heads, m.att_dk, m.att_dv, m.att_dff, m.depth);
+        p.path = p.att_f16 ? "attention_tower_f16" : "attention_tower_f32";
         p.launches = 2 + head_launches(m, dtype, false, cp);  // encode, the tower, the heads
         return true;
     }

@@ -92,12 +92,15 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
                  n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0,
                  dense_hidden_channels: int = None, dense_hidden_size: int = None, scalar_hidden_channels: int = 4,
                  final_affine: bool = True, init: str = "uniform", arimaa_hidden_channels: int = 2,
-                 arimaa_hidden_size: int = 32) -> bytes:
+                 arimaa_hidden_size: int = 32, attention: tuple = None) -> bytes:
     """`block_gain` > 1 scales every block's second BatchNorm weight: the residual stream then grows from block to block
     the way a trained network's does (a random-init tower keeps it within a few tens).
     `init`: "uniform" = PyTorch's default for Conv2d / Linear (U(+-1/sqrt(fan_in))); "kaiming_normal" = convolution weights
     from N(0, sqrt(2 / fan_in)) — a bell-shaped weight distribution with 2.4 x the standard deviation (the matrix cores'
-    power draw, and with it the clock they sustain, depends on the data: DESIGN.md, bench.py `weights`)."""
+    power draw, and with it the clock they sustain, depends on the data: DESIGN.md, bench.py `weights`).
+    `attention` = (heads, d_k, d_v, d_ff): AttentionTower(board_size, input_channels, depth, channels, heads, d_k, d_v, d_ff)
+    (python/lib/model/attention.py:8-30) in place of the ResTower, initialised as the reference does (:84-95: Xavier-normal,
+    gain (8 depth)^(-1/4) for v / project_out / ff, gain 1 for q / k; embedding N(0, 1); expand nn.Linear's default)."""
     global _INIT
     if init not in ("uniform", "kaiming_normal"):
         raise ValueError(f"unknown init '{init}'")
@@ -105,14 +108,14 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
     try:
         return _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
                              dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine,
-                             arimaa_hidden_channels, arimaa_hidden_size)
+                             arimaa_hidden_channels, arimaa_hidden_size, attention)
     finally:
         _INIT = "uniform"
 
 
 def _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
                   dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine,
-                  arimaa_hidden_channels, arimaa_hidden_size) -> bytes:
+                  arimaa_hidden_channels, arimaa_hidden_size, attention=None) -> bytes:
     g = game_spec(game)
     size, n_scalar = g["size"], g["n_scalar"]
     n_bool = g["n_bool"] if n_bool is None else n_bool
@@ -126,6 +129,42 @@ def _random_model(game, depth, channels, head, seed, query_channels, n_bool, sca
         "scalar_hidden_channels": scalar_hidden_channels, "scalar_hidden_size": scalar_hidden_size,
         "policy_kind": head, "policy_len": g["policy_len"], "bn_eps": 1e-5,
     }
+    if attention is not None:
+        _attention_tower(rng, t, meta, game, hw, n_scalar + n_bool, depth, C, *attention)
+    else:
+        _res_tower(rng, t, game, n_scalar, n_bool, depth, C, block_gain, final_affine)
+    _heads(rng, t, meta, g, head, hw, C, query_channels, scalar_hidden_channels, scalar_hidden_size, dense_hidden_channels,
+           dense_hidden_size, arimaa_hidden_channels, arimaa_hidden_size)
+    return write_model(meta, t)
+
+
+def _xavier_normal(rng, rows, cols, gain):
+    return rng.normal(0.0, gain * np.sqrt(2.0 / (rows + cols)), size=(rows, cols)).astype(np.float32)
+
+
+def _attention_tower(rng, t, meta, game, hw, c_in, depth, C, heads, d_k, d_v, d_ff):
+    meta.update({"tower_kind": "attention", "att_heads": heads, "att_d_k": d_k, "att_d_v": d_v, "att_d_ff": d_ff,
+                 "att_alpha": float((2 * depth) ** 0.25), "ln_eps": 1e-5})
+    del meta["tower_final_affine"]
+    beta = (8 * depth) ** -0.25
+    t["common.expand.weight"] = _uniform(rng, (C, c_in), c_in)
+    if game == "chess":  # raw counters (chess.rs:153-154), as for the ResTower's stem below
+        t["common.expand.weight"][:, 6] *= 0.5
+        t["common.expand.weight"][:, 7] *= 0.01
+    t["common.embedding"] = rng.normal(0.0, 1.0, size=(hw, C)).astype(np.float32)
+    for i in range(depth):
+        p = f"common.encoders.{i}."
+        # (the reference initialises the q / k / v row blocks of project_qkv.weight separately, attention.py:87-95)
+        dkt = heads * d_k
+        w = np.concatenate([_xavier_normal(rng, dkt, C, 1.0), _xavier_normal(rng, dkt, C, 1.0),
+                            _xavier_normal(rng, heads * (d_k + d_v) - dkt, C, beta)])
+        t[p + "project_qkv.weight"] = w
+        t[p + "project_out.weight"] = _xavier_normal(rng, C, heads * d_v, beta)
+        t[p + "ff.0.weight"] = _xavier_normal(rng, d_ff, C, beta)
+        t[p + "ff.2.weight"] = _xavier_normal(rng, C, d_ff, beta)
+
+
+def _res_tower(rng, t, game, n_scalar, n_bool, depth, C, block_gain, final_affine):
     _conv(rng, t, "common.tower.0", C, n_scalar + n_bool, 3)
     if game == "chess":
         # the mapper feeds raw counters (repetitions 0..2, 50-move counter 0..99; chess.rs:153-154); a trained stem
@@ -148,6 +187,10 @@ def _random_model(game, depth, channels, head, seed, query_channels, n_bool, sca
     _bn(rng, t, f"common.tower.{depth + 1}", C)
     if not final_affine:  # ResTower(..., final_affine=False) (post_act.py:207; the MuZero towers of loop_main_mu.py:78): no weight / bias
         del t[f"common.tower.{depth + 1}.weight"], t[f"common.tower.{depth + 1}.bias"]
+
+
+def _heads(rng, t, meta, g, head, hw, C, query_channels, scalar_hidden_channels, scalar_hidden_size, dense_hidden_channels,
+           dense_hidden_size, arimaa_hidden_channels, arimaa_hidden_size):
     _conv(rng, t, "scalar_head.seq.0", scalar_hidden_channels, C, 1)
     _linear(rng, t, "scalar_head.seq.3", scalar_hidden_size, scalar_hidden_channels * hw)
     _linear(rng, t, "scalar_head.seq.5", 5, scalar_hidden_size)
@@ -196,7 +239,6 @@ def _random_model(game, depth, channels, head, seed, query_channels, n_bool, sca
         _linear(rng, t, "policy_head.scalar.5", 7, arimaa_hidden_size)
     else:
         raise ValueError(f"unsupported synthetic head '{head}'")
-    return write_model(meta, t)
 
 
 def random_boards(game: str, batch: int, seed: int = 0, n_bool: int = None) -> Tuple[np.ndarray, np.ndarray]:

@@ -1281,3 +1281,48 @@ def test_abi_helpers_on_the_device(dev):
     bits, scalars_in = synth.random_boards("chess", 3, seed=2)
     split.eval_packed(bits, scalars_in)
     assert split.read_activation("tower.out", 3).shape == (3, 256, 8, 8)
+
+
+# ---- AttentionTower networks (python/lib/model/attention.py; the tower python/main/supervised_main_alpha.py:72 trains) ----
+ATT_CASES = [
+    # game, depth, d_model, (heads, d_k, d_v, d_ff), head, f16 path
+    ("chess", 4, 256, (8, 16, 16, 256), "attention", "attention_tower_f16"),   # the reference's shape (there: depth 16)
+    ("chess", 2, 256, (8, 16, 16, 512), "attention", "attention_tower_f16"),
+    ("chess", 3, 128, (8, 16, 16, 128), "dense", "attention_tower_f16"),
+    ("chess", 2, 128, (8, 16, 16, 256), "attention", "attention_tower_f16"),
+    ("chess", 2, 192, (6, 32, 16, 320), "attention", "attention_tower_f32"),   # shapes only the exact-f32 kernel takes
+    ("ataxx-7", 3, 96, (4, 12, 20, 100), "ataxx_conv", "attention_tower_f32"),
+    ("go-9", 2, 64, (4, 16, 16, 128), "conv", "attention_tower_f32"),
+    ("chess-hist-2", 2, 256, (8, 16, 16, 256), "attention", "attention_tower_f16"),  # 47 input planes: two expand k-steps
+]
+
+
+@pytest.mark.parametrize("game,depth,d_model,att,head,f16_path", ATT_CASES,
+                         ids=[f"{c[0]}-{c[1]}x{c[2]}-h{c[3][0]}k{c[3][1]}v{c[3][2]}f{c[3][3]}" for c in ATT_CASES])
+def test_attention_tower_against_the_oracle(dev, game, depth, d_model, att, head, f16_path):
+    """Exact f32 at <= 1e-4 and f16 at the f16 tolerance, ragged batches (more boards than one wave of workgroups is not
+    needed: a workgroup is a board), through the packed-input entry point."""
+    kw = dict(dense_hidden_channels=2, dense_hidden_size=32) if head == "dense" else {}
+    blob = synth.random_model(game, depth, d_model, head, seed=17, attention=att, **kw)
+    net = O.OracleNet(blob)
+    model = capi.Model(blob=blob)
+    assert not model.supports_dtype(capi.KZ_DTYPE_F32_SPLIT16)
+    batch = 37
+    bits, scalars_in = synth.random_boards(game, batch, seed=23)
+    x = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+    s_or, p_or = net.forward(x, threads=8)
+    e32 = capi.Engine(model, dev, 64, capi.KZ_DTYPE_F32)
+    assert e32.tower_path == "attention_tower_f32"
+    s, p = e32.eval_packed(bits, scalars_in)
+    assert_f32(s, s_or, "scalars f32")
+    assert_f32(p, p_or, "policy f32")
+    s1, p1 = e32.eval_packed(bits[:5], scalars_in[:5])
+    assert np.array_equal(s1, s[:5]) and np.array_equal(p1, p[:5])
+    e16 = capi.Engine(model, dev, 64, capi.KZ_DTYPE_F16)
+    assert e16.tower_path == f16_path
+    s, p = e16.eval_packed(bits, scalars_in)
+    assert_f16(s, s_or, "scalars f16")
+    assert_f16(p, p_or, "policy f16")
+    assert np.abs(softmax(p) - softmax(p_or)).max() < 5e-3
+    s1, p1 = e16.eval_packed(bits[30:], scalars_in[30:])
+    assert np.array_equal(s1, s[30:]) and np.array_equal(p1, p[30:])
