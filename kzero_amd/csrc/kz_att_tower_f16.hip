@@ -27,7 +27,12 @@ typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef h16 h16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int A16_THREADS = 512, A16_WAVES = 8, A16_TOKENS = 64, A16_HEADS = 8, A16_LDA = A16_HEADS * 16 + 8;
+// LDS rows of f16 are padded by 16 values: a row stride of 32 bytes modulo 64 makes the 16-byte fragment reads of a wave
+// (lane = 16 kq + fr reads row fr at byte 16 kq: ds_read_b128 serves lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... together)
+// hit 16 distinct 16-byte slots; with 8 (stride 16 modulo 32) rows fr = 12 and fr = 11 of neighbouring lane groups collide
+// (measured: SQ_LDS_BANK_CONFLICT 44 % of the LDS-active cycles)
+constexpr int A16_PAD = 16;
+constexpr int A16_THREADS = 512, A16_WAVES = 8, A16_TOKENS = 64, A16_HEADS = 8, A16_LDA = A16_HEADS * 16 + A16_PAD;
 constexpr int A16_MAX_CIN = 224;
 
 struct AttTower16Dev {
@@ -37,16 +42,21 @@ struct AttTower16Dev {
     const float *embedding; // [64][D] f32
     const uint4 *w_layers;  // per layer: project_qkv | project_out | ff.0 | ff.2 fragments
     h16 *y;                 // [batch * 64][D] f16
+    // fused board encode (F0, rust/kz-core/src/mapping/mod.rs:40-63): packed boards straight into the launch (bits == nullptr: x0)
+    const uint8_t *bits;
+    size_t bits_stride;
+    const float *scalars_in;
+    int n_scalar, n_bool;
     int batch, depth;
     float alpha, eps;
 };
 
 template <int D, int DFF>
 struct A16Shape {
-    static constexpr int LDX = D + 8, LDH = DFF + 8;
-    // the second region holds, one after the other: the encoded planes (<= 224 + 8 columns), all heads' attention output
-    // (128 + 8), the feed-forward hidden layer (DFF + 8)
-    static constexpr int LDR = LDH > A16_MAX_CIN + 8 ? LDH : A16_MAX_CIN + 8;
+    static constexpr int LDX = D + A16_PAD, LDH = DFF + A16_PAD;
+    // the second region holds, one after the other: the encoded planes (<= 224 columns + padding), all heads' attention output
+    // (128), the feed-forward hidden layer (DFF)
+    static constexpr int LDR = LDH > A16_MAX_CIN + A16_PAD ? LDH : A16_MAX_CIN + A16_PAD;
     static constexpr int X_ELEMS = A16_TOKENS * LDX, R_ELEMS = A16_TOKENS * LDR;
     static constexpr int RED_FLOATS = 2 * A16_TOKENS * A16_WAVES;
     static constexpr size_t LDS_BYTES = (size_t)(X_ELEMS + R_ELEMS) * 2 + RED_FLOATS * 4;
@@ -57,17 +67,28 @@ struct A16Shape {
 
 __device__ __forceinline__ h16x8 as_h8(const uint4 &v) { return *reinterpret_cast<const h16x8 *>(&v); }
 
+// The first k-steps' weight fragments of a GEMM, loaded ahead of it (before the barrier and the LayerNorm / attention / store
+// that precede it, whose time then hides the loads' latency).
+template <int NTW, int KS>
+struct Ring {
+    static constexpr int PF = KS < 4 ? KS : 4;
+    uint4 r[PF][NTW];
+};
+template <int NTW, int KS>
+__device__ __forceinline__ void ring_preload(Ring<NTW, KS> &g, const uint4 *__restrict__ wf) {
+#pragma unroll
+    for (int p = 0; p < Ring<NTW, KS>::PF; p++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) g.r[p][t] = wf[(size_t)(t * KS + p) * 64];
+}
+
 // acc[t][tt] (+)= W tile t (16 features) x tokens tile tt over KS k-steps of 32.  wf: this lane's slot of the wave's first
-// tile (tile stride KS * 64 fragments, k-step stride 64); act: LDS rows of LDB f16.  VT: the last tile is computed with the
-// operands exchanged (tokens x features).
+// tile (tile stride KS * 64 fragments, k-step stride 64), its first k-steps already in `g`; act: LDS rows of LDB f16.  VT: the
+// last tile is computed with the operands exchanged (tokens x features).
 template <int NTW, int KS, int LDB, bool VT>
-__device__ __forceinline__ void gemm16(const uint4 *__restrict__ wf, const h16 *act, int fr, int kq, f32x4 (&acc)[NTW][4]) {
-    constexpr int PF = KS < 4 ? KS : 4;
-    uint4 ring[PF][NTW];
-#pragma unroll
-    for (int p = 0; p < PF; p++)
-#pragma unroll
-        for (int t = 0; t < NTW; t++) ring[p][t] = wf[(size_t)(t * KS + p) * 64];
+__device__ __forceinline__ void gemm16(Ring<NTW, KS> &g, const uint4 *__restrict__ wf, const h16 *act, int fr, int kq,
+                                       f32x4 (&acc)[NTW][4]) {
+    constexpr int PF = Ring<NTW, KS>::PF;
     const h16 *brow = act + fr * LDB + 8 * kq;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
@@ -76,7 +97,7 @@ __device__ __forceinline__ void gemm16(const uint4 *__restrict__ wf, const h16 *
         for (int tt = 0; tt < 4; tt++) b[tt] = *reinterpret_cast<const h16x8 *>(brow + tt * 16 * LDB + ks * 32);
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
-            const h16x8 a = as_h8(ring[ks % PF][t]);
+            const h16x8 a = as_h8(g.r[ks % PF][t]);
 #pragma unroll
             for (int tt = 0; tt < 4; tt++) {
                 if (VT && t == NTW - 1) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[tt], a, acc[t][tt], 0, 0, 0);
@@ -85,7 +106,7 @@ __device__ __forceinline__ void gemm16(const uint4 *__restrict__ wf, const h16 *
         }
         if (ks + PF < KS) {
 #pragma unroll
-            for (int t = 0; t < NTW; t++) ring[ks % PF][t] = wf[(size_t)(t * KS + ks + PF) * 64];
+            for (int t = 0; t < NTW; t++) g.r[ks % PF][t] = wf[(size_t)(t * KS + ks + PF) * 64];
         }
     }
 }
@@ -120,30 +141,30 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // LayerNorm(D) without parameters over the features of every token (attention.py:80-81), X in registers: this wave's NTD
-// feature tiles of all 64 tokens.  One pass (sum and sum of squares in f32), one exchange between the waves; then the f16
-// copy into X16.  Called by all waves; ends with the X16 rows written but NOT synchronised.
-template <int D, int NTD, int LDX>
-__device__ __forceinline__ void layernorm_regs(f32x4 (&X)[NTD][4], float *red, h16 *X16, int wave, int fr, int kq, float eps) {
-    float s[4], q[4];
+// feature tiles of all 64 tokens.  One pass (sum and sum of squares in f32), one exchange between the waves: ln_partial writes
+// this wave's sums, the caller synchronises, ln_finish normalises X and writes its f16 copy into X16 (NOT synchronised).
+template <int NTD>
+__device__ __forceinline__ void ln_partial(const f32x4 (&X)[NTD][4], float *red, int wave, int fr, int kq) {
 #pragma unroll
     for (int tt = 0; tt < 4; tt++) {
-        s[tt] = 0.0f;
-        q[tt] = 0.0f;
+        float s = 0.0f, q = 0.0f;
 #pragma unroll
         for (int t = 0; t < NTD; t++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                s[tt] += X[t][tt][j];
-                q[tt] = fmaf(X[t][tt][j], X[t][tt][j], q[tt]);
+                s += X[t][tt][j];
+                q = fmaf(X[t][tt][j], X[t][tt][j], q);
             }
-        s[tt] = group_sum(s[tt]);
-        q[tt] = group_sum(q[tt]);
+        s = group_sum(s);
+        q = group_sum(q);
         if (kq == 0) {
-            red[(16 * tt + fr) * A16_WAVES + wave] = s[tt];
-            red[A16_TOKENS * A16_WAVES + (16 * tt + fr) * A16_WAVES + wave] = q[tt];
+            red[(16 * tt + fr) * A16_WAVES + wave] = s;
+            red[A16_TOKENS * A16_WAVES + (16 * tt + fr) * A16_WAVES + wave] = q;
         }
     }
-    __syncthreads();
+}
+template <int D, int NTD, int LDX>
+__device__ __forceinline__ void ln_finish(f32x4 (&X)[NTD][4], const float *red, h16 *X16, int wave, int fr, int kq, float eps) {
 #pragma unroll
     for (int tt = 0; tt < 4; tt++) {
         const f32x4 *ps = reinterpret_cast<const f32x4 *>(red + (16 * tt + fr) * A16_WAVES);
@@ -175,12 +196,35 @@ __global__ __launch_bounds__(A16_THREADS) void kz_att_tower_f16(AttTower16Dev a)
     h16 *R = X16 + S::X_ELEMS;  // IN16 / ATT16 / H16
     float *red = reinterpret_cast<float *>(R + S::R_ELEMS);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, kq = lane >> 4;
-    const int ks_in = a.cin_p / 32, ldi = a.cin_p + 8;
+    const int ks_in = a.cin_p / 32, ldi = a.cin_p + A16_PAD;
 
     for (int board = blockIdx.x; board < a.batch; board += gridDim.x) {
         // ---- the board's encoded planes -> LDS ----
         __syncthreads();
-        {
+        if (a.bits) {
+            // scalar planes first, each broadcast over the board, then the bool planes: bool i of a board = bit i % 8 of byte
+            // i / 8 (bit_buffer.rs:73-75), i = plane * 64 + square
+            const int per_row = a.cin_p / 8;
+            const uint8_t *bb = a.bits + (size_t)board * a.bits_stride;
+            const float *sc = a.scalars_in + (size_t)board * a.n_scalar;
+            for (int i = tid; i < A16_TOKENS * per_row; i += A16_THREADS) {
+                const int c = i / A16_TOKENS, r = i - c * A16_TOKENS;
+                h16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int ch = c * 8 + j;
+                    float f = 0.0f;
+                    if (ch < a.n_scalar) {
+                        f = sc[ch];
+                    } else if (ch < a.n_scalar + a.n_bool) {
+                        const unsigned bit = (unsigned)(ch - a.n_scalar) * A16_TOKENS + r;
+                        f = (float)((bb[bit >> 3] >> (bit & 7)) & 1);
+                    }
+                    v[j] = (h16)f;
+                }
+                *reinterpret_cast<h16x8 *>(R + r * ldi + c * 8) = v;
+            }
+        } else {
             const int per_row = a.cin_p / 8;
             const uint4 *src = reinterpret_cast<const uint4 *>(a.x0 + (size_t)board * A16_TOKENS * a.cin_p);
             for (int i = tid; i < A16_TOKENS * per_row; i += A16_THREADS) {
@@ -206,13 +250,20 @@ __global__ __launch_bounds__(A16_THREADS) void kz_att_tower_f16(AttTower16Dev a)
                 for (int j = 0; j < 4; j++) o[j] = (h16)X[t][tt][j];
                 *reinterpret_cast<h16x4 *>(X16 + (16 * tt + fr) * S::LDX + (wave * S::NTD + t) * 16 + 4 * kq) = o;
             }
-        __syncthreads();
 
+        // a GEMM's first weight fragments are requested one phase ahead: q | k | v's behind the previous layer's last GEMM
+        // (here: behind the expand layer), project_out's ahead of the attention, ff.0's and ff.2's ahead of the LayerNorms
+        Ring<3, S::KSD> g_qkv;
         const uint4 *wl = a.w_layers;
+        ring_preload(g_qkv, wl + (size_t)wave * 3 * S::KSD * 64 + lane);
+        __syncthreads();
         for (int l = 0; l < a.depth; l++) {
-            const uint4 *wqkv = wl, *wout = wqkv + (size_t)64 * 24 * S::KSD, *wf0 = wout + (size_t)64 * (D / 16) * S::KSA,
-                        *wf1 = wf0 + (size_t)64 * (DFF / 16) * S::KSD;
+            const uint4 *wqkv = wl + (size_t)wave * 3 * S::KSD * 64 + lane;
+            const uint4 *wout = wl + (size_t)64 * 24 * S::KSD + (size_t)wave * S::NTD * S::KSA * 64 + lane;
+            const uint4 *wf0 = wl + (size_t)64 * (24 * S::KSD + (D / 16) * S::KSA) + (size_t)wave * S::NTF * S::KSD * 64 + lane;
+            const uint4 *wf1 = wl + (size_t)64 * (24 * S::KSD + (D / 16) * S::KSA + (DFF / 16) * S::KSD) + (size_t)wave * S::NTD * S::KSF * 64 + lane;
             wl += S::LAYER_FRAGS;
+            Ring<S::NTD, S::KSA> g_out;
             // ---- q, k, v of head `wave` and its attention, in registers ----
             {
                 f32x4 qkv[3][4];
@@ -220,7 +271,8 @@ __global__ __launch_bounds__(A16_THREADS) void kz_att_tower_f16(AttTower16Dev a)
                 for (int t = 0; t < 3; t++)
 #pragma unroll
                     for (int tt = 0; tt < 4; tt++) qkv[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm16<3, S::KSD, S::LDX, true>(wqkv + (size_t)wave * 3 * S::KSD * 64 + lane, X16, fr, kq, qkv);
+                gemm16<3, S::KSD, S::LDX, true>(g_qkv, wqkv, X16, fr, kq, qkv);
+                ring_preload(g_out, wout);
                 h16x4 qf[4], kf[4], vf[4];
 #pragma unroll
                 for (int tt = 0; tt < 4; tt++)
@@ -271,25 +323,36 @@ __global__ __launch_bounds__(A16_THREADS) void kz_att_tower_f16(AttTower16Dev a)
             for (int t = 0; t < S::NTD; t++)
 #pragma unroll
                 for (int tt = 0; tt < 4; tt++) X[t][tt] *= a.alpha;
-            gemm16<S::NTD, S::KSA, A16_LDA, false>(wout + (size_t)wave * S::NTD * S::KSA * 64 + lane, R, fr, kq, X);
-            layernorm_regs<D, S::NTD, S::LDX>(X, red, X16, wave, fr, kq, a.eps);
+            gemm16<S::NTD, S::KSA, A16_LDA, false>(g_out, wout, R, fr, kq, X);
+            // (the hidden layer goes FG feature tiles per wave at a time: at d_ff 512 four tiles' accumulators and fragments
+            //  would not fit the registers beside X)
+            constexpr int FG = S::NTF > 2 ? 2 : S::NTF;
+            Ring<FG, S::KSD> g_f0;
+            ring_preload(g_f0, wf0);
+            ln_partial<S::NTD>(X, red, wave, fr, kq);
+            __syncthreads();
+            ln_finish<D, S::NTD, S::LDX>(X, red, X16, wave, fr, kq, a.eps);
             __syncthreads();
             // ---- ff_result = norm_ff(att_result * alpha + ff(att_result)) (:128-129) ----
-            {
-                f32x4 hid[S::NTF][4];
+            Ring<S::NTD, S::KSF> g_f1;
 #pragma unroll
-                for (int t = 0; t < S::NTF; t++)
+            for (int fg = 0; fg < S::NTF; fg += FG) {
+                f32x4 hid[FG][4];
+#pragma unroll
+                for (int t = 0; t < FG; t++)
 #pragma unroll
                     for (int tt = 0; tt < 4; tt++) hid[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm16<S::NTF, S::KSD, S::LDX, false>(wf0 + (size_t)wave * S::NTF * S::KSD * 64 + lane, X16, fr, kq, hid);
+                gemm16<FG, S::KSD, S::LDX, false>(g_f0, wf0 + (size_t)fg * S::KSD * 64, X16, fr, kq, hid);
+                if (fg + FG < S::NTF) ring_preload(g_f0, wf0 + (size_t)(fg + FG) * S::KSD * 64);
+                else ring_preload(g_f1, wf1);
 #pragma unroll
-                for (int t = 0; t < S::NTF; t++)
+                for (int t = 0; t < FG; t++)
 #pragma unroll
                     for (int tt = 0; tt < 4; tt++) {
                         h16x4 o;
 #pragma unroll
                         for (int j = 0; j < 4; j++) o[j] = (h16)fmaxf(hid[t][tt][j], 0.0f);
-                        *reinterpret_cast<h16x4 *>(R + (16 * tt + fr) * S::LDH + (wave * S::NTF + t) * 16 + 4 * kq) = o;
+                        *reinterpret_cast<h16x4 *>(R + (16 * tt + fr) * S::LDH + (wave * S::NTF + fg + t) * 16 + 4 * kq) = o;
                     }
             }
             __syncthreads();
@@ -297,8 +360,11 @@ __global__ __launch_bounds__(A16_THREADS) void kz_att_tower_f16(AttTower16Dev a)
             for (int t = 0; t < S::NTD; t++)
 #pragma unroll
                 for (int tt = 0; tt < 4; tt++) X[t][tt] *= a.alpha;
-            gemm16<S::NTD, S::KSF, S::LDH, false>(wf1 + (size_t)wave * S::NTD * S::KSF * 64 + lane, R, fr, kq, X);
-            layernorm_regs<D, S::NTD, S::LDX>(X, red, X16, wave, fr, kq, a.eps);
+            gemm16<S::NTD, S::KSF, S::LDH, false>(g_f1, wf1, R, fr, kq, X);
+            if (l + 1 < a.depth) ring_preload(g_qkv, wl + (size_t)wave * 3 * S::KSD * 64 + lane);
+            ln_partial<S::NTD>(X, red, wave, fr, kq);
+            __syncthreads();
+            ln_finish<D, S::NTD, S::LDX>(X, red, X16, wave, fr, kq, a.eps);
             __syncthreads();
         }
         // ---- "(h w) b c -> b c h w" (:43-44) as the NHWC rows the head kernels read ----
@@ -376,6 +442,7 @@ void launch_att_tower16(const AttTower16Args &t, hipStream_t stream) {
     d.x0 = static_cast<const h16 *>(t.x0); d.cin_p = t.cin_p;
     d.w_expand = static_cast<const uint4 *>(t.w_expand); d.embedding = t.embedding;
     d.w_layers = static_cast<const uint4 *>(t.w_layers);
+    d.bits = t.bits; d.bits_stride = t.bits_stride; d.scalars_in = t.scalars_in; d.n_scalar = t.n_scalar; d.n_bool = t.n_bool;
     d.y = static_cast<h16 *>(t.y); d.batch = t.batch; d.depth = t.depth; d.alpha = t.alpha; d.eps = t.eps;
     if (t.d_model == 128 && t.d_ff == 128) launch1<128, 128>(d, stream);
     else if (t.d_model == 128 && t.d_ff == 256) launch1<128, 256>(d, stream);

@@ -396,6 +396,13 @@ struct kz_engine {
             t.x0 = x_in; t.cin_p = cin_p; t.w_expand = wts->att16_expand; t.embedding = wts->att_embedding;
             t.w_layers = wts->att16_layers; t.y = act[0]; t.batch = batch; t.depth = m.depth; t.d_model = m.channels;
             t.d_ff = m.att_dff; t.alpha = m.att_alpha; t.eps = m.ln_eps;
+            if (packed) {  // fused board encode
+                t.bits = (const uint8_t *)packed->bits;
+                t.bits_stride = packed->stride;
+                t.scalars_in = (const float *)packed->scalars;
+                t.n_scalar = m.n_scalar;
+                t.n_bool = m.n_bool;
+            }
             prof.begin("kz_att_tower_f16", stream);
             kz::launch_att_tower16(t, stream);
             prof.end(stream);
@@ -668,7 +675,7 @@ struct kz_engine {
     int forward_packed(const void *d_bits, size_t stride, const void *d_sin, int batch, void *d_sout, void *d_pol,
                        const kz::DecodeArgs *dec = nullptr) {
         const Model &m = *model;
-        if (resident || resident32 || pairs16) {  // encode is fused into the tower launch
+        if (resident || resident32 || pairs16 || att_f16) {  // encode is fused into the tower launch
             const PackedIn in{d_bits, stride, d_sin};
             if (run_tower(batch, (float *)d_sout, (float *)d_pol, &in, dec)) return 1;
             return run_heads(batch, (float *)d_sout, (float *)d_pol);

@@ -197,6 +197,11 @@ struct AttTower16Args {
     const float *embedding;
     const void *w_layers;  // att_tower16_pack_layer, layer after layer
     void *y;               // [batch*64][d_model] f16
+    // fused board encode (F0): packed boards straight into the launch (bits == nullptr: read x0)
+    const uint8_t *bits = nullptr;
+    size_t bits_stride = 0;
+    const float *scalars_in = nullptr;
+    int n_scalar = 0, n_bool = 0;
     int batch, depth, d_model, d_ff;
     float alpha, eps;
 };

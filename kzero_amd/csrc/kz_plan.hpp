@@ -83,7 +83,7 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
         p.att_f16 = dtype == KZ_DTYPE_F16 && !force &&
                     kz::att_tower16_supported(m.h, m.w, m.c_in, m.channels, m.att_heads, m.att_dk, m.att_dv, m.att_dff, m.depth);
         p.path = p.att_f16 ? "attention_tower_f16" : "attention_tower_f32";
-        p.launches = 2 + head_launches(m, dtype, false, cp);  // encode, the tower, the heads
+        p.launches = (p.att_f16 ? 1 : 2) + head_launches(m, dtype, false, cp);  // (encode,) the tower, the heads
         return true;
     }
     p.resident = kz::tower_resident_supported(dtype, m.h, m.w, m.channels, m.depth, m.c_in) && !force;

@@ -289,7 +289,7 @@ def main_attention():
     os.makedirs(OUT, exist_ok=True)
     gen_net("chess_att2x64", 21, 3, 0.05, layers=True, onnx=True,
             game_name="chess", depth=2, channels=64, head_kind="attention", query_channels=16, attention=(4, 16, 16, 96))
-    gen_net("ataxx7_att2x32", 22, 3, 0.3,
+    gen_net("ataxx7_att2x32", 22, 3, 0.3, onnx=True,
             game_name="ataxx-7", depth=2, channels=32, head_kind="ataxx_conv", attention=(2, 8, 12, 48))
     gen_net("chess_att3x256", 23, 2, 0.05,
             game_name="chess", depth=3, channels=256, head_kind="attention", query_channels=32, attention=(8, 16, 16, 256))

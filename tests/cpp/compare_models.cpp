@@ -90,6 +90,24 @@ int main(int argc, char **argv) {
         !same(o->pa_conv, k->pa_conv, "pa_conv", msg) || !same(o->pa_fc0, k->pa_fc0, "pa_fc0", msg) || !same(o->pa_fc1, k->pa_fc1, "pa_fc1", msg))
         return bad(msg);
     if (o->flat_to_att != k->flat_to_att) return bad("flat_to_att");
+    // AttentionTower (python/lib/model/attention.py): the descriptor and every matrix
+    if (o->tower_kind != k->tower_kind || o->att_heads != k->att_heads || o->att_dk != k->att_dk || o->att_dv != k->att_dv ||
+        o->att_dff != k->att_dff || o->att_layers.size() != k->att_layers.size() || std::fabs(o->att_alpha - k->att_alpha) > 1e-6f ||
+        std::fabs(o->ln_eps - k->ln_eps) > 1e-12f)
+        return bad("attention tower descriptor");
+    if (!close(o->att_expand, k->att_expand, "att_expand", msg) || !close(o->att_embedding, k->att_embedding, "att_embedding", msg)) return bad(msg);
+    for (size_t i = 0; i < o->att_layers.size(); i++) {
+        const std::string p = "encoder." + std::to_string(i);
+        if (!close(o->att_layers[i].qkv, k->att_layers[i].qkv, (p + ".qkv").c_str(), msg) ||
+            !close(o->att_layers[i].out, k->att_layers[i].out, (p + ".out").c_str(), msg) ||
+            !close(o->att_layers[i].ff0, k->att_layers[i].ff0, (p + ".ff0").c_str(), msg) ||
+            !close(o->att_layers[i].ff1, k->att_layers[i].ff1, (p + ".ff1").c_str(), msg))
+            return bad(msg);
+    }
+    // (an AttentionTower has no BatchNorm to fold: the ONNX file holds the container's parameters one for one)
+    if (o->tower_kind == kz::TOWER_ATTENTION &&
+        (o->param_count != k->param_count || std::fabs(o->flops_per_eval - k->flops_per_eval) > 1e-6 * k->flops_per_eval))
+        return bad("param_count / flops_per_eval");
     std::printf("models equal\n");
     return 0;
 }

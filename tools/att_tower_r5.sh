@@ -6,7 +6,7 @@ O=gpurun_out/att
 mkdir -p $O
 timeout 900 python3 -m pytest tests/test_gpu_parity.py -q -m gpu -k "att2x64 or att2x32 or att3x256 or attention_tower" > $O/tests.log 2>&1
 tail -3 $O/tests.log
-for dt in f16 f32; do
+for dt in ${ATT_DTYPES:-f16 f32}; do
   python3 bench.py --workload chess-att16x256 --dtype $dt --no-others --no-cpu-baseline ${ATT_BENCH_ARGS:-} > $O/bench_$dt.json 2> $O/bench_$dt.err
   python3 tools/show_bench.py $O/bench_$dt.json | cut -c1-400
 done
