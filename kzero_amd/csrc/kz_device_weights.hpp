@@ -216,7 +216,7 @@ struct DeviceWeights {
             std::vector<uint16_t> all(per * m.att_layers.size());
             for (size_t l = 0; l < m.att_layers.size(); l++)
                 kz::att_tower16_pack_layer(m.att_layers[l].qkv.data(), m.att_layers[l].out.data(), m.att_layers[l].ff0.data(),
-                                           m.att_layers[l].ff1.data(), C, m.att_dff, all.data() + per * l);
+                                           m.att_layers[l].ff1.data(), C, m.att_dff, m.att_alpha, all.data() + per * l);
             if (upload(ex.data(), ex.size() * 2, &att16_expand) || upload(all.data(), all.size() * 2, &att16_layers) ||
                 upload_f32(m.att_embedding, &att_embedding))
                 return 1;

@@ -995,7 +995,8 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     if ((batch < 0 || batch > e->max_batch ? fail("kz_engine_launch_geometry: batch out of range") : 0)) return 1;
     const Model &m = *e->model;
     int per = 0, wgs = 0;
-    if (e->att_tower) per = 1;  // a workgroup is a board
+    if (e->att_f16) per = kz::att_tower16_boards_per_workgroup(m.channels, m.att_dff, batch);
+    else if (e->att_tower) per = 1;  // a workgroup is a board
     else if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
     else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16,
                                                          e->wide ? batch : 0);  // (per launch: the widest level this batch fills the chip with)

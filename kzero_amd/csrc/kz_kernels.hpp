@@ -206,10 +206,12 @@ struct AttTower16Args {
     float alpha, eps;
 };
 bool att_tower16_supported(int h, int w, int c_in, int d_model, int heads, int d_k, int d_v, int d_ff, int depth);
+int att_tower16_boards_per_workgroup(int d_model, int d_ff, int batch);  // of a launch of `batch` boards
 size_t att_tower16_expand_elems(int d_model, int cin_p);
 size_t att_tower16_layer_elems(int d_model, int d_ff);
 void att_tower16_pack_expand(const float *expand, int d_model, int c_in, int cin_p, uint16_t *dst);
-void att_tower16_pack_layer(const float *qkv, const float *out, const float *ff0, const float *ff1, int d_model, int d_ff, uint16_t *dst);
+void att_tower16_pack_layer(const float *qkv, const float *out, const float *ff0, const float *ff1, int d_model, int d_ff, float alpha,
+                            uint16_t *dst);
 void launch_att_tower16(const AttTower16Args &t, hipStream_t stream);
 
 // ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----
