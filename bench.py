@@ -97,7 +97,7 @@ KERNEL_OF_PATH = {
     "tower_resident_split16": "kz_tower_resident_split", "tower_resident_split16+heads": "kz_tower_resident_split",
     "tower_resident_f16g": "kz_tower_resident_f16g", "tower_resident_f16g+heads": "kz_tower_resident_f16g",
     "board_conv_f16": "kz_board_conv_f16",
-    "attention_tower_f16": "kz_att_tower_f16", "attention_tower_f32": "kz_att_tower_f32",
+    "attention_tower_f16": "kz_att_tower_f16", "attention_tower_f32": "kz_att_tower_f32", "attention_tower_f32_valu": "kz_att_tower_f32_valu",
     "board_conv_split16": "kz_board_conv_split16",
     "conv_igemm_f16": "kz_conv_igemm_f16", "conv_igemm_f32": "kz_conv_igemm_f32",
 }
@@ -106,7 +106,7 @@ KERNEL_SOURCE = {
     "kz_tower_resident_f16": "kz_tower.hip", "kz_tower_resident_f32": "kz_tower_f32.hip",
     "kz_tower_resident_split": "kz_tower_split.hip", "kz_tower_resident_f16g": "kz_tower_f16g.hip",
     "kz_board_conv_f16": "kz_board_conv.hip", "kz_board_conv_split16": "kz_board_conv.hip", "kz_conv_igemm_f16": "kz_kernels.hip", "kz_conv_igemm_f32": "kz_kernels.hip",
-    "kz_att_tower_f16": "kz_att_tower_f16.hip", "kz_att_tower_f32": "kz_att_tower.hip",
+    "kz_att_tower_f16": "kz_att_tower_mfma.hip", "kz_att_tower_f32": "kz_att_tower_mfma.hip", "kz_att_tower_f32_valu": "kz_att_tower.hip",
 }
 # device code a kernel source pulls in (hashed with it: a traffic record goes stale when either changes).  The (hi, lo) tower
 # and its plain-f16 sibling are one template (kz_tower_pairs.hpp) instantiated by a translation unit each: an edit to one

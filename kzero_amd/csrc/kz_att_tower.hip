@@ -7,7 +7,7 @@
 // attention.py:97-133), head after head: qkv of ONE head (a [n][2 d_k + d_v] GEMM), logits q k^T without scale factor (:117),
 // softmax over the keys (:119) and weights v (:122) a query row per wave; then project_out, the DeepNorm residual
 // LayerNorm(x * alpha + f(x)) (:126), the feed-forward pair of Linear layers (:128) and the second LayerNorm (:129).
-// All arithmetic is f32 FMA (this is the <= 1e-4 path, and the path of every shape the f16 kernel kz_att_tower_f16.hip does not
+// All arithmetic is f32 FMA (this is the <= 1e-4 path, and the path of every shape the matrix-core kernel kz_att_tower_mfma.hip does not
 // take); the rows it reads and writes are f32 or f16 as the engine's other kernels expect them.
 #include "kz_kernels.hpp"
 

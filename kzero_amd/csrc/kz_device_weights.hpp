@@ -210,14 +210,16 @@ struct DeviceWeights {
 
         if (m.tower_kind == kz::TOWER_ATTENTION && att_f16) {
             const int cin_p = round_up(m.c_in, 32);
-            std::vector<uint16_t> ex(kz::att_tower16_expand_elems(C, cin_p));
-            kz::att_tower16_pack_expand(m.att_expand.data(), C, m.c_in, cin_p, ex.data());
-            const size_t per = kz::att_tower16_layer_elems(C, m.att_dff);
-            std::vector<uint16_t> all(per * m.att_layers.size());
+            const bool f32 = dtype == KZ_DTYPE_F32;
+            const size_t esz = f32 ? 4 : 2;
+            std::vector<char> ex(kz::att_tower16_expand_elems(C, cin_p) * esz);
+            kz::att_tower16_pack_expand(m.att_expand.data(), C, m.c_in, cin_p, f32, ex.data());
+            const size_t per = kz::att_tower16_layer_elems(C, m.att_dff) * esz;
+            std::vector<char> all(per * m.att_layers.size());
             for (size_t l = 0; l < m.att_layers.size(); l++)
                 kz::att_tower16_pack_layer(m.att_layers[l].qkv.data(), m.att_layers[l].out.data(), m.att_layers[l].ff0.data(),
-                                           m.att_layers[l].ff1.data(), C, m.att_dff, m.att_alpha, all.data() + per * l);
-            if (upload(ex.data(), ex.size() * 2, &att16_expand) || upload(all.data(), all.size() * 2, &att16_layers) ||
+                                           m.att_layers[l].ff1.data(), C, m.att_dff, m.att_alpha, f32, all.data() + per * l);
+            if (upload(ex.data(), ex.size(), &att16_expand) || upload(all.data(), all.size(), &att16_layers) ||
                 upload_f32(m.att_embedding, &att_embedding))
                 return 1;
         } else if (m.tower_kind == kz::TOWER_ATTENTION) {

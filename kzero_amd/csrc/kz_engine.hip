@@ -391,8 +391,9 @@ struct kz_engine {
                   const kz::DecodeArgs *dec = nullptr) {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
-        if (att_f16) {  // AttentionTower on the f16 matrix cores
+        if (att_f16) {  // AttentionTower on the matrix cores, in the engine's arithmetic
             kz::AttTower16Args t{};
+            t.f32 = dtype == KZ_DTYPE_F32;
             t.x0 = x_in; t.cin_p = cin_p; t.w_expand = wts->att16_expand; t.embedding = wts->att_embedding;
             t.w_layers = wts->att16_layers; t.y = act[0]; t.batch = batch; t.depth = m.depth; t.d_model = m.channels;
             t.d_ff = m.att_dff; t.alpha = m.att_alpha; t.eps = m.ln_eps;
@@ -403,7 +404,7 @@ struct kz_engine {
                 t.n_scalar = m.n_scalar;
                 t.n_bool = m.n_bool;
             }
-            prof.begin("kz_att_tower_f16", stream);
+            prof.begin(t.f32 ? "kz_att_tower_f32" : "kz_att_tower_f16", stream);
             kz::launch_att_tower16(t, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
@@ -417,7 +418,7 @@ struct kz_engine {
             t.y = act[0]; t.ldy = cp; t.out_f16 = dtype == KZ_DTYPE_F16;
             t.batch = batch; t.h = m.h; t.w = m.w; t.depth = m.depth; t.d_model = m.channels; t.heads = m.att_heads;
             t.d_k = m.att_dk; t.d_v = m.att_dv; t.d_ff = m.att_dff; t.alpha = m.att_alpha; t.eps = m.ln_eps;
-            prof.begin("kz_att_tower_f32", stream);
+            prof.begin("kz_att_tower_f32_valu", stream);
             kz::launch_att_tower(t, stream);
             prof.end(stream);
             HIP_TRY(hipGetLastError());
@@ -995,7 +996,7 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     if ((batch < 0 || batch > e->max_batch ? fail("kz_engine_launch_geometry: batch out of range") : 0)) return 1;
     const Model &m = *e->model;
     int per = 0, wgs = 0;
-    if (e->att_f16) per = kz::att_tower16_boards_per_workgroup(m.channels, m.att_dff, batch);
+    if (e->att_f16) per = kz::att_tower16_boards_per_workgroup(m.channels, m.att_dff, batch, e->dtype == KZ_DTYPE_F32);
     else if (e->att_tower) per = 1;  // a workgroup is a board
     else if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
     else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16,

@@ -188,15 +188,16 @@ bool att_tower_supported(int h, int w, int c_in, int d_model, int heads, int d_k
 size_t att_tower_layer_elems(int d_model, int heads, int d_k, int d_v, int d_ff);
 void launch_att_tower(const AttTowerArgs &t, hipStream_t stream);
 
-// ---- the same tower on the f16 matrix cores (kz_att_tower_f16.hip): 8x8 boards, 8 heads of d_k = d_v = 16, the d_model / d_ff
-// pairs att_tower16_supported names; f16 rows in and out ----
+// ---- the same tower on the matrix cores (kz_att_tower_mfma.hip), in f16 or (f32 = true) exact f32: 8x8 boards, 8 heads of
+// d_k = d_v = 16, the d_model / d_ff pairs att_tower16_supported names; rows of the arithmetic's element type in and out ----
 struct AttTower16Args {
-    const void *x0;        // encoded input [batch*64][cin_p] f16
+    bool f32 = false;
+    const void *x0;        // encoded input [batch*64][cin_p]
     int cin_p;
     const void *w_expand;  // att_tower16_pack_expand
     const float *embedding;
     const void *w_layers;  // att_tower16_pack_layer, layer after layer
-    void *y;               // [batch*64][d_model] f16
+    void *y;               // [batch*64][d_model]
     // fused board encode (F0): packed boards straight into the launch (bits == nullptr: read x0)
     const uint8_t *bits = nullptr;
     size_t bits_stride = 0;
@@ -205,13 +206,13 @@ struct AttTower16Args {
     int batch, depth, d_model, d_ff;
     float alpha, eps;
 };
-bool att_tower16_supported(int h, int w, int c_in, int d_model, int heads, int d_k, int d_v, int d_ff, int depth);
-int att_tower16_boards_per_workgroup(int d_model, int d_ff, int batch);  // of a launch of `batch` boards
+bool att_tower16_supported(int h, int w, int c_in, int d_model, int heads, int d_k, int d_v, int d_ff, int depth, bool f32);
+int att_tower16_boards_per_workgroup(int d_model, int d_ff, int batch, bool f32);  // of a launch of `batch` boards
 size_t att_tower16_expand_elems(int d_model, int cin_p);
 size_t att_tower16_layer_elems(int d_model, int d_ff);
-void att_tower16_pack_expand(const float *expand, int d_model, int c_in, int cin_p, uint16_t *dst);
+void att_tower16_pack_expand(const float *expand, int d_model, int c_in, int cin_p, bool f32, void *dst);
 void att_tower16_pack_layer(const float *qkv, const float *out, const float *ff0, const float *ff1, int d_model, int d_ff, float alpha,
-                            uint16_t *dst);
+                            bool f32, void *dst);
 void launch_att_tower16(const AttTower16Args &t, hipStream_t stream);
 
 // ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----

@@ -18,13 +18,13 @@
 //                      else                                       -> refused (kz_model_supports_dtype says 0)
 // ------------------------------------------------------------------------------------------------
 //   AttentionTower (attention.py) instead of the ResTower:
-//     dtype f16, 8x8, 8 heads of d_k = d_v = 16, d_model 128 / 256  -> attention_tower_f16 (one launch for the tower)
-//     else (f32, or f16 on another shape)                           -> attention_tower_f32 (one launch, exact f32 arithmetic;
-//                                                                      f16 engines read and write f16 rows)
-//     f32split16                                                    -> refused
+//     8x8, 8 heads of d_k = d_v = 16, d_model 128 / 256: dtype f16 -> attention_tower_f16, f32 -> attention_tower_f32 (the same
+//                                                       launch on v_mfma_f32_16x16x4_f32; d_ff <= 256)
+//     any other shape (f32, or f16 rows around f32 arithmetic)   -> attention_tower_f32_valu (one launch, vector ALUs)
+//     f32split16                                                 -> refused
 struct PathPlan {
     bool att_tower = false;  // Model::tower_kind == TOWER_ATTENTION: kz_att_tower.hip
-    bool att_f16 = false;    // ... on the f16 matrix cores: kz_att_tower_f16.hip
+    bool att_f16 = false;    // ... on the matrix cores (f16 or exact f32): kz_att_tower_mfma.hip
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, bsplit = false, pairs16 = false;
     bool fused32 = false, fused_split = false, fused_pairs = false, board_conv = false, keep = false;
     bool wide = false;  // tower_resident_f16g with twice the boards per workgroup (kz::tower_split_wide_supported)
@@ -80,9 +80,10 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
             return false;
         }
         p.att_tower = true;
-        p.att_f16 = dtype == KZ_DTYPE_F16 && !force &&
-                    kz::att_tower16_supported(m.h, m.w, m.c_in, m.channels, m.att_heads, m.att_dk, m.att_dv, m.att_dff, m.depth);
-        p.path = p.att_f16 ? "attention_tower_f16" : "attention_tower_f32";
+        // (att_f16: the matrix-core launch, in the engine's arithmetic — f16, or exact f32)
+        p.att_f16 = !force && kz::att_tower16_supported(m.h, m.w, m.c_in, m.channels, m.att_heads, m.att_dk, m.att_dv, m.att_dff, m.depth,
+                                                        dtype == KZ_DTYPE_F32);
+        p.path = !p.att_f16 ? "attention_tower_f32_valu" : dtype == KZ_DTYPE_F32 ? "attention_tower_f32" : "attention_tower_f16";
         p.launches = (p.att_f16 ? 1 : 2) + head_launches(m, dtype, false, cp);  // (encode,) the tower, the heads
         return true;
     }

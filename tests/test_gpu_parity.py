@@ -1285,23 +1285,25 @@ def test_abi_helpers_on_the_device(dev):
 
 # ---- AttentionTower networks (python/lib/model/attention.py; the tower python/main/supervised_main_alpha.py:72 trains) ----
 ATT_CASES = [
-    # game, depth, d_model, (heads, d_k, d_v, d_ff), head, f16 path
-    ("chess", 4, 256, (8, 16, 16, 256), "attention", "attention_tower_f16"),   # the reference's shape (there: depth 16)
-    ("chess", 2, 256, (8, 16, 16, 512), "attention", "attention_tower_f16"),
-    ("chess", 3, 128, (8, 16, 16, 128), "dense", "attention_tower_f16"),
-    ("chess", 2, 128, (8, 16, 16, 256), "attention", "attention_tower_f16"),
-    ("chess", 2, 192, (6, 32, 16, 320), "attention", "attention_tower_f32"),   # shapes only the exact-f32 kernel takes
-    ("ataxx-7", 3, 96, (4, 12, 20, 100), "ataxx_conv", "attention_tower_f32"),
-    ("go-9", 2, 64, (4, 16, 16, 128), "conv", "attention_tower_f32"),
-    ("chess-hist-2", 2, 256, (8, 16, 16, 256), "attention", "attention_tower_f16"),  # 47 input planes: two expand k-steps
+    # game, depth, d_model, (heads, d_k, d_v, d_ff), head, f32 path, f16 path
+    ("chess", 4, 256, (8, 16, 16, 256), "attention", "attention_tower_f32", "attention_tower_f16"),   # the reference's shape (there: depth 16)
+    ("chess", 2, 256, (8, 16, 16, 512), "attention", "attention_tower_f32_valu", "attention_tower_f16"),  # (two f32 images of d_ff 512 exceed the LDS)
+    ("chess", 3, 128, (8, 16, 16, 128), "dense", "attention_tower_f32", "attention_tower_f16"),
+    ("chess", 2, 128, (8, 16, 16, 256), "attention", "attention_tower_f32", "attention_tower_f16"),
+    # shapes only the vector-ALU kernel takes (f16 engines: f16 rows around f32 arithmetic)
+    ("chess", 2, 192, (6, 32, 16, 320), "attention", "attention_tower_f32_valu", "attention_tower_f32_valu"),
+    ("ataxx-7", 3, 96, (4, 12, 20, 100), "ataxx_conv", "attention_tower_f32_valu", "attention_tower_f32_valu"),
+    ("go-9", 2, 64, (4, 16, 16, 128), "conv", "attention_tower_f32_valu", "attention_tower_f32_valu"),
+    ("chess-hist-2", 2, 256, (8, 16, 16, 256), "attention", "attention_tower_f32", "attention_tower_f16"),  # 47 input planes: more expand k-steps
 ]
 
 
-@pytest.mark.parametrize("game,depth,d_model,att,head,f16_path", ATT_CASES,
+@pytest.mark.parametrize("game,depth,d_model,att,head,f32_path,f16_path", ATT_CASES,
                          ids=[f"{c[0]}-{c[1]}x{c[2]}-h{c[3][0]}k{c[3][1]}v{c[3][2]}f{c[3][3]}" for c in ATT_CASES])
-def test_attention_tower_against_the_oracle(dev, game, depth, d_model, att, head, f16_path):
-    """Exact f32 at <= 1e-4 and f16 at the f16 tolerance, ragged batches (more boards than one wave of workgroups is not
-    needed: a workgroup is a board), through the packed-input entry point."""
+def test_attention_tower_against_the_oracle(dev, game, depth, d_model, att, head, f32_path, f16_path):
+    """Exact f32 at <= 1e-4 (on v_mfma_f32_16x16x4_f32 where the shape allows, else on the vector ALUs) and f16 at the f16
+    tolerance; ragged batches, and — batch 200 of an engine of 256 — the f16 launch's two boards per workgroup with an odd
+    board out; through the packed-input entry point."""
     kw = dict(dense_hidden_channels=2, dense_hidden_size=32) if head == "dense" else {}
     blob = synth.random_model(game, depth, d_model, head, seed=17, attention=att, **kw)
     net = O.OracleNet(blob)
@@ -1312,7 +1314,7 @@ def test_attention_tower_against_the_oracle(dev, game, depth, d_model, att, head
     x = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
     s_or, p_or = net.forward(x, threads=8)
     e32 = capi.Engine(model, dev, 64, capi.KZ_DTYPE_F32)
-    assert e32.tower_path == "attention_tower_f32"
+    assert e32.tower_path == f32_path
     s, p = e32.eval_packed(bits, scalars_in)
     assert_f32(s, s_or, "scalars f32")
     assert_f32(p, p_or, "policy f32")
@@ -1326,3 +1328,18 @@ def test_attention_tower_against_the_oracle(dev, game, depth, d_model, att, head
     assert np.abs(softmax(p) - softmax(p_or)).max() < 5e-3
     s1, p1 = e16.eval_packed(bits[30:], scalars_in[30:])
     assert np.array_equal(s1, s[30:]) and np.array_equal(p1, p[30:])
+    if f16_path == "attention_tower_f16" and att[3] <= 256:
+        # two boards per workgroup from batch 192 on: 201 boards = 100 pairs and one board alone
+        big = capi.Engine(model, dev, 256, capi.KZ_DTYPE_F16)
+        assert big.launch_geometry(201) == (101, 2) and big.launch_geometry(37) == (37, 1)
+        bits2, sc2 = synth.random_boards(game, 201, seed=29)
+        s2, p2 = big.eval_packed(bits2, sc2)
+        pick = [0, 1, 100, 199, 200]
+        so, po = net.forward(O.encode_input_full(bits2[pick], sc2[pick], net.n_scalar, net.n_bool, net.h, net.w), threads=8)
+        assert_f16(s2[pick], so, "scalars f16, two boards per workgroup")
+        assert_f16(p2[pick], po, "policy f16, two boards per workgroup")
+        s3, p3 = big.eval_packed(bits2[:37], sc2[:37])  # the same boards one per workgroup: the same arithmetic per board
+        if head == "dense":  # (the dense head's GEMM tiles its rows by the batch: another summation order)
+            assert np.abs(s3 - s2[:37]).max() <= F16_PATHS_ATOL and np.abs(p3 - p2[:37]).max() <= F16_PATHS_ATOL
+        else:
+            assert np.array_equal(s3, s2[:37]) and np.array_equal(p3, p2[:37])
