@@ -89,7 +89,9 @@ WEIGHT_VARIANTS = [
     ("trained-like scale (block_gain 3: the residual stream grows to ~170, logits to ~1.8e3)", dict(block_gain=3.0)),
 ]
 OTHERS = [("ataxx-8x128", "f32"), ("ataxx-8x128", "f32split16"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"),
-          ("go19-40x256", "f32split16"), ("go9-16x128", "f32split16"), ("go9-16x128", "f16")]
+          ("go19-40x256", "f32split16"), ("go9-16x128", "f32split16"), ("go9-16x128", "f16"),
+          # the reference's other tower (python/lib/model/attention.py; supervised_main_alpha.py:69-77): not a BASELINE config
+          ("chess-att16x256", "f16"), ("chess-att16x256", "f32")]
 
 KERNEL_OF_PATH = {
     "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",

@@ -1,4 +1,4 @@
-// kz_att_tower.hip — AttentionTower (python/lib/model/attention.py:8-136, the tower python/main/supervised_main_alpha.py:72
+// kz_att_tower.hip — the AttentionTower network (python/lib/model/attention.py:8-136, the tower python/main/supervised_main_alpha.py:72
 // trains in place of the ResTower) in exact f32: the whole tower of one board in ONE workgroup, ONE launch per batch.
 //
 // Every square of the board is a token of d_model features.  The token matrix X [n][d_model] stays in LDS from the expand

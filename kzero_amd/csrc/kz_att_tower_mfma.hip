@@ -1,4 +1,4 @@
-// kz_att_tower_mfma.hip — AttentionTower (python/lib/model/attention.py:8-136) on the matrix cores, in f16 (v_mfma_f32_16x16x32_f16)
+// kz_att_tower_mfma.hip — the AttentionTower network (python/lib/model/attention.py:8-136) on the matrix cores, in f16 (v_mfma_f32_16x16x32_f16)
 // and, same kernel, second instance, in exact f32 (v_mfma_f32_16x16x4_f32: the <= 1e-4 path): the whole tower of one or two
 // 8x8 boards in ONE workgroup of eight waves, ONE launch per batch.  Shapes: 64 squares, 8 heads of d_k = d_v = 16 (what
 // python/main/supervised_main_alpha.py:72 builds), d_model / d_ff of the instances at the end of this file; every other

@@ -172,7 +172,7 @@ void board_conv2_pack_weights(const float *oihw, int cout, int cin, uint16_t *ds
 void board_conv2_tables(int h, int w, std::vector<int> &rowmap, std::vector<unsigned short> &halo);
 void launch_board_conv2(const BoardConvArgs &a, hipStream_t stream);
 
-// ---- AttentionTower (python/lib/model/attention.py:8-136) in exact f32, one workgroup per board, one launch per batch
+// ---- the AttentionTower network (python/lib/model/attention.py:8-136) in exact f32, one workgroup per board, one launch per batch
 // (kz_att_tower.hip).  Reads the encoded planes, writes the tower output rows the head kernels read. ----
 struct AttTowerArgs {
     const void *x0;       // encoded input [batch*h*w][ldx0], f32 or f16 (channels beyond c_in are zero)

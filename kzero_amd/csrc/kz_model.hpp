@@ -21,7 +21,7 @@ struct Linear {  // nn.Linear, weights [out][in]
 
 enum TowerKind { TOWER_RES = 0, TOWER_ATTENTION = 1 };
 
-// One EncoderLayer of AttentionTower (python/lib/model/attention.py:48-136): four bias-free Linear layers, two LayerNorms
+// One EncoderLayer (python/lib/model/attention.py:48-136) of the AttentionTower: four bias-free Linear layers, two LayerNorms
 // without parameters
 struct AttLayer {
     std::vector<float> qkv;  // project_qkv.weight [heads * (2 d_k + d_v)][d_model]: per head q | k | v rows

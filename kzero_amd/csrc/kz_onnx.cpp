@@ -848,7 +848,7 @@ struct Matcher {
         l.b = floats(n.in[2], (size_t)l.out);
         return l;
     }
-    // ---- AttentionTower (python/lib/model/attention.py:8-136) as torch's exporter writes it: MatMul against constant [in, out]
+    // ---- the AttentionTower network (python/lib/model/attention.py:8-136) as torch's exporter writes it: MatMul against constant [in, out]
     // matrices (bias-free Linear layers), Reshape / Transpose / Slice around them, LayerNorm spelled out ----
     std::vector<const ONode *> data_consumers(const std::string &name) const {  // (Shape nodes read only the dimensions)
         std::vector<const ONode *> r;

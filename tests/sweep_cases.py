@@ -14,7 +14,9 @@ Case = namedtuple("Case", "id game depth channels head kw boards")
 
 
 def _c(game, depth, channels, head, boards=5, **kw):
-    tag = "".join(f"_{k[6:] if k.startswith('dense_') else k}{v}" for k, v in sorted(kw.items()))
+    tag = "".join(f"_{k[6:] if k.startswith('dense_') else k}{v}" for k, v in sorted(kw.items()) if k != "attention")
+    if "attention" in kw:  # (heads, d_k, d_v, d_ff) of an AttentionTower in place of the ResTower
+        tag += "_att%dh%dk%dv%df" % kw["attention"]
     return Case(f"{game}_{depth}x{channels}_{head}{tag}", game, depth, channels, head, kw, boards)
 
 
@@ -76,6 +78,18 @@ CASES = [
     _c("ttt", 1, 32, "dense", dense_hidden_size=16, boards=3),
     _c("sttt", 3, 128, "dense", dense_hidden_channels=2),
     _c("sttt", 3, 64, "dense", dense_hidden_channels=4, dense_hidden_size=32, boards=7),
+    # --- round 5: PredictionHeads(AttentionTower, ...) (python/lib/model/attention.py:8-136; the tower
+    #     python/main/supervised_main_alpha.py:72 trains: d_model 256, 8 heads, d_k = d_v = 16, d_ff 256): the matrix-core
+    #     launch's shapes in both arithmetics, and shapes only the vector-ALU kernel takes (other head counts and sizes,
+    #     boards that are not 8x8) ---
+    _c("chess", 3, 256, "attention", attention=(8, 16, 16, 256), boards=7),
+    _c("chess", 1, 128, "dense", attention=(8, 16, 16, 128), dense_hidden_channels=8, boards=3),
+    _c("chess-hist-1", 1, 256, "attention", attention=(8, 16, 16, 256), boards=3),
+    _c("chess", 3, 256, "attention", attention=(8, 16, 16, 512), boards=3),
+    _c("chess", 3, 64, "attention", attention=(4, 16, 16, 96)),
+    _c("ataxx-7", 3, 64, "ataxx_conv", attention=(4, 8, 8, 96), boards=7),
+    _c("go-9", 1, 128, "conv", attention=(8, 16, 16, 128), boards=3),
+    _c("sttt", 1, 64, "dense", attention=(2, 16, 24, 64), dense_hidden_channels=2, boards=3),
 ]
 
 # the reference's own shipping configuration (python/main/loop_main_alpha.py:16-30,68-76): Go 9x9, 16 blocks x 128

@@ -18,7 +18,8 @@ import bench  # noqa: E402  (WORKLOADS, KERNEL_SOURCE)
 
 KERNEL_MATCH = {"kz_tower_resident_f16": "kz_tower_resident<", "kz_tower_resident_f32": "kz_tower_resident_f32",
                 "kz_tower_resident_split": "kz_tower_resident_split", "kz_tower_resident_f16g": "kz_tower_resident_split",
-                "kz_board_conv_f16": "kz_board_conv_f16", "kz_board_conv_split16": "kz_board_conv_split16", "kz_conv_igemm_f16": "kz_conv_igemm", "kz_conv_igemm_f32": "kz_conv_igemm"}
+                "kz_board_conv_f16": "kz_board_conv_f16", "kz_board_conv_split16": "kz_board_conv_split16", "kz_conv_igemm_f16": "kz_conv_igemm", "kz_conv_igemm_f32": "kz_conv_igemm",
+                "kz_att_tower_f16": "OpsF16", "kz_att_tower_f32": "OpsF32", "kz_att_tower_f32_valu": "kz_att_tower_f32"}
 
 
 def mean_counter(folder, counter, match):
