@@ -1003,7 +1003,8 @@ struct Matcher {
                 for (int b = a + 1; b < 3; b++)
                     if (lo[b] < lo[a]) { std::swap(lo[a], lo[b]); std::swap(hi[a], hi[b]); std::swap(sl[a], sl[b]); }
             const int64_t dk = hi[0];
-            if (lo[0] != 0 || dk <= 0 || lo[1] != dk || hi[1] != 2 * dk || lo[2] != 2 * dk || hi[2] <= lo[2]) fail("attention tower: q | k | v slice ranges");
+            if (lo[0] != 0 || dk <= 0 || dk > (1 << 16) || lo[1] != dk || hi[1] != 2 * dk || lo[2] != 2 * dk || hi[2] <= lo[2])
+                fail("attention tower: q | k | v slice ranges");
             // logits = bmm(q^T, k^T^T), softmax over the keys, bmm with v (attention.py:117-122; no scale factor)
             const ONode &tq = sole_consumer(sl[0]->out[0], "Transpose"), &tk = sole_consumer(sl[1]->out[0], "Transpose"),
                         &tv = sole_consumer(sl[2]->out[0], "Transpose");

@@ -26,7 +26,7 @@ def test_parsers_survive_mutated_files():
                  "ataxx7_2x16.dropout_cast.onnx", "chess_2x32_att.opset9.onnx")]
     files = sorted(glob.glob(os.path.join(GOLDEN, "*.onnx"))) + variants + [os.path.join(GOLDEN, n) for n in
                                                                   ("ataxx7_2x16.kzm", "chess_2x32_att.kzm",
-                                                                   "go9_2x16_conv.kzm", "chess_1x32_dense.kzm")]
+                                                                   "go9_2x16_conv.kzm", "chess_1x32_dense.kzm", "ataxx7_att2x32.kzm")]
     for seed in ("7", "10"):  # (10: the seed that found an int overflow in the descriptor before it was range-checked)
         out = subprocess.run([exe, "400", seed] + files, capture_output=True, text=True, timeout=250,
                              env={**os.environ, "UBSAN_OPTIONS": "print_stacktrace=1"})
