@@ -186,6 +186,9 @@ struct DeviceWeights {
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
     // AttentionTower (kz_att_tower.hip): the model's own matrices in f32
     float *att_expand = nullptr, *att_embedding = nullptr, *att_layers = nullptr;
+    bool att_heads = false;  // (set before build) ScalarHead + AttentionPolicyHead in one f16 launch (kz_att_heads.hip)
+    void *ah_w = nullptr;
+    float *ah_bias = nullptr;
     bool att_f16 = false;  // (set before build) the f16 launch's fragment streams instead of att_expand / att_layers
     void *att16_expand = nullptr, *att16_layers = nullptr;
     int *bc_rowmap = nullptr;  // (experiment build: kz_board_conv2_f16's tile-row map and halo-row list)
@@ -405,7 +408,16 @@ struct DeviceWeights {
                 break;
             }
             case kz::POLICY_ATTENTION:
-                if (upload_conv(m.p_bulk, p_bulk) || upload_conv(m.p_under, p_under)) return 1;
+                if (att_heads) {
+                    const int Q = m.policy_query_channels;
+                    std::vector<uint16_t> packed(kz::att_heads_weight_elems(C, Q));
+                    std::vector<float> bias((size_t)5 * Q + 16);
+                    kz::att_heads_pack(m.p_bulk.w.data(), m.p_bulk.b.data(), m.p_under.w.data(), m.p_under.b.data(), m.sh_conv.w.data(),
+                                       m.sh_conv.b.data(), C, Q, m.sh_conv.cout, packed.data(), bias.data());
+                    if (upload(packed.data(), packed.size() * 2, &ah_w) || upload_f32(bias, &ah_bias)) return 1;
+                } else if (upload_conv(m.p_bulk, p_bulk) || upload_conv(m.p_under, p_under)) {
+                    return 1;
+                }
                 if (upload(m.flat_to_att.data(), m.flat_to_att.size() * 4, (void **)&flat_to_att)) return 1;
                 break;
             case kz::POLICY_DENSE: {

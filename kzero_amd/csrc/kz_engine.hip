@@ -562,6 +562,20 @@ struct kz_engine {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         const void *x = act[tower_out];
+        if (wts->att_heads) {  // ScalarHead + AttentionPolicyHead in one launch
+            kz::AttHeadsArgs a{};
+            a.x = x; a.ldx = cp; a.batch = batch; a.channels = m.channels; a.q = m.policy_query_channels;
+            a.hc = m.sh_conv.cout; a.hs = m.sh_fc0.out; a.policy_len = m.policy_len;
+            a.weights = wts->ah_w; a.bias = wts->ah_bias;
+            a.w1 = wts->sh_w1; a.b1 = wts->sh_b1; a.w2 = wts->sh_w2; a.b2 = wts->sh_b2;
+            a.flat_to_att = wts->flat_to_att; a.scalars = d_scalars; a.policy = d_policy;
+            a.nonfinite_flag = nf_flag; a.epoch = nf_epoch;
+            prof.begin("kz_att_heads_f16", stream);
+            kz::launch_att_heads(a, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         {
             kz::ScalarHeadArgs a{x, cp, batch, hw, m.channels, m.sh_conv.cout, m.sh_fc0.out,
                                  wts->sh_w0, wts->sh_b0, wts->sh_w1, wts->sh_b1, wts->sh_w2, wts->sh_b2, d_scalars,
@@ -877,7 +891,9 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         const char *c2 = getenv("KZ_BOARD_CONV2");  // (the opt-in board-conv organisation has its own weight packing)
         variant = c2 && c2[0] == '1' ? 400 : 0;
 #endif
-        auto key = std::make_tuple(e->model.get(), device, dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + (e->att_f16 ? 800 : 0) + variant,
+        const bool att_heads = !e->fused_heads && att_heads_one_launch(m, dtype, e->split16);
+        auto key = std::make_tuple(e->model.get(), device,
+                                   dtype + (e->split16 ? 100 : 0) + (e->pairs16 ? 200 : 0) + (e->att_f16 ? 800 : 0) + (att_heads ? 1600 : 0) + variant,
                                    e->resident || e->resident32,
                                    e->fused_heads || e->fused_split || e->fused_pairs, board_conv);
         auto it = g_cache.find(key);
@@ -891,6 +907,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             w->fused_split = e->fused_split;
             w->fused_pairs = e->fused_pairs;
             w->att_f16 = e->att_f16;
+            w->att_heads = att_heads;
             if (w->build(m, e->resident, e->fused_heads, e->resident32, e->split16, e->pairs16)) return 1;
             g_cache[key] = w;
             e->wts = w;

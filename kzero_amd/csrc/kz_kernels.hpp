@@ -215,6 +215,25 @@ void att_tower16_pack_layer(const float *qkv, const float *out, const float *ff0
                             bool f32, void *dst);
 void launch_att_tower16(const AttTower16Args &t, hipStream_t stream);
 
+// ---- ScalarHead + AttentionPolicyHead of 8x8 boards in one launch, f16 (kz_att_heads.hip): for the f16 engines whose tower
+// launch does not carry these heads itself ----
+struct AttHeadsArgs {
+    const void *x;         // tower output rows [batch*64][ldx] f16
+    int ldx, batch, channels, q, hc, hs, policy_len;
+    const void *weights;   // att_heads_pack
+    const float *bias;
+    const float *w1, *b1, *w2, *b2;  // the scalar head's Linear layers as the model stores them ([hs][hc*64], [5][hs])
+    const int32_t *flat_to_att;
+    float *scalars, *policy;
+    int *nonfinite_flag = nullptr;   // the range check of ScalarHeadArgs
+    int epoch = 0;
+};
+bool att_heads_supported(int dtype, int h, int w, int channels, int q, int hc, int hs, int policy_len);
+size_t att_heads_weight_elems(int channels, int q);
+void att_heads_pack(const float *w_bulk, const float *b_bulk, const float *w_under, const float *b_under, const float *w_sc, const float *b_sc,
+                    int channels, int q, int hc, uint16_t *dst, float *bias);
+void launch_att_heads(const AttHeadsArgs &t, hipStream_t stream);
+
 // ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----
 // Requirements: f32, channels 256 with h*w <= 64, or channels 128 with h*w <= 96; depth >= 1.
 struct Tower32Args {

@@ -37,8 +37,18 @@ bool env_on(const char *name) {
     return v && v[0] == '1';
 }
 
+// the f16 engines' one-launch ScalarHead + AttentionPolicyHead (kz_att_heads.hip)
+bool att_heads_one_launch(const Model &m, int dtype, bool split16) {
+#ifdef KZ_EXPERIMENTS
+    if (env_on("KZ_NO_ATT_HEADS")) return false;  // (A/B against the four separate launches)
+#endif
+    return m.policy_kind == kz::POLICY_ATTENTION && dtype == KZ_DTYPE_F16 && !split16 &&
+           kz::att_heads_supported(dtype, m.h, m.w, m.channels, m.policy_query_channels, m.sh_conv.cout, m.sh_fc0.out, m.policy_len);
+}
+
 // launches of run_heads for a network whose tower output is materialised (head convolutions with cout_p = round_up(cout, 32))
 int head_launches(const Model &m, int dtype, bool split16, int cp) {
+    if (att_heads_one_launch(m, dtype, split16)) return 1;
     int n = 1;  // kz_scalar_head
     const bool f16_heads = split16 || dtype == KZ_DTYPE_F16;  // 1x1 head convolutions through kz_conv1x1_split where it fits
     switch (m.policy_kind) {
