@@ -84,7 +84,7 @@ template <class Epi>
 __device__ __forceinline__ void gemm_rows(const float *A, int lda, int n, int K, const float *__restrict__ W, int N, float *wst,
                                           Epi epi) {
     const int tid = threadIdx.x, cg = tid & 15, rg = tid >> 4;
-    const bool vec_w = (K & 3) == 0;
+    const bool vec_w = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;  // (16-byte loads of W's rows)
     for (int c0 = 0; c0 < N; c0 += 64) {
         for (int r0 = 0; r0 < n; r0 += 64) {
             float acc[4][4];

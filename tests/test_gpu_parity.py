@@ -1294,6 +1294,8 @@ ATT_CASES = [
     ("chess", 2, 192, (6, 32, 16, 320), "attention", "attention_tower_f32_valu", "attention_tower_f32_valu"),
     ("ataxx-7", 3, 96, (4, 12, 20, 100), "ataxx_conv", "attention_tower_f32_valu", "attention_tower_f32_valu"),
     ("go-9", 2, 64, (4, 16, 16, 128), "conv", "attention_tower_f32_valu", "attention_tower_f32_valu"),
+    # odd sizes everywhere: project_out's and ff.2's rows (12 and 8 values) start at byte offsets that are no multiple of 16
+    ("ataxx-7", 2, 25, (3, 3, 4, 8), "ataxx_conv", "attention_tower_f32_valu", "attention_tower_f32_valu"),
     ("chess-hist-2", 2, 256, (8, 16, 16, 256), "attention", "attention_tower_f32", "attention_tower_f16"),  # 47 input planes: more expand k-steps
 ]
 
