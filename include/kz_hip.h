@@ -185,7 +185,8 @@ int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_m
 /* Environment switches read by kz_engine_create.  This is the COMPLETE list for libkzhip.so (tests/test_abi.py compares
  * it with the strings in the built library); each selects between product paths that are parity-tested against the
  * oracle, none changes results beyond summation order, all are off by default:
- *   KZ_FORCE_GENERIC=1      no one-launch tower: one launch per layer ("board_conv_f16" / "conv_igemm_*")
+ *   KZ_FORCE_GENERIC=1      no one-launch tower: one launch per layer ("board_conv_f16" / "conv_igemm_*"); an AttentionTower
+ *                           network: the vector-ALU kernel ("attention_tower_f32_valu") instead of the matrix-core launch
  *   KZ_NO_BOARD_CONV=1      per-layer f16 convolutions through the implicit-GEMM kernel instead of the board-tile kernel
  *   KZ_NO_RESIDENT_F16G=1   no "tower_resident_f16g" launch (f16 shapes other than the chess network go per layer)
  *   KZ_NO_FUSED_HEADS=1     the "...+heads" launches without their heads: tower launch + separate head kernels
@@ -208,7 +209,11 @@ int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_m
  * "tower_resident_split16" (the other shapes of
  * KZ_DTYPE_F32_SPLIT16: tower launch + f32 head kernels).  One launch per layer:
  * "board_conv_f16" (whole boards as LDS tiles, Go-size boards), "board_conv_split16" (the same per-layer kernel in split
- * arithmetic: KZ_DTYPE_F32_SPLIT16 on boards the one-launch split tower cannot hold), "conv_igemm_f16", "conv_igemm_f32". */
+ * arithmetic: KZ_DTYPE_F32_SPLIT16 on boards the one-launch split tower cannot hold), "conv_igemm_f16", "conv_igemm_f32".
+ * Networks whose tower is the reference's AttentionTower (python/lib/model/attention.py:8-45) instead of the ResTower — one
+ * launch for the tower: "attention_tower_f16" / "attention_tower_f32" (8x8 boards, 8 heads of d_k = d_v = 16, d_model 128 / 256:
+ * f16 and exact f32 on the matrix cores), "attention_tower_f32_valu" (every other shape: exact f32 on the vector ALUs; an f16
+ * engine reads and writes f16 rows around it).  KZ_DTYPE_F32_SPLIT16 has no AttentionTower kernel: kz_model_supports_dtype = 0. */
 const char *kz_engine_tower_path(const kz_engine *engine);
 /* How the dominant launch of that path covers the chip for a batch of `batch` boards: workgroups per launch and boards
  * per workgroup (per-layer paths: boards_per_workgroup = 0 when a workgroup holds a tile, not whole boards). */

@@ -33,8 +33,16 @@ CASES = [("chess", 20, 256, "attention", 256, capi.KZ_DTYPE_F16, 200),
          ("go-13", 4, 128, "conv", 255, capi.KZ_DTYPE_F16, 100),     # one 13x13 board in eleven tiles
          ("go-13", 2, 192, "conv", 255, capi.KZ_DTYPE_F16, 100),
          ("go-9", 4, 128, "conv", 2047, capi.KZ_DTYPE_F16, 100),     # round 5: three boards per workgroup (sixteen tiles), ragged
-         ("chess", 4, 128, "attention", 2045, capi.KZ_DTYPE_F16, 100)]  # ... four 8x8 boards
-KW = {("go-9", 1025): dict(scalar_hidden_channels=8, scalar_hidden_size=128)}
+         ("chess", 4, 128, "attention", 2045, capi.KZ_DTYPE_F16, 100),  # ... four 8x8 boards
+         # round 5: AttentionTower networks — the matrix-core launch in f16 (two boards per workgroup, an odd board out; one per
+         # workgroup) and exact f32, the vector-ALU kernel, the one-launch ScalarHead + AttentionPolicyHead
+         ("chess", 6, 256, "attention", 253, capi.KZ_DTYPE_F16, 150),
+         ("chess", 6, 256, "attention", 97, capi.KZ_DTYPE_F16, 150),
+         ("chess", 4, 256, "attention", 249, capi.KZ_DTYPE_F32, 60),
+         ("ataxx-7", 3, 64, "ataxx_conv", 254, capi.KZ_DTYPE_F32, 60)]
+KW = {("go-9", 1025): dict(scalar_hidden_channels=8, scalar_hidden_size=128),
+      ("chess", 253): dict(attention=(8, 16, 16, 256)), ("chess", 97): dict(attention=(8, 16, 16, 256)),
+      ("chess", 249): dict(attention=(8, 16, 16, 256)), ("ataxx-7", 254): dict(attention=(4, 8, 8, 96))}
 bad = 0
 for game, depth, ch, head, batch, dtype, reps in CASES:
     blob = synth.random_model(game, depth, ch, head, seed=9, **KW.get((game, batch), {}))
