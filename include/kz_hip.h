@@ -46,6 +46,7 @@ extern "C" {
 #define KZ_POLICY_ATTENTION 2  /* AttentionPolicyHead, post_act.py:115-141 */
 #define KZ_POLICY_DENSE 3      /* DensePolicyHead,     post_act.py:26-51 */
 #define KZ_POLICY_ARIMAA 4     /* ArimaaPolicyHead,    post_act.py:144-173 (the server's arimaa-split game, server.rs:174) */
+#define KZ_POLICY_NONE 5       /* no PredictionHeads: a DenseNetwork (python/lib/model/simple.py:7-33), one Linear yields scalars and policy */
 
 typedef struct kz_model kz_model;
 typedef struct kz_engine kz_engine;
@@ -213,7 +214,8 @@ int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_m
  * Networks whose tower is the reference's AttentionTower (python/lib/model/attention.py:8-45) instead of the ResTower — one
  * launch for the tower: "attention_tower_f16" / "attention_tower_f32" (8x8 boards, 8 heads of d_k = d_v = 16, d_model 128 / 256:
  * f16 and exact f32 on the matrix cores), "attention_tower_f32_valu" (every other shape: exact f32 on the vector ALUs; an f16
- * engine reads and writes f16 rows around it).  KZ_DTYPE_F32_SPLIT16 has no AttentionTower kernel: kz_model_supports_dtype = 0. */
+ * engine reads and writes f16 rows around it).  KZ_DTYPE_F32_SPLIT16 has no AttentionTower kernel: kz_model_supports_dtype = 0.
+ * "dense_network_f32": a DenseNetwork (python/lib/model/simple.py), the whole network in one launch, f32 arithmetic. */
 const char *kz_engine_tower_path(const kz_engine *engine);
 /* How the dominant launch of that path covers the chip for a batch of `batch` boards: workgroups per launch and boards
  * per workgroup (per-layer paths: boards_per_workgroup = 0 when a workgroup holds a tile, not whole boards). */

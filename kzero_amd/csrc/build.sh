@@ -14,12 +14,12 @@ if [ "$EXP" = "1" ]; then
   OUT=${KZ_OUT:-../libkzhip_exp.so}
   B=${KZ_BUILD_DIR:-build_exp}
   DEFS="-DKZ_EXPERIMENTS"
-  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower4.hip kz_tower_f32.hip kz_tower_split.hip kz_tower_f16g.hip kz_tower_pairs_pack.hip kz_conv1x1_split.hip kz_board_conv.hip kz_board_conv2.hip kz_att_tower.hip kz_att_tower_mfma.hip kz_att_heads.hip kz_engine.hip"
+  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower4.hip kz_tower_f32.hip kz_tower_split.hip kz_tower_f16g.hip kz_tower_pairs_pack.hip kz_conv1x1_split.hip kz_board_conv.hip kz_board_conv2.hip kz_att_tower.hip kz_att_tower_mfma.hip kz_att_heads.hip kz_dense_network.hip kz_engine.hip"
 else
   OUT=${KZ_OUT:-../libkzhip.so}
   B=${KZ_BUILD_DIR:-build}
   DEFS=""
-  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower_f32.hip kz_tower_split.hip kz_tower_f16g.hip kz_tower_pairs_pack.hip kz_conv1x1_split.hip kz_board_conv.hip kz_att_tower.hip kz_att_tower_mfma.hip kz_att_heads.hip kz_engine.hip"
+  HIP_SRCS="kz_kernels.hip kz_tower.hip kz_tower_f32.hip kz_tower_split.hip kz_tower_f16g.hip kz_tower_pairs_pack.hip kz_conv1x1_split.hip kz_board_conv.hip kz_att_tower.hip kz_att_tower_mfma.hip kz_att_heads.hip kz_dense_network.hip kz_engine.hip"
 fi
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mcode-object-version=5 -Wall -Wno-unused-result $DEFS ${KZ_EXTRA_FLAGS:-}"
 mkdir -p $B

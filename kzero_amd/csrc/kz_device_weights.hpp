@@ -186,6 +186,9 @@ struct DeviceWeights {
     bool conv2 = false;  // the board-tile layers go through kz_board_conv2_f16
     // AttentionTower (kz_att_tower.hip): the model's own matrices in f32
     float *att_expand = nullptr, *att_embedding = nullptr, *att_layers = nullptr;
+    // DenseNetwork (kz_dense_network.hip)
+    float *dn_w_in = nullptr, *dn_b_in = nullptr, *dn_blocks = nullptr, *dn_sf = nullptr, *dn_tf = nullptr, *dn_w_out = nullptr,
+          *dn_b_out = nullptr;
     bool att_heads = false;  // (set before build) ScalarHead + AttentionPolicyHead in one f16 launch (kz_att_heads.hip)
     void *ah_w = nullptr;
     float *ah_bias = nullptr;
@@ -204,6 +207,22 @@ struct DeviceWeights {
         resident = want_resident;
         fused_heads = want_resident && want_fused;
 
+        if (m.tower_kind == kz::TOWER_DENSE_NET) {
+            // dn_in's columns from the channel-major flatten (c * hw + p) to the encoded rows' order (p * cin_p + c)
+            const int cin_p = round_up(m.c_in, 32), n_in = hw * cin_p;
+            std::vector<float> w_in((size_t)C * n_in, 0.0f);
+            for (int o = 0; o < C; o++)
+                for (int c = 0; c < m.c_in; c++)
+                    for (int p = 0; p < hw; p++) w_in[(size_t)o * n_in + (size_t)p * cin_p + c] = m.dn_in.w[(size_t)o * m.dn_in.in + (size_t)c * hw + p];
+            std::vector<float> blocks;
+            blocks.reserve(kz::dense_network_block_elems(C) * m.dn_blocks.size());
+            for (auto &b : m.dn_blocks)
+                for (const std::vector<float> *v : {&b.sa, &b.ta, &b.la.w, &b.la.b, &b.sb, &b.tb, &b.lb.w, &b.lb.b}) blocks.insert(blocks.end(), v->begin(), v->end());
+            if (upload_f32(w_in, &dn_w_in) || upload_f32(m.dn_in.b, &dn_b_in) || upload_f32(blocks, &dn_blocks) || upload_f32(m.dn_sf, &dn_sf) ||
+                upload_f32(m.dn_tf, &dn_tf) || upload_f32(m.dn_out.w, &dn_w_out) || upload_f32(m.dn_out.b, &dn_b_out))
+                return 1;
+            return 0;
+        }
         std::vector<float> ps(cp, 1.0f), pt(cp, 0.0f);
         for (int i = 0; i < C; i++) {
             ps[i] = m.final_scale[i];
@@ -420,6 +439,7 @@ struct DeviceWeights {
                 }
                 if (upload(m.flat_to_att.data(), m.flat_to_att.size() * 4, (void **)&flat_to_att)) return 1;
                 break;
+            case kz::POLICY_NONE: break;
             case kz::POLICY_DENSE: {
                 int ch = C, ch_p = cp;
                 if (m.dense_hidden_channels) {

@@ -136,6 +136,7 @@ struct kz_engine {
         return 0;
     }
     std::vector<void *> allocs, pinned;
+    bool dense_net = false;  // DenseNetwork: kz_dense_network.hip runs the whole network
     bool att_tower = false;  // AttentionTower network: kz_att_tower.hip runs the tower
     bool att_f16 = false;    // ... kz_att_tower_f16.hip does
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, pairs16 = false;
@@ -391,6 +392,20 @@ struct kz_engine {
                   const kz::DecodeArgs *dec = nullptr) {
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
+        if (dense_net) {  // DenseNetwork: encoded planes in x_in -> scalars and policy, one launch
+            kz::DenseNetArgs t{};
+            t.x0 = x_in; t.in_f16 = dtype == KZ_DTYPE_F16; t.batch = batch; t.hw = hw; t.cin_p = cin_p; t.size = m.channels;
+            t.depth = m.depth; t.res = m.dn_res ? 1 : 0; t.policy_len = m.policy_len;
+            t.w_in = wts->dn_w_in; t.b_in = wts->dn_b_in; t.blocks = wts->dn_blocks; t.sf = wts->dn_sf; t.tf = wts->dn_tf;
+            t.w_out = wts->dn_w_out; t.b_out = wts->dn_b_out; t.scalars = d_scalars; t.policy = d_policy;
+            t.nonfinite_flag = nf_flag; t.epoch = nf_epoch;
+            prof.begin("kz_dense_network", stream);
+            kz::launch_dense_network(t, stream);
+            prof.end(stream);
+            HIP_TRY(hipGetLastError());
+            tower_out = 0;
+            return 0;
+        }
         if (att_f16) {  // AttentionTower on the matrix cores, in the engine's arithmetic
             kz::AttTower16Args t{};
             t.f32 = dtype == KZ_DTYPE_F32;
@@ -558,7 +573,7 @@ struct kz_engine {
     }
 
     int run_heads(int batch, float *d_scalars, float *d_policy) {
-        if (fused_heads || fused32 || fused_split || fused_pairs) return 0;  // written by the tower launch
+        if (fused_heads || fused32 || fused_split || fused_pairs || dense_net) return 0;  // written by the tower launch
         const Model &m = *model;
         const int hw = m.h * m.w, M = batch * hw;
         const void *x = act[tower_out];
@@ -658,6 +673,7 @@ struct kz_engine {
                 prof.end(stream);
                 break;
             }
+            case kz::POLICY_NONE: break;
             case kz::POLICY_DENSE: {
                 const void *flat = x;
                 int flat_ld = hw * cp;
@@ -849,6 +865,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
         std::string why;
         if (!plan_path(m, max_batch, split16 ? KZ_DTYPE_F32_SPLIT16 : dtype, plan, why)) return fail("kz_engine_create: " + why);
     }
+    e->dense_net = plan.dense_net;
     e->att_tower = plan.att_tower;
     e->att_f16 = plan.att_f16;
     e->resident = plan.resident;
@@ -937,7 +954,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
 #ifdef KZ_EXPERIMENTS
     if (e->nb4 && e->dmalloc(&e->xres, kz::tower4_scratch_bytes(max_batch))) return 1;
 #endif
-    const int nact = (e->resident || e->resident32 || e->pairs16 || e->att_tower) ? 1 : 3;
+    const int nact = (e->resident || e->resident32 || e->pairs16 || e->att_tower || e->dense_net) ? 1 : 3;
     for (int i = 0; i < nact; i++)
         if (e->dmalloc(&e->act[i], rows * e->cp * e->esz)) return 1;
     // head temporaries
@@ -951,6 +968,7 @@ KZ_API int kz_engine_create(const kz_model *model, int device, int max_batch, in
             h0 = rows * w.p_bulk.cout_p;
             h1 = (size_t)max_batch * 8 * w.p_under.cout_p;
             break;
+        case kz::POLICY_NONE: break;
         case kz::POLICY_DENSE:
             if (m.dense_hidden_channels) h0 = rows * w.p_conv0.cout_p;
             if (m.dense_hidden_size) h1 = (size_t)max_batch * w.p_fc0.cout_p;
@@ -1013,7 +1031,8 @@ KZ_API int kz_engine_launch_geometry(const kz_engine *e, int batch, int *workgro
     if ((batch < 0 || batch > e->max_batch ? fail("kz_engine_launch_geometry: batch out of range") : 0)) return 1;
     const Model &m = *e->model;
     int per = 0, wgs = 0;
-    if (e->att_f16) per = kz::att_tower16_boards_per_workgroup(m.channels, m.att_dff, batch, e->dtype == KZ_DTYPE_F32);
+    if (e->dense_net) per = 1;
+    else if (e->att_f16) per = kz::att_tower16_boards_per_workgroup(m.channels, m.att_dff, batch, e->dtype == KZ_DTYPE_F32);
     else if (e->att_tower) per = 1;  // a workgroup is a board
     else if (e->resident) per = e->nb4 ? 4 : e->cin_p > 32 ? 2 : kz::tower_resident_boards_per_workgroup();
     else if ((e->split16 && !e->bsplit) || e->pairs16) per = kz::tower_split_boards_per_workgroup(m.h, m.w, m.channels, e->split16,

@@ -234,6 +234,21 @@ void att_heads_pack(const float *w_bulk, const float *b_bulk, const float *w_und
                     int channels, int q, int hc, uint16_t *dst, float *bias);
 void launch_att_heads(const AttHeadsArgs &t, hipStream_t stream);
 
+// ---- DenseNetwork with its DenseBlocks (python/lib/model/simple.py:7-52) in one launch, f32 arithmetic (kz_dense_network.hip) ----
+struct DenseNetArgs {
+    const void *x0;        // encoded input rows [batch*hw][cin_p], f32 or f16
+    int in_f16, batch, hw, cin_p, size, depth, res, policy_len;
+    const float *w_in, *b_in;    // [size][hw*cin_p] (columns in the rows' order: square-major, channels padded), [size]
+    const float *blocks;         // per block: sa | ta | wa [size][size] | ba | sb | tb | wb | bb
+    const float *sf, *tf, *w_out, *b_out;  // final BatchNorm1d as an affine; [5 + policy_len][size], [5 + policy_len]
+    float *scalars, *policy;
+    int *nonfinite_flag;
+    int epoch;
+};
+bool dense_network_supported(int h, int w, int c_in, int size, int depth, int policy_len);
+size_t dense_network_block_elems(int size);
+void launch_dense_network(const DenseNetArgs &a, hipStream_t stream);
+
 // ---- board-resident tower in exact f32 (kz_tower_f32.hip): stem + 2*depth 3x3 convolutions in ONE launch ----
 // Requirements: f32, channels 256 with h*w <= 64, or channels 128 with h*w <= 96; depth >= 1.
 struct Tower32Args {

@@ -228,6 +228,19 @@ void finalize_model(Model &m) {
         params += (int64_t)l.w.size() + (int64_t)l.b.size();
     };
     for (auto &c : m.tower) conv(c, hw);
+    if (m.tower_kind == TOWER_DENSE_NET) {
+        lin(m.dn_in);
+        for (auto &b : m.dn_blocks) {
+            lin(b.la);
+            lin(b.lb);
+            params += 4 * C;  // (the two BatchNorm1d as affines; the container counts their four vectors each: parse_model sets it)
+        }
+        lin(m.dn_out);
+        params += 2 * C;
+        m.flops_per_eval = 2.0 * macs;
+        if (m.param_count == 0) m.param_count = params;
+        return;
+    }
     if (m.tower_kind == TOWER_ATTENTION) {
         macs += attention_tower_macs(m);
         params += (int64_t)m.att_expand.size() + (int64_t)m.att_embedding.size();
@@ -263,6 +276,7 @@ void finalize_model(Model &m) {
             lin(m.pa_fc0);
             lin(m.pa_fc1);
             break;
+        case POLICY_NONE: break;
     }
     m.flops_per_eval = 2.0 * macs;
     if (m.param_count == 0) m.param_count = params;
@@ -311,6 +325,44 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
     if (kind == c.strings.end()) {
         err = "missing descriptor key 'policy_kind'";
         return nullptr;
+    }
+    {
+        auto tkd = c.strings.find("tower_kind");
+        if (tkd != c.strings.end() && tkd->second == "dense_network") {
+            // DenseNetwork with its DenseBlocks (python/lib/model/simple.py:7-52) under its state_dict names: seq.1 Linear; seq.{2+i}.seq.{0,2,3,5} per
+            // block; seq.{2+depth} BatchNorm1d; seq.{4+depth} Linear
+            if (kind->second != "none") {
+                err = "a dense_network has policy_kind 'none'";
+                return nullptr;
+            }
+            m->tower_kind = TOWER_DENSE_NET;
+            m->policy_kind = POLICY_NONE;
+            m->dn_res = L.geti("dn_res", 0) != 0;
+            const int size = m->channels, in = m->c_in * m->h * m->w;
+            if ((int64_t)m->policy_len + 5 > (1 << 24)) {
+                err = "bad architecture descriptor";
+                return nullptr;
+            }
+            std::vector<float> s, t;
+            m->dn_in = L.linear("seq.1", size, in);
+            for (int i = 0; i < m->depth; i++) {
+                const std::string p = "seq." + std::to_string(2 + i) + ".seq.";
+                Model::DnBlock b;
+                L.bn_affine(p + "0", size, true, eps, b.sa, b.ta);
+                b.la = L.linear(p + "2", size, size);
+                L.bn_affine(p + "3", size, true, eps, b.sb, b.tb);
+                b.lb = L.linear(p + "5", size, size);
+                m->dn_blocks.push_back(std::move(b));
+            }
+            L.bn_affine("seq." + std::to_string(2 + m->depth), size, true, eps, m->dn_sf, m->dn_tf);
+            m->dn_out = L.linear("seq." + std::to_string(4 + m->depth), 5 + m->policy_len, size);
+            m->final_scale.assign(size, 1.0f);
+            m->final_shift.assign(size, 0.0f);
+            if (!L.ok) return nullptr;
+            m->param_count = L.params;
+            m->flops_per_eval = 2.0 * ((double)size * in + 2.0 * m->depth * size * size + (double)(5 + m->policy_len) * size);
+            return m.release();
+        }
     }
     if (kind->second == "ataxx_conv") m->policy_kind = POLICY_ATAXX_CONV;
     else if (kind->second == "conv") m->policy_kind = POLICY_CONV;
@@ -479,6 +531,7 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
             macs += (double)hw * C * C + (double)hw * 4 * C + (double)hw * hc * C + (double)hs * hc * hw + 7.0 * hs;
             break;
         }
+        case POLICY_NONE: break;  // (a dense_network returned above)
     }
     if (!L.ok) return nullptr;
     m->param_count = L.params;
@@ -549,6 +602,7 @@ Model *pad_channels(const Model &m, int cpad) {
             o->p_conv1 = widen(m.p_conv1, m.p_conv1.cout, cpad);
             o->pa_conv = widen(m.pa_conv, m.pa_conv.cout, cpad);
             break;
+        case POLICY_NONE: break;
     }
     (void)C;
     return o.release();

@@ -19,7 +19,7 @@ struct Linear {  // nn.Linear, weights [out][in]
     std::vector<float> w, b;
 };
 
-enum TowerKind { TOWER_RES = 0, TOWER_ATTENTION = 1 };
+enum TowerKind { TOWER_RES = 0, TOWER_ATTENTION = 1, TOWER_DENSE_NET = 2 };
 
 // One EncoderLayer (python/lib/model/attention.py:48-136) of the AttentionTower: four bias-free Linear layers, two LayerNorms
 // without parameters
@@ -30,7 +30,8 @@ struct AttLayer {
     std::vector<float> ff1;  // ff.2.weight [d_model][d_ff]
 };
 
-enum PolicyKind { POLICY_ATAXX_CONV = 0, POLICY_CONV = 1, POLICY_ATTENTION = 2, POLICY_DENSE = 3, POLICY_ARIMAA = 4 };
+enum PolicyKind { POLICY_ATAXX_CONV = 0, POLICY_CONV = 1, POLICY_ATTENTION = 2, POLICY_DENSE = 3, POLICY_ARIMAA = 4,
+                  POLICY_NONE = 5 };  // NONE: a DenseNetwork (no PredictionHeads: one Linear yields scalars and policy)
 
 struct Model {
     // architecture descriptor
@@ -75,6 +76,19 @@ struct Model {
     // BEHIND the scalar branch's 1 + 6 outputs: pa_conv (C -> hc) + ReLU, Flatten, pa_fc0 (hc*hw -> hs) + ReLU, pa_fc1 (hs -> 7)
     Conv pa_conv;
     Linear pa_fc0, pa_fc1;
+
+    // DenseNetwork(game, depth, size, res) (python/lib/model/simple.py:7-52; the reference's own test networks,
+    // python/main/write_test_networks.py:14-18) — the WHOLE network, no tower / heads: Flatten (channel-major), Linear dn_in,
+    // `depth` DenseBlocks (BatchNorm1d as y = s x + t, ReLU, Linear, BatchNorm1d, ReLU, Linear; x + y when dn_res), BatchNorm1d,
+    // ReLU, Linear dn_out to 5 + policy_len.  tower_kind == TOWER_DENSE_NET, channels = size, policy_kind = POLICY_NONE.
+    struct DnBlock {
+        std::vector<float> sa, ta, sb, tb;
+        Linear la, lb;
+    };
+    bool dn_res = false;
+    Linear dn_in, dn_out;
+    std::vector<DnBlock> dn_blocks;
+    std::vector<float> dn_sf, dn_tf;
 
     int64_t param_count = 0;
     double flops_per_eval = 0;

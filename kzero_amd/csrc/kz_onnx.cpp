@@ -1061,6 +1061,92 @@ struct Matcher {
         return back->out[0];
     }
 
+    // ---- DenseNetwork with its DenseBlocks (python/lib/model/simple.py:7-52): Flatten, Gemm, blocks of BatchNormalization, Relu, Gemm,
+    // BatchNormalization, Relu, Gemm (+ Add with the block's input), BatchNormalization, Relu, Gemm; scalars = Slice [:, :5],
+    // policy = Slice [:, 5:] (reshaped to the game's policy shape) ----
+    void dense_network(Model &m, const ONode &flatten) const {
+        if (flatten.attr_i("axis", 1) != 1) fail("dense network: Flatten must keep the batch axis");
+        const ONode &gin = sole_consumer(flatten.out[0], "Gemm");
+        m.dn_in = gemm(gin);
+        const int size = m.dn_in.out;
+        if (m.dn_in.in != m.c_in * m.h * m.w) fail("dense network: the first Linear does not read the whole input");
+        m.tower_kind = TOWER_DENSE_NET;
+        m.policy_kind = POLICY_NONE;
+        m.channels = size;
+        std::string cur = gin.out[0];
+        bool first = true;
+        for (;;) {
+            auto bns = consumers(cur, "BatchNormalization");
+            if (bns.size() != 1) fail("dense network: expected one BatchNormalization behind '" + cur + "'");
+            std::vector<float> sa, ta;
+            bn_affine(*bns[0], size, sa, ta);
+            const ONode &r1 = sole_consumer(bns[0]->out[0], "Relu");
+            const ONode &g1 = sole_consumer(r1.out[0], "Gemm");
+            Linear l1 = gemm(g1);
+            if (l1.in != size) fail("dense network: Linear input size");
+            if (!consumers(g1.out[0], "Slice").empty()) {  // the last Linear: scalars | policy
+                if (consumers(cur).size() != 1) fail("dense network: the last block's output feeds something else too");
+                m.dn_sf = sa;
+                m.dn_tf = ta;
+                m.dn_out = std::move(l1);
+                cur = g1.out[0];
+                break;
+            }
+            Model::DnBlock b;
+            b.sa = sa;
+            b.ta = ta;
+            b.la = std::move(l1);
+            const ONode &bn2 = sole_consumer(g1.out[0], "BatchNormalization");
+            bn_affine(bn2, size, b.sb, b.tb);
+            const ONode &r2 = sole_consumer(bn2.out[0], "Relu");
+            const ONode &g2 = sole_consumer(r2.out[0], "Gemm");
+            b.lb = gemm(g2);
+            if (b.la.out != size || b.lb.in != size || b.lb.out != size) fail("dense network: block sizes");
+            auto adds = consumers(g2.out[0], "Add");
+            bool res = false;
+            std::string next = g2.out[0];
+            if (adds.size() == 1 && consumers(g2.out[0]).size() == 1) {
+                const ONode &add = *adds[0];
+                if (!((add.in[0] == cur && add.in[1] == g2.out[0]) || (add.in[1] == cur && add.in[0] == g2.out[0])))
+                    fail("dense network: the residual Add does not join the block's input with its output");
+                res = true;
+                next = add.out[0];
+            } else if (consumers(cur).size() != 1) {
+                fail("dense network: a block input with two consumers but no residual Add");
+            }
+            if (!first && res != m.dn_res) fail("dense network: blocks with and without residual");
+            m.dn_res = res;
+            first = false;
+            m.dn_blocks.push_back(std::move(b));
+            cur = next;
+            if (m.dn_blocks.size() > 4096) fail("dense network: too many blocks");
+        }
+        m.depth = (int)m.dn_blocks.size();
+        // scalars = output[:, :5]; policy = output[:, 5:].view(-1, *policy_shape) (simple.py:29-33)
+        const int outs = m.dn_out.out;
+        if (outs <= 5) fail("dense network: the last Linear must yield 5 scalars and the policy");
+        auto range_of = [&](const ONode &sl, int64_t &lo, int64_t &hi) {
+            const std::vector<int64_t> st = int_param(sl, "starts", 1), en = int_param(sl, "ends", 2), ax = int_param(sl, "axes", 3),
+                                       sp = int_param(sl, "steps", 4);
+            if (st.size() != 1 || en.size() != 1 || ax.size() != 1 || ax[0] != 1 || (!sp.empty() && (sp.size() != 1 || sp[0] != 1)))
+                fail("dense network: the outputs must be slices of axis 1");
+            lo = st[0];
+            hi = std::min<int64_t>(en[0], outs);
+        };
+        const ONode &ss = expect_producer("scalars", "Slice");
+        const ONode *ps = producer("policy");
+        if (ps && ps->op == "Reshape") ps = producer(ps->in[0]);
+        if (!ps || ps->op != "Slice" || ss.in[0] != cur || ps->in[0] != cur) fail("dense network: scalars / policy are not slices of the last Linear");
+        int64_t lo = 0, hi = 0;
+        range_of(ss, lo, hi);
+        if (lo != 0 || hi != 5) fail("dense network: scalars must be columns 0..5");
+        range_of(*ps, lo, hi);
+        if (lo != 5 || hi != outs) fail("dense network: the policy must be columns 5..");
+        m.policy_len = outs - 5;
+        m.final_scale.assign(size, 1.0f);
+        m.final_shift.assign(size, 0.0f);
+    }
+
     // name <- Relu <- Conv1x1 <- src ?  returns the conv
     bool relu_conv1x1(const std::string &name, const std::string &src, Conv &out) const {
         const ONode *r = producer(name, "Relu");
@@ -1106,6 +1192,13 @@ Model *parse_onnx(const void *blob, size_t len, int n_scalar, std::string &err) 
             fail("outputs must be ('scalars', 'policy'), or three outputs (value, wdl, policy) in that order (network/common.rs:36-49)");
         const int hw = m->h * m->w;
 
+        auto flat_in = M.consumers("input", "Flatten");
+        if (flat_in.size() == 1 && M.consumers("input", "Conv").empty() && M.consumers("input", "Transpose").empty()) {
+            // ---- DenseNetwork (simple.py:7-33): no tower, no heads ----
+            M.dense_network(*m, *flat_in[0]);
+            finalize_model(*m);
+            return m.release();
+        }
         std::string t;  // tower output seen by the heads
         int C = 0;
         auto to_tokens = M.consumers("input", "Transpose");

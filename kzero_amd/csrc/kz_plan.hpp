@@ -22,7 +22,9 @@
 //                                                       launch on v_mfma_f32_16x16x4_f32; d_ff <= 256)
 //     any other shape (f32, or f16 rows around f32 arithmetic)   -> attention_tower_f32_valu (one launch, vector ALUs)
 //     f32split16                                                 -> refused
+//   DenseNetwork (simple.py: no tower, no heads), f32 / f16         -> dense_network_f32 (one launch, f32 arithmetic)
 struct PathPlan {
+    bool dense_net = false;  // Model::tower_kind == TOWER_DENSE_NET: kz_dense_network.hip runs the whole network
     bool att_tower = false;  // Model::tower_kind == TOWER_ATTENTION: kz_att_tower.hip
     bool att_f16 = false;    // ... on the matrix cores (f16 or exact f32): kz_att_tower_mfma.hip
     bool resident = false, fused_heads = false, resident32 = false, split16 = false, bsplit = false, pairs16 = false;
@@ -68,6 +70,7 @@ int head_launches(const Model &m, int dtype, bool split16, int cp) {
         case kz::POLICY_ATTENTION: n += 3; break;
         case kz::POLICY_ARIMAA: n += 3; break;  // bulk: two 1x1 convolutions; the scalar branch through kz_scalar_head
         case kz::POLICY_DENSE: n += (m.dense_hidden_channels ? 1 : 0) + (m.dense_hidden_size ? 2 : 1); break;
+        case kz::POLICY_NONE: return 0;
     }
     return n;
 }
@@ -79,6 +82,20 @@ bool plan_path(const Model &m, int max_batch, int dtype_in, PathPlan &p, std::st
     const int cp = round_up(m.channels, 32);
     const bool force = env_on("KZ_FORCE_GENERIC"), nofuse = env_on("KZ_NO_FUSED_HEADS"), noboard = env_on("KZ_NO_BOARD_CONV");
     p = PathPlan();
+    if (m.tower_kind == kz::TOWER_DENSE_NET) {  // DenseNetwork (simple.py): the whole network is one launch behind the encode
+        if (split16) {
+            why = "KZ_DTYPE_F32_SPLIT16 has no DenseNetwork kernel: such a network runs in f32 arithmetic (KZ_DTYPE_F32, or KZ_DTYPE_F16 rows around it)";
+            return false;
+        }
+        if (!kz::dense_network_supported(m.h, m.w, m.c_in, m.channels, m.depth, m.policy_len)) {
+            why = "dense network: the board's input vector and the hidden vectors do not fit the LDS of one workgroup";
+            return false;
+        }
+        p.dense_net = true;
+        p.path = "dense_network_f32";
+        p.launches = 2;
+        return true;
+    }
     if (m.tower_kind == kz::TOWER_ATTENTION) {
         if (split16) {
             why = "KZ_DTYPE_F32_SPLIT16 has no attention-tower kernel: an AttentionTower network runs as KZ_DTYPE_F32 (exact) or KZ_DTYPE_F16";

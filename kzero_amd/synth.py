@@ -92,7 +92,7 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
                  n_bool: int = None, scalar_hidden_size: int = 32, block_gain: float = 1.0,
                  dense_hidden_channels: int = None, dense_hidden_size: int = None, scalar_hidden_channels: int = 4,
                  final_affine: bool = True, init: str = "uniform", arimaa_hidden_channels: int = 2,
-                 arimaa_hidden_size: int = 32, attention: tuple = None) -> bytes:
+                 arimaa_hidden_size: int = 32, attention: tuple = None, dense_network: bool = None) -> bytes:
     """`block_gain` > 1 scales every block's second BatchNorm weight: the residual stream then grows from block to block
     the way a trained network's does (a random-init tower keeps it within a few tens).
     `init`: "uniform" = PyTorch's default for Conv2d / Linear (U(+-1/sqrt(fan_in))); "kaiming_normal" = convolution weights
@@ -100,7 +100,9 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
     power draw, and with it the clock they sustain, depends on the data: DESIGN.md, bench.py `weights`).
     `attention` = (heads, d_k, d_v, d_ff): AttentionTower(board_size, input_channels, depth, channels, heads, d_k, d_v, d_ff)
     (python/lib/model/attention.py:8-30) in place of the ResTower, initialised as the reference does (:84-95: Xavier-normal,
-    gain (8 depth)^(-1/4) for v / project_out / ff, gain 1 for q / k; embedding N(0, 1); expand nn.Linear's default)."""
+    gain (8 depth)^(-1/4) for v / project_out / ff, gain 1 for q / k; embedding N(0, 1); expand nn.Linear's default).
+    `dense_network` = res (True / False), with head "none": DenseNetwork(game, depth, size = channels, res)
+    (python/lib/model/simple.py:7-52) — the whole network, no tower and no heads."""
     global _INIT
     if init not in ("uniform", "kaiming_normal"):
         raise ValueError(f"unknown init '{init}'")
@@ -108,14 +110,14 @@ def random_model(game: str, depth: int, channels: int, head: str, seed: int = 0,
     try:
         return _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
                              dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine,
-                             arimaa_hidden_channels, arimaa_hidden_size, attention)
+                             arimaa_hidden_channels, arimaa_hidden_size, attention, dense_network)
     finally:
         _INIT = "uniform"
 
 
 def _random_model(game, depth, channels, head, seed, query_channels, n_bool, scalar_hidden_size, block_gain,
                   dense_hidden_channels, dense_hidden_size, scalar_hidden_channels, final_affine,
-                  arimaa_hidden_channels, arimaa_hidden_size, attention=None) -> bytes:
+                  arimaa_hidden_channels, arimaa_hidden_size, attention=None, dense_network=None) -> bytes:
     g = game_spec(game)
     size, n_scalar = g["size"], g["n_scalar"]
     n_bool = g["n_bool"] if n_bool is None else n_bool
@@ -129,6 +131,24 @@ def _random_model(game, depth, channels, head, seed, query_channels, n_bool, sca
         "scalar_hidden_channels": scalar_hidden_channels, "scalar_hidden_size": scalar_hidden_size,
         "policy_kind": head, "policy_len": g["policy_len"], "bn_eps": 1e-5,
     }
+    if dense_network is not None:
+        if head != "none":
+            raise ValueError("a DenseNetwork has no heads: head='none'")
+        meta.update({"tower_kind": "dense_network", "dn_res": 1 if dense_network else 0})
+        for k in ("tower_final_affine", "scalar_hidden_channels", "scalar_hidden_size"):
+            del meta[k]
+        _linear(rng, t, "seq.1", C, (n_scalar + n_bool) * hw)
+        if game == "chess":  # raw counters (chess.rs:153-154): planes 6 and 7 of the channel-major flatten
+            t["seq.1.weight"][:, 6 * hw:7 * hw] *= 0.5
+            t["seq.1.weight"][:, 7 * hw:8 * hw] *= 0.01
+        for i in range(depth):
+            _bn(rng, t, f"seq.{2 + i}.seq.0", C)
+            _linear(rng, t, f"seq.{2 + i}.seq.2", C, C)
+            _bn(rng, t, f"seq.{2 + i}.seq.3", C)
+            _linear(rng, t, f"seq.{2 + i}.seq.5", C, C)
+        _bn(rng, t, f"seq.{2 + depth}", C)
+        _linear(rng, t, f"seq.{4 + depth}", 5 + g["policy_len"], C)
+        return write_model(meta, t)
     if attention is not None:
         _attention_tower(rng, t, meta, game, hw, n_scalar + n_bool, depth, C, *attention)
     else:

@@ -40,6 +40,7 @@ from lib.model.post_act import (  # noqa: E402  (reference)
     DensePolicyHead, ResBlock, ArimaaPolicyHead,
 )
 from lib.model.attention import AttentionTower  # noqa: E402  (reference)
+from lib.model.simple import DenseNetwork  # noqa: E402  (reference)
 
 from kzero_amd.model_file import write_model  # noqa: E402
 
@@ -114,7 +115,7 @@ def randomize_bn(net, gen):
     """Give every BN non-trivial affine parameters and running statistics
     (cf. python/main/write_test_networks.py:24-37 which trains for the same reason)."""
     for m in net.modules():
-        if isinstance(m, nn.BatchNorm2d):
+        if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
             with torch.no_grad():
                 m.weight.copy_(torch.empty_like(m.weight).uniform_(0.6, 1.4, generator=gen))
                 m.bias.copy_(torch.empty_like(m.bias).normal_(0.0, 0.2, generator=gen))
@@ -145,11 +146,26 @@ def export_onnx(net, path, shape):
                           dynamo=False)
 
 
-def gen_net(name, seed, batch, p_bool, layers=False, onnx=False, **kw):
+def build_dense_network(game_name, depth, size, res):
+    """DenseNetwork(game, depth, size, res) (python/lib/model/simple.py:7-33): no tower, no heads — Flatten, Linear, `depth`
+    DenseBlocks (BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU, Linear, residual optional), BatchNorm1d, ReLU, Linear to
+    5 + policy_size; the reference's own test networks (python/main/write_test_networks.py:14-18)."""
+    game = Game.find(game_name)
+    net = DenseNetwork(game, depth, size, res)
+    meta = {
+        "game": game.name, "board_h": game.board_size, "board_w": game.board_size,
+        "input_scalar_channels": game.input_scalar_channels, "input_bool_channels": game.input_bool_channels,
+        "tower_kind": "dense_network", "tower_depth": depth, "tower_channels": size, "dn_res": 1 if res else 0,
+        "policy_kind": "none", "policy_len": game.policy_size, "bn_eps": 1e-5,
+    }
+    return game, net, meta, (game.input_scalar_channels, game.input_bool_channels)
+
+
+def gen_net(name, seed, batch, p_bool, layers=False, onnx=False, dense_network=None, **kw):
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1)
     rng = np.random.default_rng(seed + 2)
-    game, net, meta, (n_scalar, n_bool) = build(**kw)
+    game, net, meta, (n_scalar, n_bool) = build_dense_network(*dense_network) if dense_network else build(**kw)
     randomize_bn(net, gen)
     net.eval()  # save_onnx.py:82
 
@@ -295,8 +311,19 @@ def main_attention():
             game_name="chess", depth=3, channels=256, head_kind="attention", query_channels=32, attention=(8, 16, 16, 256))
 
 
+def main_dense_network():
+    """The reference's own test networks (python/main/write_test_networks.py:14-18: DenseNetwork(sttt, 1, 64, False / True))
+    and a deeper one on chess."""
+    os.makedirs(OUT, exist_ok=True)
+    gen_net("sttt_dn1x64", 31, 3, 0.3, onnx=True, dense_network=("sttt", 1, 64, False))
+    gen_net("sttt_dn1x64_res", 32, 3, 0.3, onnx=True, dense_network=("sttt", 1, 64, True))
+    gen_net("chess_dn3x96_res", 33, 2, 0.05, dense_network=("chess", 3, 96, True))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "round5":
+    if len(sys.argv) > 1 and sys.argv[1] == "dense_network":
+        main_dense_network()
+    elif len(sys.argv) > 1 and sys.argv[1] == "round5":
         main_round5()
     elif len(sys.argv) > 1 and sys.argv[1] == "attention":
         main_attention()

@@ -59,7 +59,8 @@ typedef struct kzo_net {
 
     int h, w, n_scalar, n_bool, c_in;
     int depth, channels, final_affine;
-    int tower_kind; /* 0 ResTower (post_act.py:201-211), 1 AttentionTower (attention.py:8-45) */
+    int tower_kind; /* 0 ResTower (post_act.py:201-211), 1 AttentionTower (attention.py:8-45), 2 DenseNetwork (simple.py:7-33: the whole net) */
+    int dn_res;
     int att_heads, att_dk, att_dv, att_dff;
     float att_alpha, ln_eps;
     int sh_channels, sh_size;
@@ -251,6 +252,9 @@ KZO_EXPORT int kzo_load(const void *blob, size_t len, kzo_net **out) {
             kzo_free(net);
             return fail("bad attention tower descriptor");
         }
+    } else if (tk && tk->kind == 2 && !strcmp(tk->s, "dense_network")) {
+        net->tower_kind = 2;
+        net->dn_res = (int)meta_int(net, "dn_res", 0);
     } else if (tk && !(tk->kind == 2 && !strcmp(tk->s, "res"))) {
         kzo_free(net);
         return fail("unknown tower_kind");
@@ -260,7 +264,8 @@ KZO_EXPORT int kzo_load(const void *blob, size_t len, kzo_net **out) {
         kzo_free(net);
         return fail("missing policy_kind");
     }
-    if (!strcmp(kind->s, "ataxx_conv")) net->policy_kind = 0;
+    if (net->tower_kind == 2 && !strcmp(kind->s, "none")) net->policy_kind = -1;
+    else if (!strcmp(kind->s, "ataxx_conv")) net->policy_kind = 0;
     else if (!strcmp(kind->s, "conv")) net->policy_kind = 1;
     else if (!strcmp(kind->s, "attention")) net->policy_kind = 2;
     else if (!strcmp(kind->s, "dense")) net->policy_kind = 3;
@@ -604,12 +609,72 @@ done:
     return rc;
 }
 
+/* nn.BatchNorm1d in eval mode followed by ReLU, in place on a vector */
+static int bn1d_relu(const kzo_net *net, const char *prefix, float *v, int n) {
+    bnp bn;
+    if (get_bn(net, prefix, n, 1, &bn)) return -1;
+    for (int i = 0; i < n; i++) {
+        const float y = (v[i] - bn.mean[i]) / sqrtf(bn.var[i] + net->bn_eps) * bn.weight[i] + bn.bias[i];
+        v[i] = y > 0.0f ? y : 0.0f;
+    }
+    return 0;
+}
+
+static int get_linear(const kzo_net *net, const char *prefix, int out, int in, const float **w, const float **b) {
+    char name[128];
+    snprintf(name, sizeof name, "%s.weight", prefix);
+    *w = tensor_f32(net, name, (uint64_t)out * in);
+    snprintf(name, sizeof name, "%s.bias", prefix);
+    *b = tensor_f32(net, name, (uint64_t)out);
+    return (*w && *b) ? 0 : -1;
+}
+
+/* DenseNetwork.forward (python/lib/model/simple.py:26-33) for one board: Flatten (channel-major, as the NCHW input lies),
+ * Linear, `depth` DenseBlocks (:36-52: BatchNorm1d, ReLU, Linear, BatchNorm1d, ReLU, Linear; x + y when res), BatchNorm1d, ReLU,
+ * Linear; scalars = output[:5], policy = output[5:]. */
+static int dense_network(const kzo_net *net, const float *input, float *scalars_out, float *policy_out) {
+    const int in = net->c_in * net->h * net->w, size = net->channels, outs = 5 + net->policy_len;
+    char name[128];
+    const float *w, *b;
+    int rc = -1;
+    float *cur = malloc(sizeof(float) * (size_t)size), *a = malloc(sizeof(float) * (size_t)size), *hmid = malloc(sizeof(float) * (size_t)size);
+    float *out = malloc(sizeof(float) * (size_t)outs);
+    if (get_linear(net, "seq.1", size, in, &w, &b)) goto done;
+    linear(input, in, w, b, size, cur);
+    for (int i = 0; i < net->depth; i++) {
+        memcpy(a, cur, sizeof(float) * (size_t)size);
+        snprintf(name, sizeof name, "seq.%d.seq.0", 2 + i);
+        if (bn1d_relu(net, name, a, size)) goto done;
+        snprintf(name, sizeof name, "seq.%d.seq.2", 2 + i);
+        if (get_linear(net, name, size, size, &w, &b)) goto done;
+        linear(a, size, w, b, size, hmid);
+        snprintf(name, sizeof name, "seq.%d.seq.3", 2 + i);
+        if (bn1d_relu(net, name, hmid, size)) goto done;
+        snprintf(name, sizeof name, "seq.%d.seq.5", 2 + i);
+        if (get_linear(net, name, size, size, &w, &b)) goto done;
+        linear(hmid, size, w, b, size, a);
+        for (int j = 0; j < size; j++) cur[j] = net->dn_res ? cur[j] + a[j] : a[j];
+    }
+    snprintf(name, sizeof name, "seq.%d", 2 + net->depth);
+    if (bn1d_relu(net, name, cur, size)) goto done;
+    snprintf(name, sizeof name, "seq.%d", 4 + net->depth);
+    if (get_linear(net, name, outs, size, &w, &b)) goto done;
+    linear(cur, size, w, b, outs, out);
+    memcpy(scalars_out, out, sizeof(float) * 5);
+    memcpy(policy_out, out + 5, sizeof(float) * (size_t)net->policy_len);
+    rc = 0;
+done:
+    free(cur); free(a); free(hmid); free(out);
+    return rc;
+}
+
 /* One board through PredictionHeads.forward (post_act.py:194-198). Returns 0 or -1. */
 static int forward_board(const kzo_net *net, const float *input, float *scalars_out, float *policy_out, int board,
                          kzo_trace_fn trace, void *user) {
     const int h = net->h, w = net->w, hw = h * w, C = net->channels;
     char name[128];
     int rc = -1;
+    if (net->tower_kind == 2) return dense_network(net, input, scalars_out, policy_out);
     float *x = malloc(sizeof(float) * (size_t)C * hw);
     float *t0 = malloc(sizeof(float) * (size_t)C * hw);
     float *t1 = malloc(sizeof(float) * (size_t)C * hw);

@@ -90,6 +90,17 @@ int main(int argc, char **argv) {
         !same(o->pa_conv, k->pa_conv, "pa_conv", msg) || !same(o->pa_fc0, k->pa_fc0, "pa_fc0", msg) || !same(o->pa_fc1, k->pa_fc1, "pa_fc1", msg))
         return bad(msg);
     if (o->flat_to_att != k->flat_to_att) return bad("flat_to_att");
+    // DenseNetwork (python/lib/model/simple.py)
+    if (o->dn_res != k->dn_res || o->dn_blocks.size() != k->dn_blocks.size()) return bad("dense network descriptor");
+    if (!same(o->dn_in, k->dn_in, "dn_in", msg) || !same(o->dn_out, k->dn_out, "dn_out", msg) || !close(o->dn_sf, k->dn_sf, "dn_sf", msg) ||
+        !close(o->dn_tf, k->dn_tf, "dn_tf", msg))
+        return bad(msg);
+    for (size_t i = 0; i < o->dn_blocks.size(); i++) {
+        const auto &a = o->dn_blocks[i], &b = k->dn_blocks[i];
+        if (!close(a.sa, b.sa, "dn.sa", msg) || !close(a.ta, b.ta, "dn.ta", msg) || !close(a.sb, b.sb, "dn.sb", msg) || !close(a.tb, b.tb, "dn.tb", msg) ||
+            !same(a.la, b.la, "dn.la", msg) || !same(a.lb, b.lb, "dn.lb", msg))
+            return bad(msg);
+    }
     // AttentionTower (python/lib/model/attention.py): the descriptor and every matrix
     if (o->tower_kind != k->tower_kind || o->att_heads != k->att_heads || o->att_dk != k->att_dk || o->att_dv != k->att_dv ||
         o->att_dff != k->att_dff || o->att_layers.size() != k->att_layers.size() || std::fabs(o->att_alpha - k->att_alpha) > 1e-6f ||

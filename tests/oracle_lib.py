@@ -143,7 +143,9 @@ GOLDEN_NETS = ["ataxx7_2x16", "ataxx7_4x64", "chess_2x32_att", "chess_2x32_dense
                # round 5: the other games the server dispatches (server.rs:114-185)
                "arimaa_2x32", "ttt_2x16_dense", "sttt_2x16_dense_h",
                # PredictionHeads(AttentionTower, ...) (python/lib/model/attention.py; supervised_main_alpha.py:69-77)
-               "chess_att2x64", "ataxx7_att2x32", "chess_att3x256"]
+               "chess_att2x64", "ataxx7_att2x32", "chess_att3x256",
+               # DenseNetwork (python/lib/model/simple.py; the reference's own test networks, write_test_networks.py:14-18)
+               "sttt_dn1x64", "sttt_dn1x64_res", "chess_dn3x96_res"]
 
 
 def load_blob(name):

@@ -14,7 +14,7 @@ Case = namedtuple("Case", "id game depth channels head kw boards")
 
 
 def _c(game, depth, channels, head, boards=5, **kw):
-    tag = "".join(f"_{k[6:] if k.startswith('dense_') else k}{v}" for k, v in sorted(kw.items()) if k != "attention")
+    tag = "".join(f"_{k[6:] if k.startswith('dense_') and k != 'dense_network' else k}{v}" for k, v in sorted(kw.items()) if k != "attention")
     if "attention" in kw:  # (heads, d_k, d_v, d_ff) of an AttentionTower in place of the ResTower
         tag += "_att%dh%dk%dv%df" % kw["attention"]
     return Case(f"{game}_{depth}x{channels}_{head}{tag}", game, depth, channels, head, kw, boards)
@@ -90,6 +90,10 @@ CASES = [
     _c("ataxx-7", 3, 64, "ataxx_conv", attention=(4, 8, 8, 96), boards=7),
     _c("go-9", 1, 128, "conv", attention=(8, 16, 16, 128), boards=3),
     _c("sttt", 1, 64, "dense", attention=(2, 16, 24, 64), dense_hidden_channels=2, boards=3),
+    # --- DenseNetwork(game, depth, size, res) (python/lib/model/simple.py:7-52): the whole network an MLP ---
+    _c("sttt", 1, 64, "none", dense_network=False, boards=7),
+    _c("chess", 3, 256, "none", dense_network=True, boards=3),
+    _c("go-9", 2, 100, "none", dense_network=True),
 ]
 
 # the reference's own shipping configuration (python/main/loop_main_alpha.py:16-30,68-76): Go 9x9, 16 blocks x 128

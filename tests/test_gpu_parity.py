@@ -133,7 +133,8 @@ def test_onnx_variants_match_golden(dev, entry):
 
 @pytest.mark.parametrize("name,n_scalar", [("ataxx7_2x16", 1), ("chess_2x32_att", 8), ("chess_2x32_dense_h", 8),
                                            ("go9_2x16_conv_terr", 6), ("arimaa_2x32", 12), ("ttt_2x16_dense", 0),
-                                           ("sttt_2x16_dense_h", 0), ("chess_att2x64", 8), ("ataxx7_att2x32", 1)])
+                                           ("sttt_2x16_dense_h", 0), ("chess_att2x64", 8), ("ataxx7_att2x32", 1),
+                                           ("sttt_dn1x64", 0), ("sttt_dn1x64_res", 0)])
 def test_onnx_models_match_golden(dev, name, n_scalar):
     """N1: the engine fed with the trainer's ONNX file gives the reference PyTorch outputs (<= 1e-4, f32) and agrees
     with the same network loaded from the KZMODEL1 container."""

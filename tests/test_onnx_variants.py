@@ -53,12 +53,13 @@ def test_variant_parses_to_the_container_model(compare_exe, entry):
 
 
 @pytest.mark.parametrize("name,n_scalar", [("arimaa_2x32", 12), ("ttt_2x16_dense", 0), ("sttt_2x16_dense_h", 0),
-                                           ("chess_att2x64", 8), ("ataxx7_att2x32", 1)])
+                                           ("chess_att2x64", 8), ("ataxx7_att2x32", 1), ("sttt_dn1x64", 0), ("sttt_dn1x64_res", 0)])
 def test_round5_games_exported_by_the_reference_parse_to_the_container_model(compare_exe, name, n_scalar):
     """The other games the server dispatches (server.rs:114-185): arimaa-split's ArimaaPolicyHead (a fifth head kind) and
     ttt / sttt through DensePolicyHead with its trailing .view(-1, 1, n, n) — the reference exporter's opset-10 files.
     And PredictionHeads(AttentionTower, ...) (python/lib/model/attention.py; supervised_main_alpha.py:69-77): 258 nodes of
-    MatMul / Reshape / Transpose / Slice / Softmax / spelled-out LayerNorm for two encoder layers."""
+    MatMul / Reshape / Transpose / Slice / Softmax / spelled-out LayerNorm for two encoder layers.  And DenseNetwork
+    (python/lib/model/simple.py; write_test_networks.py:14-18): no tower, no heads, the outputs two slices of one Linear."""
     out = subprocess.run([compare_exe, os.path.join(GOLDEN, f"{name}.onnx"), str(n_scalar), os.path.join(GOLDEN, f"{name}.kzm")],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "models equal" in out.stdout, out.stdout + out.stderr[-2000:]
