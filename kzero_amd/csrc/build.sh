@@ -38,7 +38,7 @@ done
 for src in kz_model.cpp kz_onnx.cpp; do
   obj=$B/${src%.cpp}.o
   objs+=("$obj")
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ] || [ kz_onnx_match.hpp -nt "$obj" ]; then
     g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -c "$src" -o "$obj" &
     pids+=($!)
   fi
