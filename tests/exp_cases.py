@@ -1,8 +1,9 @@
 """Parity cases of the EXPERIMENT build (kzero_amd/libkzhip_exp.so: `KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh`): the kernel
 organisations that were built, measured and not adopted — four boards per workgroup (kz_tower4.hip), two Go boards per
 workgroup (kz_board_conv2.hip), the 32x32x16 MFMA variants, hipGraph replay, three Ataxx boards per workgroup of the
-exact-f32 launch — each against the product kernels compiled
-into the same library and against the oracle.  None of this code is in libkzhip.so.
+exact-f32 launch — each against the product kernels compiled into the same library and against the oracle; and, the other
+way round, the four head launches that the product's one-launch ScalarHead + AttentionPolicyHead kernel replaced
+(KZ_NO_ATT_HEADS=1).  None of the experiment code is in libkzhip.so.
 
 Not collected by `pytest tests/` (the file name does not match test_*.py): tests/test_gpu_experiments.py runs it in a
 child pytest process with KZ_LIB_PATH pointing at the experiment library.
@@ -230,3 +231,30 @@ def test_three_board_f32_launch_agrees_with_the_oracle(dev):
         st, pt = three_tower.eval_packed(bits[:n], scalars_in[:n])
         assert_f32(pt, p_ref[:n], f"policy, separate heads, {n} boards")
         assert_f32(st, s_ref[:n], f"scalars, separate heads, {n} boards")
+
+
+@pytest.mark.parametrize("game,depth,channels,kw", [
+    ("chess", 3, 128, {}),                                   # tower_resident_f16g, Q = C = 128
+    ("chess", 2, 256, dict(query_channels=64)),              # the chess launch without its heads (Q != 256)
+    ("chess", 2, 256, dict(attention=(8, 16, 16, 256))),     # the AttentionTower network
+    ("chess-hist-1", 2, 192, {}),
+])
+def test_one_launch_attention_heads_agree_with_the_four_launches(dev, game, depth, channels, kw):
+    """kz_att_heads_f16 (ScalarHead + AttentionPolicyHead of a board in one launch) against the four launches it replaces
+    (KZ_NO_ATT_HEADS=1, experiment build only: kz_scalar_head, two kz_conv1x1_split, kz_attention_mfma) — same operands and
+    rounding points (the 1x1 convolutions' outputs rounded to f16), other summation orders."""
+    blob = synth.random_model(game, depth, channels, "attention", seed=41, **kw)
+    model = capi.Model(blob=blob)
+    bits, scalars_in = synth.random_boards(game, 77, seed=42)
+    one = capi.Engine(model, dev, 128, capi.KZ_DTYPE_F16)
+    n_one = model.plan(128, capi.KZ_DTYPE_F16)[1]
+    os.environ["KZ_NO_ATT_HEADS"] = "1"
+    try:
+        four = capi.Engine(model, dev, 128, capi.KZ_DTYPE_F16)
+        n_four = model.plan(128, capi.KZ_DTYPE_F16)[1]
+    finally:
+        del os.environ["KZ_NO_ATT_HEADS"]
+    assert n_four == n_one + 3, (n_one, n_four)
+    s1, p1 = one.eval_packed(bits, scalars_in)
+    s4, p4 = four.eval_packed(bits, scalars_in)
+    assert np.abs(s1 - s4).max() <= F16_PATHS_ATOL and np.abs(p1 - p4).max() <= F16_PATHS_ATOL * max(1.0, float(np.abs(p4).max()))
