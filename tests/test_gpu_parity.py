@@ -1346,3 +1346,49 @@ def test_attention_tower_against_the_oracle(dev, game, depth, d_model, att, head
             assert np.abs(s3 - s2[:37]).max() <= F16_PATHS_ATOL and np.abs(p3 - p2[:37]).max() <= F16_PATHS_ATOL
         else:
             assert np.array_equal(s3, s2[:37]) and np.array_equal(p3, p2[:37])
+
+
+@pytest.mark.parametrize("dtype", [capi.KZ_DTYPE_F16, capi.KZ_DTYPE_F32])
+def test_attention_network_full_size_default_shim_entry(dev, dtype):
+    """The network python/main/supervised_main_alpha.py:69-77 builds — AttentionTower(8, 21, 16, 256, 8, 16, 16, 256) under the
+    ScalarHead and AttentionPolicyHead(game, 256, 256) — at full depth on 256 boards through the entry points `HipNetwork`
+    uses by default (submit_packed_decoded on all four slots, wait_decoded): against the oracle's decode_output of the ORACLE's
+    logits on every board (f16: the stated probability / value tolerances; exact f32: 1e-4) and against this library's own
+    logits decoded on the host."""
+    blob = synth.random_model("chess", 16, 256, "attention", seed=51, attention=(8, 16, 16, 256))
+    net = O.OracleNet(blob)
+    bits, scalars_in = synth.random_boards("chess", 256, seed=52)
+    s_ora, p_ora = net.forward(O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, 8, 8), threads=16)
+    eng = capi.Engine(capi.Model(blob=blob), dev, 256, dtype)
+    assert eng.tower_path == ("attention_tower_f16" if dtype == capi.KZ_DTYPE_F16 else "attention_tower_f32")
+    s_own, p_own = eng.eval_packed(bits, scalars_in)
+    if dtype == capi.KZ_DTYPE_F16:
+        assert_f16(s_own, s_ora, "scalars")
+        assert_f16(p_own, p_ora, "policy")
+    else:
+        assert_f32(s_own, s_ora, "scalars")
+        assert_f32(p_own, p_ora, "policy")
+    slots = []
+    for k in range(capi.KZ_ENGINE_SLOTS):
+        order = np.roll(np.arange(256), -64 * k)
+        moves = _c1_move_lists(net.policy_len, 256, seed=200 + k, finished=(9 + k,))
+        slots.append((order, moves, eng.submit_packed_decoded(k, bits[order], scalars_in[order], moves)))
+    worst_p = worst_v = worst_own = 0.0
+    for k in (1, 3, 0, 2):
+        order, moves, off = slots[k]
+        v, probs = eng.wait_decoded(k, off)
+        v_ora, probs_ora = O.decode_output(s_ora[order], p_ora[order], moves)
+        v_own, probs_own = O.decode_output(s_own[order], p_own[order], moves)
+        assert probs[9 + k].size == 0
+        for b in range(256):
+            if moves[b].size:
+                worst_p = max(worst_p, float(np.abs(probs[b] - probs_ora[b]).max()))
+                worst_own = max(worst_own, float(np.abs(probs[b] - probs_own[b]).max()))
+        worst_v = max(worst_v, float(np.abs(v[:, :4] - v_ora[:, :4]).max()))
+        worst_own = max(worst_own, float(np.abs(v - v_own).max()))
+    print(f"[decoded {eng.tower_path}] vs oracle: max |dprob| {worst_p:.2e}, max |dvalue, dwdl| {worst_v:.2e}; vs own logits: {worst_own:.2e}")
+    if dtype == capi.KZ_DTYPE_F16:
+        assert worst_p <= F16_PROB_ATOL and worst_v <= F16_VALUE_ATOL
+    else:
+        assert worst_p <= F32_ATOL and worst_v <= F32_ATOL
+    assert worst_own <= 2e-6
