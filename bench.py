@@ -88,10 +88,10 @@ WEIGHT_VARIANTS = [
     ("kaiming_normal (N(0, sqrt(2 / fan_in)) convolution weights)", dict(init="kaiming_normal")),
     ("trained-like scale (block_gain 3: the residual stream grows to ~170, logits to ~1.8e3)", dict(block_gain=3.0)),
 ]
+# BASELINE.json configs[1] (A1, f32), configs[2] at the <= 1e-4 default arithmetic, configs[4] (G8) in both arithmetics — and
+# nothing else: AttentionTower / DenseNetwork (SURVEY.md:145, out of scope) and go9-16x128 stay selectable with --workload
 OTHERS = [("ataxx-8x128", "f32"), ("ataxx-8x128", "f32split16"), ("go19-40x256", "f16"), ("chess-20x256", "f32split16"),
-          ("go19-40x256", "f32split16"), ("go9-16x128", "f32split16"), ("go9-16x128", "f16"),
-          # the reference's other tower (python/lib/model/attention.py; supervised_main_alpha.py:69-77): not a BASELINE config
-          ("chess-att16x256", "f16"), ("chess-att16x256", "f32")]
+          ("go19-40x256", "f32split16")]
 
 KERNEL_OF_PATH = {
     "tower_resident_f16+heads": "kz_tower_resident_f16", "tower_resident_f16": "kz_tower_resident_f16",
@@ -117,6 +117,7 @@ _PAIRS = ["kz_tower_pairs.hpp", "kz_tower_pairs_shapes.hpp", "kz_conv_heads.hpp"
 KERNEL_DEVICE_HEADERS = {"kz_tower.hip": ["kz_decode_dev.hpp"], "kz_tower_f32.hip": ["kz_conv_heads.hpp", "kz_decode_dev.hpp"],
                          "kz_tower_split.hip": _PAIRS, "kz_tower_f16g.hip": _PAIRS}
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "hbm_traffic.json")
+FULL_RECORD = os.environ.get("KZ_BENCH_FULL_RECORD", os.path.join(REPO, "bench_full.json"))
 
 
 def kernel_source_hash(kernel: str) -> str:
@@ -147,9 +148,15 @@ def parse_args(argv=None):
                     help="seconds of untimed conditioning steps before the --warmup steps (0 to disable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the sub-records of the other BASELINE configs")
+    ap.add_argument("--weight-variants", action="store_true",
+                    help="also run the headline network with other weight statistics (full record only: others[].weights)")
     ap.add_argument("--no-seam", action="store_true", help="skip the whole-seam sub-record (generators -> executor loop); --no-others skips it too")
     ap.add_argument("--seam-seconds", type=float, default=2.0)
-    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive timed region")
+    ap.add_argument("--boundary", default="decoded", choices=["decoded", "resident"],
+                    help="what `value` times.  decoded (default): host boards + move lists in, decoded values + legal-move "
+                         "probabilities out — what a caller of the Network trait gets.  resident: packed boards already in HBM, raw "
+                         "outputs left there (kernel A/B runs; what `value` was up to round 5)")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the secondary timed regions (device-resident and raw host boundary)")
     ap.add_argument("--other-seconds", type=float, default=1.0, help="timed seconds per sub-record")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time for the cpu_baseline sample")
     ap.add_argument("--fake-step", type=float, default=None, metavar="MS",
@@ -265,10 +272,11 @@ def cpu_baseline(blob, bits, scalars_in, target_seconds):
     except Exception as ex:  # noqa: BLE001
         a0 = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     return {"value": round(n / dt, 3), "unit": "evals/s", "cores": cores, "kind": "port", "a0": a0,
-            "sample": f"{n} boards of the same synthetic batch, oracle/kz_oracle.c f32 NCHW direct conv (zero-padded planes, nine taps and two output channels per pass), "
-                      f"OpenMP over boards on {cores} threads = the container's CPU quota (cgroup cpu.max; the affinity mask "
-                      f"allows {affinity}, the machine reports {os.cpu_count()}: a whole socket is not this process's to "
-                      f"use), {dt:.1f} s; single-thread {1.0 / one:.3f} evals/s"}
+            "sample": f"{n} boards of the same batch, oracle/kz_oracle.c (f32 direct conv), OpenMP on {cores} threads, {dt:.1f} s; "
+                      f"1 thread: {1.0 / one:.2f} evals/s",
+            "sample_detail": f"f32 NCHW direct conv (zero-padded planes, nine taps and two output channels per pass); {cores} threads = the "
+                             f"container's CPU quota (cgroup cpu.max; the affinity mask allows {affinity}, the machine reports "
+                             f"{os.cpu_count()}: a whole socket is not this process's to use)"}
 
 
 def committed_traffic(kernel: str, workload: str, batch: int):
@@ -293,7 +301,8 @@ class Workload:
 
     def __init__(self, capi, synth, name, dtype_name, batch, n_engines, device, seed, model_kw=None):
         import numpy as np
-        self.np, self.capi = np, capi
+        from kzero_amd import benchlib
+        self.np, self.capi, self.benchlib = np, capi, benchlib
         self.name, self.dtype_name, self.B, self.device = name, dtype_name, batch, device
         wl = WORKLOADS[name]
         self.wl = wl
@@ -386,16 +395,10 @@ class Workload:
         """The HBM-bound kernels around a per-layer tower (board encode in front, head kernels behind — the BN / ReLU tails
         themselves are fused into the convolutions' epilogues): average launch time and achieved GB/s against the 8 TB/s HBM
         peak, from the same HIP events as the dominant kernel.  Algorithmic bytes: what the kernel must read and write."""
-        info, B = self.info, self.B
-        hw, C = info.board_h * info.board_w, info.tower_channels
-        esz = 2 if self.dtype_name == "f16" else 4
-        cin_rows = 64 if self.tower_path == "board_conv_f16" and info.input_channels <= 64 else -(-info.input_channels // 32) * 32
-        act = B * hw * C * esz
-        byt = {"kz_encode_packed": B * (self.stride + 4 * info.input_scalar_channels) + B * hw * cin_rows * esz,
-               "kz_scalar_head": act + 4 * (4 * C + 32 * 4 * hw + 5 * 32) + B * 5 * 4,
-               "kz_conv1x1_split": act + C * C * 2 + B * info.policy_len * 4,
-               "kz_policy_conv": B * hw * C * esz + B * info.policy_len * 4,
-               "kz_policy_extra": act + B * 4, "kz_split_rows": 2 * act}
+        info = self.info
+        byt = self.benchlib.side_kernel_bytes(self.tower_path, self.dtype_name, self.B, info.board_h * info.board_w,
+                                              info.tower_channels, info.input_channels, info.input_scalar_channels,
+                                              self.stride, info.policy_len)
         out = []
         for name, nbytes in byt.items():
             ms = n = 0
@@ -403,9 +406,7 @@ class Workload:
                 m, k = e.kernel_time(name)
                 ms, n = ms + m, n + k
             if n:
-                us = ms / n * 1e3
-                out.append({"kernel": name, "launches": n, "avg_launch_us": round(us, 2), "algorithmic_bytes": int(nbytes),
-                            "achieved_GBps": round(nbytes / (us * 1e-6) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (us * 1e-6) / 8e12, 4)})
+                out.append(self.benchlib.bandwidth_record(name, n, ms / n * 1e3, nbytes))
         return out
 
     def kernel_time(self):
@@ -435,6 +436,16 @@ class Workload:
     def check_finite(self):
         s = self.outs[0][0].to_host(self.np.float32, (self.B, 5))
         assert self.np.isfinite(s).all(), "non-finite network output"
+
+    def check_finite_decoded(self):
+        """One more batch through the decoded boundary, read back: finite values, every board's probabilities sum to 1."""
+        np = self.np
+        e = self.host_engines[0]
+        e.submit_packed_decoded_csr(0, self.bits, self.scalars_in, self.moves[0], self.moves[1])
+        v, probs = e.wait_decoded(0, self.moves[0])
+        assert np.isfinite(v).all(), "non-finite decoded values"
+        sums = np.array([p.sum() for p in probs])
+        assert np.abs(sums - 1.0).max() < 1e-3, f"decoded probabilities do not sum to 1: {sums.min()}..{sums.max()}"
 
     def flops_per_launch(self, launches_per_step):
         info, B = self.info, self.B
@@ -477,7 +488,7 @@ class Workload:
             return int(2.5 * act + 9 * C * C * wbytes)
         return None
 
-    def roofline(self, k_ms, k_n, steps, evals_per_s_per_gpu):
+    def roofline(self, k_ms, k_n, steps, evals_per_s_per_gpu, concurrent=None):
         peak = 157.3 if self.dtype_name == "f32" else 2500.0  # f32split16: algorithmic FLOP against the f16 matrix cores
         avg_ms = k_ms / max(k_n, 1)
         fpl = self.flops_per_launch(k_n / max(steps, 1))
@@ -491,7 +502,12 @@ class Workload:
         # or a third of what the chip does.  `traffic` = HBM-side bytes of one launch from the committed PMC passes,
         # `traffic_ratio` = traffic / the launch's algorithmic bytes (weights once + what it must read and write).
         chip = evals_per_s_per_gpu * self.info.flops_per_eval / 1e12
-        return {"bound": "mfma", "kernel": self.kernel, "achieved": round(chip, 2), "peak": peak, "unit": "TFLOP/s",
+        if concurrent is None:  # the host boundary drives ONE engine of a one-launch path: its two slot streams run side by side
+            concurrent = 2 if self.tower_path.endswith("+heads") else len(self.host_engines)
+        # a fraction above 1 means the FLOP model or the timing is wrong: say so instead of printing it as an achievement
+        bad = [k for k, v in (("frac", chip / peak), ("launch_frac", achieved / peak)) if not 0.0 <= v <= 1.0]
+        return {**({"error": f"{', '.join(bad)} outside [0, 1]: the FLOP model or the launch timing is wrong"} if bad else {}),
+                "bound": "mfma", "kernel": self.kernel, "achieved": round(chip, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(chip / peak, 4), "launch_achieved": round(achieved, 2), "launch_frac": round(achieved / peak, 4),
                 "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic_ratio": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,
@@ -500,7 +516,7 @@ class Workload:
                                   "events around each of its ~85 launches per batch cost 1.7 % of the rate)") if self.per_layer
                 else "HIP events around every launch of the timed steps",
                 "workgroups_per_launch": wgs, "boards_per_workgroup": per or None,
-                "concurrent_launches": len(self.engines),
+                "concurrent_launches": concurrent,
                 "chip_frac": round(chip / peak, 4)}
 
     def close(self):
@@ -516,15 +532,17 @@ class Workload:
 
 
 def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm, model_kw=None):
-    """~`seconds` of timed steps of another BASELINE config on this GPU (N=1 only), device-resident like `value`."""
+    """~`seconds` of timed steps of another BASELINE config on this GPU (N=1 only), through the same decoded host boundary
+    as `value`."""
     wl = WORKLOADS[name]
     w = Workload(capi, synth, name, dtype_name, wl["batch"], wl["engines"][dtype_name], device, seed=1000, model_kw=model_kw)
     try:
-        w.condition(w.step_resident, prewarm)
+        step = w.step_host_decoded
+        w.condition(step, prewarm)
         t0 = time.perf_counter()
         probe = max(4, 2 * len(w.engines))
         for i in range(probe):
-            w.step_resident(i)
+            step(i)
         w.sync()
         per = (time.perf_counter() - t0) / probe
         steps = max(probe, int(seconds / max(per, 1e-6)))
@@ -532,19 +550,19 @@ def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm, model_kw
             w.profiling(True)
         t0 = time.perf_counter()
         for i in range(steps):
-            w.step_resident(i)
+            step(i)
         w.sync()
         dt = time.perf_counter() - t0
         if w.per_layer:
-            k_ms, k_n = w.instrumented_pass(w.step_resident, min(steps, 50))
+            k_ms, k_n = w.instrumented_pass(step, min(steps, 50))
         else:
             k_ms, k_n = w.kernel_time()
             w.profiling(False)
-        w.check_finite()
+        w.check_finite_decoded()
         value = steps * w.B / dt
         return {"metric": f"self-play NN evals/sec, {wl['label']}, 1 GPU", "workload": name, "dtype": dtype_name,
-                "value": round(value, 1), "unit": "evals/s", "batch": w.B, "steps": steps,
-                "ms_per_step": round(dt / steps * 1e3, 4), "engines_per_gpu": len(w.engines), "tower_path": w.tower_path,
+                "value": round(value, 1), "unit": "evals/s", "batch": w.B, "steps": steps, "boundary": "decoded host boundary",
+                "ms_per_step": round(dt / steps * 1e3, 4), "engines_per_gpu": len(w.host_engines), "tower_path": w.tower_path,
                 "flop_per_eval": w.info.flops_per_eval,
                 "roofline": w.roofline(k_ms, k_n, min(steps, 50) if w.per_layer else steps, value),
                 **({"hbm_bound_kernels": w.small} if getattr(w, "small", None) else {})}
@@ -697,14 +715,16 @@ def fake_main(args, benchlib, rank, local_rank, world, dist):
                                               "numa_node": numa["numa_node"], "numa_bound": numa["bound"], "host_cpus": numa["cpus"],
                                               "evals_s": round(args.steps / benchlib.median_region(own), 3)})
     if rank == 0:
-        print(json.dumps({"metric": "fake steps/sec (launcher test)", "value": round(args.steps * world / elapsed, 3),
+        from kzero_amd import benchline
+        print(benchline.emit({"metric": "fake steps/sec (launcher test)", "value": round(args.steps * world / elapsed, 3),
                           "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "regions": len(regions), "value_min": round(args.steps * world / max(regions), 3),
                           "value_max": round(args.steps * world / min(regions), 3),
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "fake", "devices_seen": sorted(set(seen)),
                           "per_rank": per_rank,
-                          "config": {"workload": "sleep", "parallelism": f"dp{world} (no collective)"}}), flush=True)
+                          "config": {"workload": "sleep", "parallelism": f"dp{world} (no collective)"}},
+                             os.environ.get("KZ_BENCH_FULL_RECORD")), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return 0
@@ -712,7 +732,7 @@ def fake_main(args, benchlib, rank, local_rank, world, dist):
 
 def main():
     args = parse_args()
-    from kzero_amd import benchlib
+    from kzero_amd import benchlib, benchline
     rank, local_rank, world, distributed = benchlib.rank_info()
     if args.gpus > 1 and not distributed:
         return spawn_ranks(args)  # nothing in this process has touched the GPU
@@ -748,62 +768,65 @@ def main():
     w = Workload(capi, synth, args.workload, args.dtype, args.batch, args.engines, device, benchlib.board_seed(rank))
     B = args.batch
 
-    # ---- timed regions 1 (`value`): inputs resident in HBM, outputs left in HBM; `--repeats` regions of K steps ----
-    w.condition(w.step_resident, args.prewarm)
-    own, h_own = [], []
-    regions = benchlib.run_timed_regions(w.step_resident, w.sync, args.steps, args.warmup, args.repeats, dist,
-                                         on_timed_start=None if w.per_layer else (lambda: w.profiling(True)), owns=own)
-    if w.per_layer:
-        k_ms, k_n = w.instrumented_pass(w.step_resident, min(args.steps, 50))
-    else:
-        k_ms, k_n = w.kernel_time()
-        w.profiling(False)
-    w.check_finite()
-    elapsed = benchlib.median_region(regions)
-    value = benchlib.whole_job_value(args.steps, B, world, elapsed)
-    region_values = [benchlib.whole_job_value(args.steps, B, world, t) for t in regions]
+    def timed(step, own, profile=True, prewarm=args.prewarm):
+        """`--repeats` regions of K steps of `step`, each bracketed by barrier + device sync; with `profile`, HIP events
+        around every launch of the timed steps (per-layer paths: an instrumented pass of the same steps behind them)."""
+        w.condition(step, prewarm)
+        regs = benchlib.run_timed_regions(step, w.sync, args.steps, args.warmup, args.repeats, dist,
+                                          on_timed_start=(lambda: w.profiling(True)) if profile and not w.per_layer else None, owns=own)
+        k = (0.0, 0)
+        if profile:
+            if w.per_layer:
+                k = w.instrumented_pass(step, min(args.steps, 50))
+            else:
+                k = w.kernel_time()
+                w.profiling(False)
+        vals = [benchlib.whole_job_value(args.steps, B, world, t) for t in regs]
+        med = benchlib.median_region(regs)
+        return {"regions": regs, "elapsed": med, "value": benchlib.whole_job_value(args.steps, B, world, med),
+                "values": vals, "k_ms": k[0], "k_n": k[1]}
 
-    # ---- timed regions 2 (`value_host_boundary`): the same K steps through the host-pointer boundary ----
+    # ---- timed regions 1 (`value`): the K steps through the boundary a caller has — host boards and move lists in, decoded
+    # values and legal-move probabilities out (kz_engine_submit_packed_decoded -> kz_engine_wait_decoded: what hip.rs runs
+    # by default, replacing cudnn.rs:55-87 + common.rs:16-100); H2D and D2H inside the timed region ----
+    own, r_own, h_own = [], [], []
+    decoded = args.boundary == "decoded"
+    main = timed(w.step_host_decoded if decoded else w.step_resident, own)
+    if decoded:
+        w.check_finite_decoded()
+    else:
+        w.check_finite()
+    regions, elapsed, value, region_values, k_ms, k_n = (main[k] for k in ("regions", "elapsed", "value", "values", "k_ms", "k_n"))
+    info = w.info
+    peak = 157.3 if args.dtype == "f32" else 2500.0
+
+    # ---- timed regions 2 (`value_device_resident`): packed boards already in HBM, raw outputs left in HBM ----
+    res = main
+    if decoded and not args.no_host_io:
+        res = timed(w.step_resident, r_own, prewarm=min(args.prewarm, 0.1))
+        w.check_finite()
+
+    # ---- timed regions 3 (`value_host_boundary_raw`): host boards in, the raw (scalars, policy) rows out
+    # (kz_engine_submit_packed -> kz_engine_wait_view: the reference's evaluate_batch alone, 7.5 KB D2H per chess eval) ----
     host = None
-    if not args.no_host_io:
-        w.condition(w.step_host, min(args.prewarm, 0.1))
-        h_regions = benchlib.run_timed_regions(w.step_host, w.sync, args.steps, args.warmup, args.repeats, dist,
-                                               on_timed_start=None if w.per_layer else (lambda: w.profiling(True)), owns=h_own)
-        if w.per_layer:
-            h_ms, h_n = w.instrumented_pass(w.step_host, min(args.steps, 50))
-        else:
-            h_ms, h_n = w.kernel_time()
-            w.profiling(False)
-        h_elapsed = benchlib.median_region(h_regions)
-        h_value = benchlib.whole_job_value(args.steps, B, world, h_elapsed)
-        h_values = [benchlib.whole_job_value(args.steps, B, world, t) for t in h_regions]
-        info = w.info
-        host = {"value": round(h_value, 1), "value_min": round(min(h_values), 1), "value_max": round(max(h_values), 1),
-                "unit": "evals/s", "steps": args.steps, "regions": len(h_regions),
-                "ms_per_step": round(h_elapsed / args.steps * 1e3, 4), "of_resident": round(h_value / value, 4),
+    if decoded and not args.no_host_io:
+        raw = timed(w.step_host, h_own, prewarm=min(args.prewarm, 0.1))
+        host = {"value": round(raw["value"], 1), "value_min": round(min(raw["values"]), 1), "value_max": round(max(raw["values"]), 1),
+                "unit": "evals/s", "steps": args.steps, "regions": len(raw["regions"]),
+                "ms_per_step": round(raw["elapsed"] / args.steps * 1e3, 4), "of_value": round(raw["value"] / value, 4),
                 "engines_per_gpu": len(w.host_engines),
                 "entry_points": "kz_engine_submit_packed -> kz_engine_wait_view (pinned staging, "
                                 f"{capi.KZ_ENGINE_SLOTS} slots per engine)",
                 "h2d_bytes_per_eval": int(w.stride + 4 * info.input_scalar_channels),
                 "d2h_bytes_per_eval": int(4 * (5 + info.policy_len)),
-                "kernel_avg_launch_ms": round(h_ms / max(h_n, 1), 5),
-                "chip_frac": round(h_value / world * info.flops_per_eval / 1e12 / (157.3 if args.dtype == "f32" else 2500.0), 4)}
-
-    # ---- timed regions 3 (`pcie_inclusive.decoded`): the boundary the Rust shim uses by default — move lists in, decoded
-    # values and legal-move probabilities out (0.2 KB instead of 7.5 KB per chess evaluation over PCIe) ----
-    if host is not None and w.info.input_scalar_channels >= 0:
-        try:
-            w.condition(w.step_host_decoded, min(args.prewarm, 0.1))
-            d_regions = benchlib.run_timed_regions(w.step_host_decoded, w.sync, args.steps, args.warmup, args.repeats, dist)
-            d_values = [benchlib.whole_job_value(args.steps, B, world, t) for t in d_regions]
-            d_value = benchlib.whole_job_value(args.steps, B, world, benchlib.median_region(d_regions))
-            host["decoded"] = {"value": round(d_value, 1), "value_min": round(min(d_values), 1), "value_max": round(max(d_values), 1),
-                               "of_resident": round(d_value / value, 4), "regions": len(d_regions),
-                               "entry_points": "kz_engine_submit_packed_decoded -> kz_engine_wait_decoded (hip.rs's default): "
-                                               "20-50 legal moves per board, decode_output inside the launch on the one-launch paths",
-                               "d2h_bytes_per_eval": int(20 + 4 * 35), "h2d_bytes_per_eval": int(w.stride + 4 * w.info.input_scalar_channels + 8 + 4 * 35)}
-        except Exception as ex:  # noqa: BLE001 (an additional record: its failure must not cost the line)
-            host["decoded"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+                "kernel_avg_launch_ms": round(raw["k_ms"] / max(raw["k_n"], 1), 5),
+                "chip_frac": round(raw["value"] / world * info.flops_per_eval / 1e12 / peak, 4)}
+    resident = {"value": round(res["value"], 1), "value_min": round(min(res["values"]), 1), "value_max": round(max(res["values"]), 1),
+                "regions": len(res["regions"]), "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 4),
+                "of_value": round(res["value"] / value, 4), "engines_per_gpu": len(w.engines),
+                "entry_points": "kz_engine_enqueue_packed_device (no PCIe in the timed region; no caller of the Network trait can obtain it)",
+                "kernel_avg_launch_ms": round(res["k_ms"] / max(res["k_n"], 1), 5),
+                "chip_frac": round(res["value"] / world * info.flops_per_eval / 1e12 / peak, 4)}
 
     # every rank's own line (a slow rank — NUMA, thermals, a bad link — must be visible next to the aggregate)
     per_rank = benchlib.gather_objects(dist, {
@@ -811,7 +834,7 @@ def main():
         "numa_bound": numa["bound"], "numa_bound_before_first_hip_call": numa.get("bound_before_first_hip_call", False),
         "host_cpus": numa["cpus"], "evals_s": round(args.steps * B / benchlib.median_region(own), 1),
         "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
-        "pcie_inclusive_evals_s": round(args.steps * B / benchlib.median_region(h_own), 1) if h_own else None})
+        "device_resident_evals_s": round(args.steps * B / benchlib.median_region(r_own), 1) if r_own else None})
     if rank != 0:
         w.close()
         if dist is not None:
@@ -822,40 +845,49 @@ def main():
     wl = WORKLOADS[args.workload]
     metric = ("self-play NN evals/sec (node), Chess 20x256 ResNet b=256, 1/2/4/8 GPU" if args.is_default_line else
               f"self-play NN evals/sec (node), {wl['label'].rsplit(' b=', 1)[0]} b={B}, {world} GPU")
-    roof = w.roofline(k_ms, k_n, min(args.steps, 50) if w.per_layer else args.steps * len(regions), value / world)
-    if host:  # the same fraction for the number a caller of the host-pointer boundary gets
-        roof["host_boundary_frac"] = host["chip_frac"]
+    roof = w.roofline(k_ms, k_n, min(args.steps, 50) if w.per_layer else args.steps * len(regions), value / world,
+                      concurrent=None if decoded else len(w.engines))
+    roof["device_resident_frac"] = resident["chip_frac"]
+    n_moves = int(w.moves[0][-1]) / B if w.moves is not None else 0
     out = {
         "metric": metric,
+        # value = the MEDIAN of `regions` timed regions of `steps` steps each through the decoded host boundary (every region
+        # bracketed by barrier + device sync); ms_per_step x steps = that region
         "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        # value = the MEDIAN of `regions` timed regions of `steps` steps each (every region bracketed by barrier + device
-        # sync); ms_per_step x steps = that region
         "regions": len(regions), "value_min": round(min(region_values), 1), "value_max": round(max(region_values), 1),
         "region_values": [round(v, 1) for v in region_values],
-        # what the reference's evaluate_batch boundary delivers (host boards in, host results out): compare THIS with the
-        # reference's `real` evals/s; the measurement contract keeps it out of `value` (inputs resident in HBM)
-        "value_host_boundary": host["value"] if host else None,
-        # ... and through the boundary the Rust shim uses by default (move lists in, decoded values + legal-move probabilities out)
-        "value_host_boundary_decoded": (host or {}).get("decoded", {}).get("value"),
-        "schema": "r5: value = median region; roofline.achieved/frac = the chip's (all concurrent launches; since r4), "
-                  "launch_achieved/launch_frac = one launch's (what frac meant in r1-r3)",
-        "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}, packed boards resident in HBM",
-                   "engines_per_gpu": args.engines, "conditioning_s": args.prewarm, "tower_path": w.tower_path,
+        # the same K steps with the packed boards already in HBM and the raw outputs left there (what `value` was up to round 5)
+        "value_device_resident": resident["value"] if decoded and not args.no_host_io else None,
+        # ... and through the raw host boundary (the reference's evaluate_batch alone: 7.5 KB of policy rows back per chess eval)
+        "value_host_boundary_raw": host["value"] if host else None,
+        "schema": "r6: value = the decoded host boundary (hip.rs's default entry points), median region; value_device_resident "
+                  "= r1-r5's value; roofline follows value: achieved/frac = the chip's (all concurrent launches), launch_frac = one launch's",
+        "config": {"workload": f"{args.workload} {wl['head']} head, executor batch {B}",
+                   "boundary": ("host boards + move lists in, decoded values + legal-move probabilities out "
+                                "(kz_engine_submit_packed_decoded/_wait_decoded), PCIe inside the timed region") if decoded else
+                   "device-resident (--boundary resident): packed boards in HBM, raw outputs left in HBM",
+                   "engines_per_gpu": len(w.host_engines) if decoded else len(w.engines), "conditioning_s": args.prewarm, "tower_path": w.tower_path,
                    "parallelism": f"dp{world} (no collective)", "flop_per_eval": w.info.flops_per_eval,
                    "weights": "PyTorch-default uniform init, seed 0 (others[].weights: the same network with other statistics)",
-                   "device_resident_evals_s": round(value, 1),
-                   "host_boundary_evals_s": host["value"] if host else None},
+                   "legal_moves_per_board": round(n_moves, 1),
+                   "h2d_bytes_per_eval": int(w.stride + 4 * info.input_scalar_channels + 8 + 4 * n_moves),
+                   "d2h_bytes_per_eval": int(20 + 4 * n_moves),
+                   "device_resident_evals_s": resident["value"],
+                   "host_boundary_raw_evals_s": host["value"] if host else None},
         "devices_seen": sorted(set(devices_seen)),
         "per_rank": per_rank,
         "roofline": roof,
+        "device_resident": resident,
     }
     if len(set(devices_seen)) < world:  # (only reachable with KZ_BENCH_ALLOW_SHARED_GPU=1)
         out["shared_gpu"] = True
         out["data"] = "synthetic; REHEARSAL: %d ranks share %d GPU(s) — not a scaling measurement" % (world, len(set(devices_seen)))
     if host:
-        out["pcie_inclusive"] = host
+        out["host_boundary_raw"] = host
+    if getattr(w, "small", None):
+        out["hbm_bound_kernels"] = w.small
     blob, bits, scalars_in = w.blob, w.bits, w.scalars_in
     w.close()
     if world == 1 and args.is_default_line and not args.no_others:
@@ -866,7 +898,7 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 out["others"].append({"workload": n, "dtype": d, "error": f"{type(ex).__name__}: {ex}"[:300]})
         # the headline network with other weight statistics, same box, same run (the matrix cores' power depends on the data)
-        for label, kw in WEIGHT_VARIANTS:
+        for label, kw in (WEIGHT_VARIANTS if args.weight_variants else []):
             try:
                 rec = sub_record(capi, synth, "chess-20x256", "f16", device, args.other_seconds, args.prewarm, model_kw=kw)
                 rec["weights"] = label
@@ -878,6 +910,7 @@ def main():
         par = [o for o in out["others"] if o.get("workload") == "chess-20x256" and o.get("dtype") == "f32split16" and "value" in o]
         if par:
             out["value_parity_default"] = par[0]["value"]
+            out["config"]["parity_default_dtype"] = "f32split16 (<= 1e-4 vs the oracle; hip.rs's default unless KZ_HIP_DTYPE=f16)"
             out["config"]["parity_default"] = ("KZ_DTYPE_F32_SPLIT16 (<= 1e-4 against the oracle; what the Rust binding runs unless "
                                                f"KZ_HIP_DTYPE=f16): {par[0]['value']} evals/s, frac {par[0]['roofline']['frac']}")
     if world == 1 and args.is_default_line and not args.no_seam and not args.no_others:
@@ -905,7 +938,8 @@ def main():
         except Exception as ex:  # noqa: BLE001 (the oracle library is test infrastructure: its absence must not cost the line)
             out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": None, "kind": "port",
                                    "error": f"{type(ex).__name__}: {ex}"[:300]}
-    print(json.dumps(out), flush=True)
+    # ONE line of at most 4 KB on stdout (kzero_amd/benchline.py); everything measured goes to bench_full.json beside it
+    print(benchline.emit(out, FULL_RECORD), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return 0

@@ -258,3 +258,42 @@ def median_region(regions: list) -> float:
 def whole_job_value(steps: int, batch: int, world: int, elapsed_max: float) -> float:
     """evals/s of the whole job: the units all ranks processed / the slowest rank's time."""
     return steps * batch * world / elapsed_max
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# byte model of the HBM-bound side kernels (bench.py's `hbm_bound_kernels`; tests/test_bench_line.py)
+# ------------------------------------------------------------------------------------------------------------------
+HBM_PEAK_BPS = 8e12  # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def side_kernel_bytes(tower_path: str, dtype_name: str, batch: int, hw: int, channels: int, input_channels: int,
+                      input_scalar_channels: int, bits_stride: int, policy_len: int) -> dict:
+    """Algorithmic bytes per launch — what the kernel must read plus what it must write — of the HBM-bound kernels around a
+    per-layer tower (board encode in front, head kernels behind; the BN / ReLU tails themselves are fused into the
+    convolutions' epilogues).  Channel counts are the padded row widths the engine allocates (kz_engine.hip, kz_engine_create)."""
+    esz = 2 if dtype_name == "f16" else 4
+    C = -(-channels // 32) * 32
+    # encoded input rows: 64 channels when the f16 stem runs through the board-tile kernel (kz_device_weights.hpp `stem64`)
+    cin_rows = 64 if tower_path == "board_conv_f16" and input_channels <= 64 else -(-input_channels // 32) * 32
+    act = batch * hw * C * esz
+    # kz_split_rows converts f32 rows to (hi, lo) f16 pairs: 4 B in + 4 B out per element.  When the stem itself runs in
+    # split arithmetic (board_conv_split16 and <= 32 input planes: kz_engine.hip `wts->stem_split`) it converts the ENCODED
+    # INPUT rows (one 32-channel chunk), otherwise the stem's f32 output at the tower width
+    split_c = 32 if tower_path == "board_conv_split16" and input_channels <= 32 else C
+    return {"kz_encode_packed": batch * (bits_stride + 4 * input_scalar_channels) + batch * hw * cin_rows * esz,
+            "kz_scalar_head": act + 4 * (4 * C + 32 * 4 * hw + 5 * 32) + batch * 5 * 4,
+            "kz_conv1x1_split": act + C * C * 2 + batch * policy_len * 4,
+            "kz_policy_conv": act + batch * policy_len * 4,
+            "kz_policy_extra": act + batch * 4,
+            "kz_split_rows": batch * hw * split_c * (4 + 4)}
+
+
+def bandwidth_record(kernel: str, launches: int, avg_launch_us: float, nbytes: int) -> dict:
+    """One `hbm_bound_kernels` row.  A fraction of the HBM peak above 1 means the byte model is wrong (round 5 printed
+    kz_split_rows at 4.4 x the peak because it charged the tower width for a 32-channel conversion): it is flagged."""
+    bps = nbytes / (avg_launch_us * 1e-6)
+    rec = {"kernel": kernel, "launches": launches, "avg_launch_us": round(avg_launch_us, 2), "algorithmic_bytes": int(nbytes),
+           "achieved_GBps": round(bps / 1e9, 1), "frac_of_hbm_peak": round(bps / HBM_PEAK_BPS, 4)}
+    if bps > HBM_PEAK_BPS:
+        rec["error"] = "above the HBM peak: the byte model is wrong (or the launch was served from L2)"
+    return rec
