@@ -186,9 +186,17 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // ---- set-up, ordered by latency: (1) this thread's 12 image pieces of chunk 0 are requested FIRST — everything about
     // a tile row (board, pixel, image row) is arithmetic on the thread id, no table is read — (2) then the weight ring,
     // (3) then, under those loads, the halo clear, the fragment rows and the accumulators.
-    // Slot i of a thread = tile row (tid >> 3) + 32 i, 16-byte piece tid & 7 of its 64 channels; the same 12 slots serve
+    // Slot i of a thread = tile row trow + 32 i, 16-byte piece `piece` of its 64 channels; the same 12 slots serve
     // the staging of every chunk, the residual and the output stores.
-    const int piece = tid & 7;
+    // f16: a ds_write_b128 is served in eight groups of 8 contiguous lanes, banks (a / 4) mod 32.  With a group = the eight
+    // pieces of ONE row (rounds 1-5: piece = tid & 7, row = tid >> 3), pieces 0..3 went to plane 0 and 4..7 to plane 1 at
+    // the same row offset — the planes are a multiple of 256 B apart for the fragment reads — and every group took two
+    // cycles: ~3e6 of the 5.8e6 SQ_LDS_BANK_CONFLICT cycles of a Go launch.  A group is now pieces 0..3 of rows r and r + 4
+    // (4 x 80 B = 64 mod 128: the other half of the bank row; 4 x 144 B likewise in the epilogue's output tile), the next
+    // group the same rows' pieces 4..7: lane bits (0,1) = piece low bits, 2 = row bit 2, 3 = the plane, (4,5) = row bits
+    // (0,1), the wave = row bits (3,4).  A wave's load or store still covers the same eight whole 128-byte rows.
+    const int piece = SPLIT ? (tid & 7) : ((tid & 3) | ((tid >> 1) & 4));
+    const int trow = SPLIT ? (tid >> 3) : (((tid >> 4) & 3) | (tid & 4) | ((tid >> 6) << 3));
     // f16: pieces 0..3 = channels [0, 32) -> plane 0, 4..7 -> plane 1.  SPLIT: pieces 0..3 = the hi halves of channel
     // pieces c = 0..3, 4..7 their lo halves: channel piece c lives in plane c & 1 at 16 (c >> 1), lo 32 bytes behind hi —
     // lane groups kq and kq + 1 then read the two planes at the same row offset, like the f16 instance
@@ -228,7 +236,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         if constexpr (SPLIT) return po_dbg[i];
 #endif
         if constexpr (SPLIT) {
-            const int base = *reinterpret_cast<const int *>(lds + a.rm_off + ROWS * 2 + ((tid >> 3) + i * 32) * 4);
+            const int base = *reinterpret_cast<const int *>(lds + a.rm_off + ROWS * 2 + (trow + i * 32) * 4);
             return base < 0 ? -1 : base + piece * 16;
         } else {
             return po[i];
@@ -239,9 +247,15 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         int b, q, irow;
-        const bool ok = locate((tid >> 3) + i * 32, b, q, irow);
+        const bool ok = locate(trow + i * 32, b, q, irow);
         irow0[i] = irow;
+#ifdef KZ_BC_L2_ABLATE
+        // DIAGNOSTIC BUILD ONLY (tools/ab_go_l2.sh; results are wrong): every workgroup of XCD x stages from, adds and stores to
+        // board x — the same instruction stream with the activation traffic served by the XCD's L2 instead of HBM
+        const unsigned pix = __umul24((unsigned)((board0 + b) & 7), (unsigned)a.hw) + (unsigned)q;
+#else
         const unsigned pix = __umul24((unsigned)(board0 + b), (unsigned)a.hw) + (unsigned)q;  // < boards * hw < 2^24
+#endif
         // (SPLIT: a row is [hi 32 | lo 32] per group of 32 channels — a chunk is again 128 contiguous bytes, pieces 0..3 its
         // hi halves, 4..7 its lo halves, and the same offsets serve input, residual and output)
         const int po_i = ok ? (int)((__umul24(pix, (unsigned)a.ld) + (unsigned)piece * 8) * 2) : -1;
@@ -252,8 +266,8 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         v0[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (int)((__umul24(pix, (unsigned)a.ldx) + (unsigned)piece * 8) * 2) : -1, 0, 0);
         if (piece == 0) {
             // (SPLIT: a padding row is marked in the table itself — there is no po[i] to ask)
-            *reinterpret_cast<unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2) = SPLIT && !ok ? (unsigned short)0xffff : (unsigned short)irow;
-            if constexpr (SPLIT) *reinterpret_cast<int *>(lds + a.rm_off + ROWS * 2 + ((tid >> 3) + i * 32) * 4) = po_i;  // (piece 0: the row's own offset)
+            *reinterpret_cast<unsigned short *>(lds + a.rm_off + (trow + i * 32) * 2) = SPLIT && !ok ? (unsigned short)0xffff : (unsigned short)irow;
+            if constexpr (SPLIT) *reinterpret_cast<int *>(lds + a.rm_off + ROWS * 2 + (trow + i * 32) * 4) = po_i;  // (piece 0: the row's own offset)
         }
         if constexpr (SPLIT) {
             if (!ok) irow0[i] = -1;
@@ -449,7 +463,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
             // every wave is done with this chunk's fragments; then the ring takes the next chunk's first PF k-steps ----
             int erow[12];
 #pragma unroll
-            for (int i = 0; i < 12; i++) erow[i] = *reinterpret_cast<const unsigned short *>(lds + a.rm_off + ((tid >> 3) + i * 32) * 2);
+            for (int i = 0; i < 12; i++) erow[i] = *reinterpret_cast<const unsigned short *>(lds + a.rm_off + (trow + i * 32) * 2);
             __syncthreads();
             KZ_STAMP(6 + (chunk & 3) * 4);
 #pragma unroll
@@ -472,7 +486,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         KZ_STAMP(18);
         const auto yrsrc = a.y32 ? __builtin_amdgcn_make_buffer_rsrc(a.y32, 0, a.bytes32, 0x00020000)
                                  : __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
-        const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
+        const int out_lds = trow * ORS + piece * 16;  // + i * 32 * ORS
         const float floor_ = a.relu ? 0.0f : -__builtin_inff();
         constexpr int NH = NTW / 2;
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -562,7 +576,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // each lane then replaces the 8 bytes it owns (its 4 channels of a pixel row) by relu(acc) + residual, added in f32.
     __syncthreads();  // every wave is done with the last chunk's fragments
     KZ_STAMP(18);
-    const int out_lds = (tid >> 3) * ORS + piece * 16;  // + i * 32 * ORS
+    const int out_lds = trow * ORS + piece * 16;  // + i * 32 * ORS
     if (with_res) {
 #pragma unroll
         for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
