@@ -30,7 +30,7 @@ objs=()
 for src in $HIP_SRCS; do
   obj=$B/${src%.hip}.o
   objs+=("$obj")
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_kernels.hpp -nt "$obj" ] || [ kz_conv_heads.hpp -nt "$obj" ] || [ kz_decode_dev.hpp -nt "$obj" ] || [ kz_tower_pairs.hpp -nt "$obj" ] || [ kz_tower_pairs_shapes.hpp -nt "$obj" ] || [ kz_tower_pairs_exp32.hpp -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ] || [ ../../include/kz_hip.h -nt "$obj" ] || { [ "$src" = kz_engine.hip ] && { [ kz_plan.hpp -nt "$obj" ] || [ kz_device_weights.hpp -nt "$obj" ] || [ kz_engine_util.hpp -nt "$obj" ]; }; }; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ kz_kernels.hpp -nt "$obj" ] || [ kz_conv_heads.hpp -nt "$obj" ] || [ kz_decode_dev.hpp -nt "$obj" ] || [ kz_tower_pairs.hpp -nt "$obj" ] || [ kz_tower_pairs_shapes.hpp -nt "$obj" ] || [ kz_tower_pairs_exp32.hpp -nt "$obj" ] || [ kz_model.hpp -nt "$obj" ] || [ ../../include/kz_hip.h -nt "$obj" ] || { [ "$src" = kz_engine.hip ] && { [ kz_plan.hpp -nt "$obj" ] || [ kz_device_weights.hpp -nt "$obj" ] || [ kz_engine_util.hpp -nt "$obj" ] || [ kz_engine_state.hpp -nt "$obj" ] || [ kz_engine_forward.hpp -nt "$obj" ]; }; }; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

@@ -10,6 +10,37 @@ int fail(const std::string &msg) {
     return 1;
 }
 
+// No C++ exception may cross the C ABI: the host on the other side is Rust (kzero_amd/rust/hip.rs), where an unwinding
+// foreign exception is undefined behaviour / an abort.  Every `extern "C"` entry point of kz_engine.hip runs its body through
+// this: std::bad_alloc / std::length_error from host-side packing or an absurd max_batch become a non-zero return with a
+// message behind kz_last_error(), like every other failure (the shim turns non-zero into the panic cudnn.rs:29-43 raises).
+template <class F>
+int guarded(const char *what, F &&body, int on_exception = 1) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try {
+            g_err.assign(what);
+            g_err.append(": out of host memory (std::bad_alloc)");
+        } catch (...) {
+        }
+    } catch (const std::exception &e) {
+        try {
+            g_err.assign(what);
+            g_err.append(": C++ exception: ");
+            g_err.append(e.what());
+        } catch (...) {
+        }
+    } catch (...) {
+        try {
+            g_err.assign(what);
+            g_err.append(": unknown C++ exception");
+        } catch (...) {
+        }
+    }
+    return on_exception;
+}
+
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \

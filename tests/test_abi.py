@@ -113,6 +113,50 @@ def test_bad_models_are_rejected_with_a_message():
         capi.Model(blob=write_model(meta2, dict(read_model(blob)[1])))
 
 
+def test_no_cpp_exception_crosses_the_c_abi():
+    """The host on the other side of the C ABI is Rust (kzero_amd/rust/hip.rs): an exception that unwinds through `extern "C"`
+    is undefined behaviour there.  Absurd sizes — from a corrupted settings value or a hostile model file — must come back
+    as a non-zero return with a message (the shim turns that into the panic rust/kz-core/src/network/cudnn.rs:29-43 raises),
+    and the process must survive.  Runs without a GPU: the checks sit in front of the first HIP call."""
+    import struct
+    model = capi.Model(blob=O.load_blob("ataxx7_2x16"))
+    for mb in (2**31 - 1, 2**30, 50_000_000):
+        with pytest.raises(capi.KzError, match="max_batch .* too large"):
+            capi.Engine(model, 0, mb, capi.KZ_DTYPE_F32)
+    with pytest.raises(capi.KzError, match="positive"):
+        capi.Engine(model, 0, 0, capi.KZ_DTYPE_F32)
+    # a container whose declared counts overflow every allocation: n_meta / n_tensors = 0xFFFFFFFF, a tensor of 2^62 dims
+    blob = O.load_blob("ataxx7_2x16")
+    for bad in (blob[:8] + struct.pack("<I", 0xFFFFFFFF) + blob[12:],
+                blob[:8] + struct.pack("<I", 0) + struct.pack("<I", 0xFFFFFFFF) + b"\x00" * 64,
+                blob[:8] + struct.pack("<I", 0) + struct.pack("<I", 1) + struct.pack("<H", 1) + b"t" + struct.pack("<BI", 0, 0xFFFFFFFF) + b"\x00" * 64,
+                blob[:8] + struct.pack("<I", 1) + struct.pack("<H", 0xFFFF) + b"k" * 10):
+        with pytest.raises(capi.KzError) as ei:
+            capi.Model(blob=bad)
+        assert str(ei.value)                       # a message, not an abort
+    # the ONNX reader's side of the same rule: a length-delimited field that claims 2^63 bytes
+    with pytest.raises(capi.KzError):
+        capi.Model(blob=b"\x08\x07\x3a" + b"\xff" * 9 + b"\x7f" + b"\x00" * 32)
+    # ... and the library still works afterwards
+    assert capi.Model(blob=blob).info.policy_len == 17 * 49 + 1
+
+
+def test_the_guard_turns_every_kind_of_exception_into_a_return_code():
+    """The guard every entry point runs through (kz_engine_util.hpp `guarded`), exercised for real: the experiment build
+    throws from inside kz_device_count on request — std::length_error, std::bad_alloc, a non-std exception."""
+    import subprocess, sys
+    exp = os.path.join(os.path.dirname(capi.LIB_PATH), "libkzhip_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("libkzhip_exp.so not built")
+    for mode, needle in (("1", "C++ exception: vector::_M_default_append"), ("2", "out of host memory"), ("3", "unknown C++ exception")):
+        code = ("from kzero_amd import capi\n"
+                "try:\n    capi.device_count(); print('NO ERROR')\n"
+                "except capi.KzError as e:\n    print('KzError:', e)\n")
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZ_LIB_PATH=exp, KZ_TEST_THROW=mode),
+                           capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
+        assert p.returncode == 0 and "KzError: kz_device_count: " + needle in p.stdout, (p.stdout, p.stderr)
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """The product path must fail when it cannot run on a GPU; it never computes on the CPU."""
     try:
