@@ -577,11 +577,12 @@ def sub_record(capi, synth, name, dtype_name, device, seconds, prewarm, model_kw
 # "pre" = the generators computed the policy indices (move generation + lookups on their threads) and the GPU decodes;
 # "packed" = pre-packed boards and move lists: the channel and PCIe alone (what rounds 1-3 reported as `seam`).
 SEAM_CONFIGS = [
-    dict(name="hip.rs default (KZ_HIP_DECODE=device, KZ_HIP_PREP_THREADS=1): encode_input and move lists at submit, shared "
-              "between the executor thread and one helper thread; gather + softmax inside the network's launch; one executor thread",
-         work="real", gpu_threads=1, depth=3, device_decode=1, helpers=1),
-    dict(name="the same without the helper thread (KZ_HIP_PREP_THREADS=0: all host work on the executor thread, as in round 4)",
+    dict(name="hip.rs default (KZ_HIP_DECODE=device, KZ_HIP_PREP_THREADS=0): encode_input and move lists at submit on the executor "
+              "thread; gather + softmax inside the network's launch; one executor thread",
          work="real", gpu_threads=1, depth=3, device_decode=1, helpers=0),
+    dict(name="the same with one prep helper thread (KZ_HIP_PREP_THREADS=1: the batch's host work cut in two; the C++ mirror's "
+              "persistent helper — the Rust shim's scoped threads spawn per batch and are not what this times)",
+         work="real", gpu_threads=1, depth=3, device_decode=1, helpers=1),
     dict(name="KZ_HIP_DECODE=host (the reference's decode_output on the executor thread), one executor thread", work="real",
          gpu_threads=1, depth=3, device_decode=0, helpers=0),
     dict(name="KZ_HIP_DECODE=host, gpu_threads_per_device = 4", work="real", gpu_threads=4, depth=2, device_decode=0, helpers=0),

@@ -1,6 +1,6 @@
 #!/bin/bash
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 # A/B of the tower-only launch (KZ_NO_FUSED_HEADS=1) with 2 and 4 boards per workgroup: identical outputs, then timing
 # interleaved on one box.   tools/ab_nb4.sh [engines for NB=4, default 4]
 export KZ_NO_FUSED_HEADS=1

@@ -1,6 +1,6 @@
 #!/bin/bash
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 # NB=4 tower-only, one launch filling the chip (batch 1024 = 256 workgroups): product vs ablation builds, same box
 export KZ_NO_FUSED_HEADS=1 KZ_TOWER_NB=4
 for r in 1 2; do for v in "" _NOXLOAD _NOXIO; do

@@ -1,6 +1,6 @@
 #!/bin/bash
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 # A/B of the tower-only launch (KZ_NO_FUSED_HEADS=1) with 4 and 8 waves per workgroup: identical outputs, then timing
 # interleaved on one box.
 export KZ_NO_FUSED_HEADS=1

@@ -1,6 +1,6 @@
 #!/bin/bash
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 # Chess 20x256 plain f16 through the generic one-launch tower (KZ_NO_TOWER_F16=1: tower_resident_f16g, one board per
 # workgroup, separate head launches): 16x16x32 against 32x32x16 MFMAs — does the lower register-file traffic per FLOP
 # of the large tile raise the power-limited rate in a real kernel?  Usage (GPU box): bash tools/f16g32_ab.sh

@@ -1,6 +1,6 @@
 #!/bin/bash
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 # hipGraph replay (KZ_HIP_GRAPH=1) against eager launches on the multi-launch paths: Go-19 40x256 f16 B=512 (85 launches
 # per batch), Ataxx 8x128 f16 B=256 (one-launch tower + 4 head launches, host-bound), device-resident and PCIe-inclusive.
 # Usage (GPU box): bash tools/graph_ab.sh

@@ -1,6 +1,6 @@
 export KZ_NO_FUSED_HEADS=1 KZ_TOWER_NB=${NB:-4}
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 for e in 1 2 3 4 6; do
 python bench.py --no-others --no-cpu-baseline --no-host-io --steps 1500 --warmup 30 --engines $e ${BENCH_ARGS:-} | python -c "
 import json,sys

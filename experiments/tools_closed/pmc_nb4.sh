@@ -1,6 +1,6 @@
 #!/bin/bash
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 # in-load clock and MFMA-busy share of the tower-only launch at a FULL chip: NB=2 (batch 512) vs NB=4 (batch 1024)
 export TMPDIR=/tmp KZ_NO_FUSED_HEADS=1
 for cfg in "2 512" "4 1024"; do set -- $cfg; nb=$1; batch=$2

@@ -1,6 +1,6 @@
 #!/bin/bash
-# (experiment kernels: needs the experiment build, KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh)
-export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/kzero_amd/libkzhip_exp.so}
+# (experiment kernels: needs the experiment build, experiments/build.sh)
+export KZ_LIB_PATH=${KZ_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/experiments/libkzhip_exp.so}
 # Chess 20x256 through KZ_DTYPE_F32_SPLIT16: the 16x16x32 launch (default) against the 32x32x16 one (KZ_SPLIT_MFMA32=1),
 # alternating, plus the split parity tests on both.  Usage (GPU box): bash tools/split32_ab.sh
 mkdir -p gpurun_out/s32

@@ -31,7 +31,7 @@ struct StartupSettings {
     // not in the reference: decode_output on the GPU instead of on the executor thread
     bool device_decode = false;
     // not in the reference: helper threads per executor thread that share a batch's host work (encode_input, move lists)
-    // with it (HipNetwork::set_prep_helpers; hip.rs: KZ_HIP_PREP_THREADS, default 1)
+    // with it (HipNetwork::set_prep_helpers; hip.rs: KZ_HIP_PREP_THREADS, default 0)
     size_t prep_helpers = 0;
 };
 

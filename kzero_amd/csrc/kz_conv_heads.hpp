@@ -191,6 +191,9 @@ __device__ __forceinline__ void conv_heads_tail(const Dev &a, unsigned char *lds
         // this workgroup above; wave w gathers and normalises the available moves of boards w, w + 4, ...
         __threadfence();
         __syncthreads();
+        // (four waves share the staging region, a quarter each, and take boards w, w + 4, ...: every instantiation of this tail
+        // is a 256-thread workgroup — a wider one would write past the region and decode boards twice)
+        if (blockDim.x != 256) __builtin_trap();
         const int wv = tid >> 6, cap = stage_bytes / 16;  // floats per wave
         float *st = reinterpret_cast<float *>(lds + stage) + wv * cap;
         for (int bb = wv; bb < boards; bb += 4) {

@@ -392,6 +392,12 @@ static Model *parse_model_checked(const void *blob, size_t len, std::string &err
         }
         m->att_alpha = c.floats.count("att_alpha") ? (float)c.floats.at("att_alpha") : (float)std::pow(2.0 * m->depth, 0.25);
         if (c.floats.count("ln_eps")) m->ln_eps = (float)c.floats.at("ln_eps");
+        // LayerNorm(x * alpha + f(x)): the matrix-core tower folds 1 / alpha into the weights and uses eps / alpha^2
+        // (att_tower16_pack_layer), which is the same function only for a finite alpha > 0 and a finite eps >= 0
+        if (!(std::isfinite(m->att_alpha) && m->att_alpha > 0.0f) || !(std::isfinite(m->ln_eps) && m->ln_eps >= 0.0f)) {
+            err = "attention tower: att_alpha must be finite and > 0, ln_eps finite and >= 0";
+            return nullptr;
+        }
         m->att_expand = L.f32("common.expand.weight", (uint64_t)C * m->c_in);
         m->att_embedding = L.f32("common.embedding", (uint64_t)hw * C);
         for (int i = 0; i < m->depth; i++) {

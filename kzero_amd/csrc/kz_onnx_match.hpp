@@ -307,6 +307,10 @@ struct Matcher {
             matmul_weight(f1, din, d2, L.ff1);
             if (din != dff || d2 != D) fail("attention tower: ff.2 sizes");
             const std::string next = layernorm(deepnorm_add(y, f1, alpha2), eps2);
+            for (float v : {alpha, alpha2})
+                if (!(std::isfinite(v) && v > 0.0f)) fail("attention tower: the residual scale (alpha) must be finite and > 0");
+            for (float v : {eps, eps2})
+                if (!(std::isfinite(v) && v >= 0.0f)) fail("attention tower: LayerNorm epsilon must be finite and >= 0");
             if (m.att_layers.empty()) {
                 m.att_heads = H; m.att_dk = (int)dk; m.att_dv = dv; m.att_dff = dff; m.att_alpha = alpha; m.ln_eps = eps;
             }

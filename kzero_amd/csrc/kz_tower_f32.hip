@@ -414,6 +414,9 @@ bool conv_heads_fit(int nt, int policy_kind, int extra_moves, int pc, int h, int
     if (pc < 1 || pc > 32 || hc + (extra_moves ? 1 : 0) > 32) return false;  // two 16-channel tiles per small conv
     const int nb = nt * 16 / hw, nseg = 256 / hs;
     if (nb > 4) return false;
+    // the in-launch decode keeps the five raw scalars of board b at sred[8 b ..]: the partial-sum region (nseg * nb * hs floats)
+    // must hold nb * 8 (always true for hs <= 256 — nseg * hs > 128 — and checked where the assumption is made)
+    if (nseg * hs < 8) return false;
     // the zero rows' LDS: conv activations, extra-move plane, hidden, last Linear's weights, partial sums
     const size_t floats = (size_t)nb * hc * hw + (size_t)nb * hw + (size_t)nb * hs + (size_t)5 * hs + (size_t)nseg * nb * hs;
     // (scratch_bytes = 0: the zero rows of the f32 images, what the exact-f32 and the split launches have)

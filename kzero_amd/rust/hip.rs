@@ -18,8 +18,10 @@
 //!    gpu_threads_per_device >= 4 with it for a 256-channel chess network in f16).  Since round 5 the gather + softmax is
 //!    the last step of the network's own launch (one launch per batch, no copy operations: 532k) and
 //!  * a batch's host work before the launch (`encode_input` of every board, `move_to_index` of every available move) is
-//!    shared with `KZ_HIP_PREP_THREADS` scoped helper threads (default 1: the executor thread does half of it), so that
-//!    one executor thread per GPU keeps up on a slow host core too: `prepare` below.
+//!    shared with `KZ_HIP_PREP_THREADS` scoped helper threads when asked for (default 0: all of it on the executor
+//!    thread, which is what the committed seam figures of the default were measured with on the C++ mirror; the mirror's
+//!    helper is a persistent thread, the scoped threads here spawn per batch — a different cost model that has not been
+//!    compiled or timed, so it is opt-in): `prepare` below.
 //!
 //! NOT compiled in this repository's CI (no cargo in the build image); written against the cited signatures.
 
@@ -236,7 +238,7 @@ pub struct HipNetwork<B: Board, M: BoardMapper<B>> {
     device_decode: bool,
     move_offsets: Vec<i64>,
     move_indices: Vec<i32>,
-    /// `KZ_HIP_PREP_THREADS` (default 1) + 1 ranges of a batch, each prepared by one thread (`prepare`)
+    /// `KZ_HIP_PREP_THREADS` (default 0) + 1 ranges of a batch, each prepared by one thread (`prepare`)
     ranges: Vec<PrepRange>,
     ph: PhantomData<B>,
 }
@@ -326,10 +328,15 @@ impl<B: Board, M: BoardMapper<B>> HipNetwork<B, M> {
             move_offsets: vec![],
             move_indices: vec![],
             ranges: {
+                // (a malformed value is not worth a panic in a constructor: no helpers, and say so once)
                 let helpers: usize = match std::env::var("KZ_HIP_PREP_THREADS") {
-                    Err(_) => 1,
-                    Ok(v) => v.parse().unwrap_or_else(|_| panic!("KZ_HIP_PREP_THREADS must be a number, got '{}'", v)),
-                };
+                    Err(_) => 0,
+                    Ok(v) => v.trim().parse().unwrap_or_else(|_| {
+                        eprintln!("kz_hip: KZ_HIP_PREP_THREADS='{}' is not a number: using 0 helper threads", v);
+                        0
+                    }),
+                }
+                .min(8);
                 (0..helpers + 1).map(|_| PrepRange::default()).collect()
             },
             ph: PhantomData,

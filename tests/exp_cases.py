@@ -1,4 +1,4 @@
-"""Parity cases of the EXPERIMENT build (kzero_amd/libkzhip_exp.so: `KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh`): the kernel
+"""Parity cases of the EXPERIMENT build (experiments/libkzhip_exp.so: `experiments/build.sh`): the kernel
 organisations that were built, measured and not adopted — four boards per workgroup (kz_tower4.hip), two Go boards per
 workgroup (kz_board_conv2.hip), the 32x32x16 MFMA variants, hipGraph replay, three Ataxx boards per workgroup of the
 exact-f32 launch — each against the product kernels compiled into the same library and against the oracle; and, the other

@@ -145,7 +145,7 @@ def test_the_guard_turns_every_kind_of_exception_into_a_return_code():
     """The guard every entry point runs through (kz_engine_util.hpp `guarded`), exercised for real: the experiment build
     throws from inside kz_device_count on request — std::length_error, std::bad_alloc, a non-std exception."""
     import subprocess, sys
-    exp = os.path.join(os.path.dirname(capi.LIB_PATH), "libkzhip_exp.so")
+    exp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "experiments", "libkzhip_exp.so")
     if not os.path.exists(exp):
         pytest.skip("libkzhip_exp.so not built")
     for mode, needle in (("1", "C++ exception: vector::_M_default_append"), ("2", "out of host memory"), ("3", "unknown C++ exception")):

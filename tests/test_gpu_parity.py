@@ -4,10 +4,12 @@ Tolerances:
   f32 path: max |delta| <= 1e-4 on policy logits and the 5 scalars (BASELINE.json north_star / BASELINE.md §4).
   f16 path: 1e-4 is not attainable by construction (f16 storage of weights and activations, f32 accumulate: every
             layer rounds the residual stream to 11 bits).  Stated tolerance, per board and per output tensor:
-            max |delta| <= F16_REL * max(1, max |ref|)   with F16_REL = 5e-3   (largest value any test measures: 2.3e-3)
-            rms |delta| <= F16_RMS * max(1, max |ref|)   with F16_RMS = 1e-3   (measured 3.4e-4: rms |dlogit| 1.1e-3 at
-                                                                                logit scale 3.3, chess 20x256)
-            A mis-scaled layer or a wrong weight fragment moves the rms by far more than 3x.
+            max |delta| <= F16_REL * max(1, max |ref|)   with F16_REL = 3.5e-3 (1.5 x the largest value any test measures: 2.3e-3)
+            rms |delta| <= F16_RMS * max(1, max |ref|)   with F16_RMS = 6e-4   (1.5 x the largest measured, 3.4e-4 ... 4e-4:
+                                                                                rms |dlogit| 1.1e-3 at logit scale 3.3, chess 20x256)
+            and, on the three BASELINE configs at full size (A1, C1, G8), post-softmax max |delta p| <= F16_SOFTMAX_ATOL = 1e-3.
+            The bounds sit 1.5 x above what is measured (round 5 had them 2 x above: a 2 x numerical regression passed);
+            a mis-scaled layer or a wrong weight fragment moves the rms by far more than that.
             Two f16 paths of this library against each other (same operands and rounding points, different summation
             order) are bounded relative to the output scale as well: F16_PATHS_REL for 2-block nets, _DEEP for 40+ layers.
 """
@@ -23,8 +25,9 @@ from tests import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 F32_ATOL = 1e-4
-F16_REL = 5e-3
-F16_RMS = 1e-3
+F16_REL = 3.5e-3
+F16_RMS = 6e-4
+F16_SOFTMAX_ATOL = 1e-3
 # two f16 paths of this library against each other (measured <= 2e-4 on 2-block nets, <= 4e-3 after 41 convolutions at
 # logit scale 3.3): absolute on the shallow nets (outputs of order 1), relative to the output scale on the deep ones
 F16_PATHS_ATOL = 2e-3
@@ -331,6 +334,9 @@ def test_config_a1_ataxx_8x128_f32_batch256(dev):
     s16, p16 = eng16.eval_packed(bits, scalars_in)
     assert_f16(s16, s_ref, "f16 scalars")
     assert_f16(p16, p_ref, "f16 policy")
+    sm = float(np.abs(softmax(p16) - softmax(p_ref)).max())
+    print(f"ataxx 8x128 f16 vs oracle, 256 boards: max |dsoftmax| {sm:.2e}")
+    assert sm <= F16_SOFTMAX_ATOL, f"A1 f16: post-softmax max |delta p| = {sm:.3e} > {F16_SOFTMAX_ATOL}"
     # and through the arithmetic the Rust binding defaults to (KZ_HIP_DTYPE=parity): ONE launch per batch since round 3 —
     # the same 1e-4, on every entry point (the asynchronous pair writes straight into the slot's pinned staging)
     split = capi.Engine(capi.Model(blob=blob), dev, 256, capi.KZ_DTYPE_F32_SPLIT16)
@@ -423,7 +429,7 @@ def test_config_c1_f16_against_the_f32_accurate_launch_on_the_whole_batch(dev, c
     sm = np.abs(softmax(p) - softmax(p_ref)).max()
     print(f"chess 20x256 f16 vs f32-accurate, 256 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, max |dsoftmax| {sm:.2e}, "
           f"rms |dlogit| {np.sqrt(np.mean((p - p_ref) ** 2)):.2e}")
-    assert sm < 1e-3
+    assert sm <= F16_SOFTMAX_ATOL
 
 
 # what the Rust shim runs by default (KZ_HIP_DECODE=device, kzero_amd/rust/hip.rs): legal-move probabilities, f16
@@ -615,8 +621,9 @@ def test_config_g8_go19_40x256_at_executor_batch_512(dev, go19_full, go19_full_o
     s_ref, p_ref = f32.eval_packed(bits[sample], scalars_in[sample])
     rs = assert_f16(s[sample], s_ref, "scalars, 64 of 512 boards vs exact f32")
     rp = assert_f16(p[sample], p_ref, "policy, 64 of 512 boards vs exact f32")
-    print(f"go-19 40x256 B=512 f16 vs exact f32 on 64 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, "
-          f"max |dsoftmax| {np.abs(softmax(p[sample]) - softmax(p_ref)).max():.2e}")
+    sm = float(np.abs(softmax(p[sample]) - softmax(p_ref)).max())
+    print(f"go-19 40x256 B=512 f16 vs exact f32 on 64 boards: scalars rel {rs:.2e}, policy rel {rp:.2e}, max |dsoftmax| {sm:.2e}")
+    assert sm <= F16_SOFTMAX_ATOL, f"G8 f16: post-softmax max |delta p| = {sm:.3e} > {F16_SOFTMAX_ATOL}"
     so, po = go19_full_oracle
     assert np.array_equal(sample[::4], G8_PICK)  # boards 0, 32, ..., 480
     assert_f32(s_ref[::4], so, "exact f32 vs oracle, scalars")

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_go_clk
 rm -rf $out
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $out -o run -- python3 bench.py --repeats 1 --workload go19-40x256 --dtype f16 --no-cpu-baseline --no-others --no-host-io --no-seam --engines 1 --steps 4 --warmup 1 --prewarm 0 > $out.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $out -o run -- python3 bench.py --repeats 1 --workload go19-40x256 --dtype f16 --no-cpu-baseline --no-others --boundary resident --no-host-io --no-seam --engines 1 --steps 4 --warmup 1 --prewarm 0 > $out.log 2>&1
 python3 - "$out/run_counter_collection.csv" <<'PY'
 import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))

@@ -12,7 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   out=$PWD/gpurun_out/pmc_traffic_${TAG}_$c
   rm -rf "$out"
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out" -o run -- python3 bench.py --repeats 1 --workload $WL --dtype $DT \
-     ${BATCH:+--batch $BATCH} --engines 1 --steps ${STEPS:-60} --warmup ${WARMUP:-10} --prewarm 0 --no-cpu-baseline --no-others --no-host-io \
+     ${BATCH:+--batch $BATCH} --engines 1 --steps ${STEPS:-60} --warmup ${WARMUP:-10} --prewarm 0 --boundary resident --no-cpu-baseline --no-others --no-host-io \
      > "$out.log" 2>&1
 done
 python3 tools/pmc_traffic.py "$WL" "$DT" "${BATCH:-0}" "$PWD/gpurun_out/pmc_traffic_${TAG}_FETCH_SIZE" "$PWD/gpurun_out/pmc_traffic_${TAG}_WRITE_SIZE"

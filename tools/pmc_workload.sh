@@ -12,7 +12,7 @@ for set in clk sq l2; do
   esac
   out=$PWD/gpurun_out/pmcw_${WL}_${DT}_$set
   rm -rf $out
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 bench.py --repeats 1 --workload $WL --dtype $DT --no-cpu-baseline --no-others --no-host-io --no-seam --engines 1 --steps $STEPS --warmup 5 --prewarm 0 > $out.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o run -- python3 bench.py --repeats 1 --workload $WL --dtype $DT --no-cpu-baseline --no-others --boundary resident --no-host-io --no-seam --engines 1 --steps $STEPS --warmup 5 --prewarm 0 > $out.log 2>&1
   python3 - "$out/run_counter_collection.csv" "$WL $DT $set" <<'PY'
 import csv,sys,collections
 try:

@@ -4,7 +4,7 @@
 mkdir -p gpurun_out/power
 run() {  # name, bench args...
   name=$1; shift
-  python bench.py "$@" --no-cpu-baseline --no-others --no-seam --no-host-io > gpurun_out/power/$name.json 2> gpurun_out/power/$name.err &
+  python bench.py "$@" --no-cpu-baseline --no-others --no-seam --boundary resident --no-host-io > gpurun_out/power/$name.json 2> gpurun_out/power/$name.err &
   pid=$!
   sleep 4
   for i in 1 2 3 4 5 6; do
