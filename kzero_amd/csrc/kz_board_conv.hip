@@ -56,12 +56,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int MT = 24;                 // 16-row tiles per workgroup
+// Wave shape of the f16 instance (template parameters of the body; the split instance is <4, 3>):
+//   NTW = 16-channel output tiles per wave: 4 = all 64 channels of the workgroup x a row quarter (6 tiles: a weight fragment
+//         feeds 6 MFMAs, the four waves load the SAME 4 KB of weights per k-step); 2 = 32 channels x a row half (12 tiles:
+//         a weight fragment feeds 12 MFMAs, a wave loads 2 KB per k-step — half the traffic through the CU's one L1 path —
+//         and every image tile is read from LDS by two waves instead of one)
+//   PF  = weight ring depth in k-steps; PF x NTW = 12 registers of 16 bytes, which double as the staging buffer
 #ifndef KZ_BC_NTW
 #define KZ_BC_NTW 4
 #endif
-constexpr int NTW = KZ_BC_NTW;         // 16-channel output tiles per wave: 4 = all 64 channels of the workgroup x a
-                                       // row quarter (6 tiles); 2 = 32 channels x a row half (12 tiles)
-constexpr int MTW = MT / NTW;          // tiles per wave (there are NTW row groups)
 constexpr int ROWS = MT * 16;          // 384
 constexpr int OCW = 64;                // output channels per workgroup
 constexpr int CH = 64;                 // input channels per staged chunk
@@ -69,11 +72,14 @@ constexpr int PRS = 32 * 2 + 16;       // plane row stride: 32 channels + 16 B p
 constexpr int LDS_MAX = 80 * 1024;     // two workgroups per CU
 constexpr int ORS = OCW * 2 + 16;      // row stride of the epilogue's output tile
 constexpr int KPC = 18;                // k-steps (32 channels of one tap) per chunk: 9 taps x 2
-#ifndef KZ_BC_PF
-#define KZ_BC_PF 3
-#endif
-constexpr int PF = KZ_BC_PF;           // weight ring depth in k-steps (a k-step is 24 MFMAs = 384 cycles per wave)
-static_assert(KPC % PF == 0, "ring stage of a k-step must not depend on the chunk");
+// f(integral_constant<0>), ..., f(integral_constant<N - 1>), in order
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 // fragment read from an integer LDS byte address (the dynamic LDS block starts at 0; going through the `lds` symbol
 // costs a v_add per read)
@@ -144,8 +150,12 @@ struct BoardConvDev {
 // (hi*hi + lo*hi + hi*lo, f32 accumulation) — the arithmetic of kz_tower_split.hip, per layer: a chunk is 32 channels, its
 // hi halves in plane 0 and lo halves in plane 1 of the same image, a tap takes a hi and a lo weight step from the ring.  In
 // HBM a pixel row is [hi 32 | lo 32] per group of 32 channels: a chunk, and a pass of the epilogue, are whole 128-byte lines.
-template <bool SPLIT>
+template <bool SPLIT, int NTW, int PF>
 __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
+    constexpr int MTW = MT / NTW;  // tiles per wave (there are NTW row groups)
+    static_assert(KPC % PF == 0, "ring stage of a k-step must not depend on the chunk");
+    static_assert(NTW * PF == 12, "12 staging pieces = PF ring stages x NTW registers");
+    static_assert(!SPLIT || NTW == 4, "the split epilogue's two passes are written for 64 channels per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -338,7 +348,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // LDS address of this lane's fragment row per tile for one tap: a constant row offset in the halo image.
     // (pitch_prs is the line's bytes behind an optimisation barrier inside the chunk loop: the rows are the same for every
     // chunk, and the compiler would otherwise hoist all 9 x 12 of them out of the loop and spill them)
-    auto tap_rows = [&](int tap, int lo, int hi, int pitch_prs, int (&T)[MTW]) {
+    auto tap_rows = [&](int tap, int lo, int hi, int pitch_prs, int (&T)[MT / NTW]) {
         const int off = (tap / 3 - 1) * pitch_prs + (tap % 3 - 1) * PRS;
 #pragma unroll
         for (int i = 0; i < MTW; i++) {
@@ -376,19 +386,20 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         const auto trsrc = last_chunk ? rrsrc : xrsrc;
         const int tsoff = last_chunk ? nquarter * OCW * (SPLIT ? 4 : 2) : (chunk + 1) * 128;  // (a chunk is 128 bytes of a row either way)
 
-        // Two half-steps per k-step: the MFMAs of tiles 0..2 run while the fragments of tiles 3..5 are read, and
-        // vice versa (the fragments of the NEXT k-step's first half); the other wave of the SIMD (the CU's second
-        // workgroup) fills whatever latency is left.
-        // A wave whose sixth tile is pure padding (Go's 361 pixels are 22.6 tiles, so tile 23 — wave 3's sixth — holds
-        // none) does not issue that tile's fragment read and 4 MFMAs: 4 % of the launch's MFMA work, and of its power.
-        constexpr int HT = MTW / 2;
+        // A k-step in NP parts of three tiles: the MFMAs of one part run while the fragments of the next are read (the last
+        // part reads the NEXT k-step's first); the other wave of the SIMD (the CU's second workgroup) fills whatever latency
+        // is left.  (NTW = 4: two parts — the half-steps of rounds 1-5; NTW = 2: four.)
+        // A wave whose last tile is pure padding (Go's 361 pixels are 22.6 tiles, so tile 23 holds none) does not issue that
+        // tile's fragment read and NTW MFMAs: 4 % of the launch's MFMA work, and of its power.
+        constexpr int HT = 3, NP = MTW / HT;
+        static_assert(MTW % HT == 0 && NP % 2 == 0, "parts alternate between two fragment buffers; part 0 is always buffer 0");
         int T[MTW];
-        h16x8 bfA[HT], bfB[HT] = {};
+        h16x8 bf[2][HT] = {};
         int pitch_prs = a.line16 * 16;  // bytes from a line to the next
         asm volatile("" : "+s"(pitch_prs));
         tap_rows(0, 0, MTW, pitch_prs, T);
 #pragma unroll
-        for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i]);
+        for (int i = 0; i < HT; i++) bf[0][i] = lds_frag(T[i]);
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int next_tap = tap < 8 ? tap + 1 : 8;
@@ -402,54 +413,58 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                 const bool stage_done = SPLIT ? ks != 0 : true;  // this MFMA step is the last one that reads the stage
                 const int ao = SPLIT ? (ks == 1 ? 32 : 0) : ks * 32;  // where this step's fragments sit in a row (SPLIT: lo behind hi)
                 const int ao_next = ks == KS - 1 ? 0 : SPLIT ? (ks + 1 == 1 ? 32 : 0) : (ks + 1) * 32;
-                // ---- half 1 ----
-#pragma unroll
-                for (int i = 0; i < HT - 1; i++) bfB[i] = lds_frag(T[HT + i] + ao);
-                if (!skip_last_tile) bfB[HT - 1] = lds_frag(T[MTW - 1] + ao);
                 h16x8 af[NTW];  // aliases of the ring stage (no copy: the stage is reloaded after this k-step's MFMAs)
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) af[nt] = *reinterpret_cast<const h16x8 *>(&wreg[stage][nt]);
+                static_for<NP>([&](auto P) __attribute__((always_inline)) {
+                    constexpr int p = decltype(P)::value;  // (a constant expression: the scheduling barriers take immediates)
+                    constexpr int cur = p & 1, nxt = cur ^ 1;
+                    constexpr bool last_part = p == NP - 1;
+                    // ---- the next part's fragments: tiles (p + 1) HT ..; behind the last part, the next k-step's first ----
+                    // T is updated in place for the next tap as soon as a part's rows have been read for the last time
+                    if (!last_part) {
 #pragma unroll
-                for (int i = 0; i < HT; i++)
+                        for (int i = 0; i < HT; i++) {
+                            const int t = (p + 1) * HT + i;
+                            if (t != MTW - 1) bf[nxt][i] = lds_frag(T[t] + ao);
+                        }
+                        if (p + 1 == NP - 1 && !skip_last_tile) bf[nxt][HT - 1] = lds_frag(T[MTW - 1] + ao);
+                        if (ks == KS - 1) tap_rows(next_tap, (p + 1) * HT, (p + 2) * HT, pitch_prs, T);
+                    } else {
+                        if (ks == KS - 1) tap_rows(next_tap, 0, HT, pitch_prs, T);
 #pragma unroll
-                    for (int nt = 0; nt < NTW; nt++)
-                        acc[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfA[i], acc[nt][i], 0, 0, 0);
-                // the reads first: a fragment is then consumed >= 12 MFMAs (192 cycles) after its read was issued
-                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT - 1, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, HT * NTW, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- half 2 ----
-                // T is updated in place for the next tap: rows 0..2 are dead after the last half-2 read of this tap,
-                // rows 3..5 after the half-1 read above
-                if (ks == KS - 1) tap_rows(next_tap, 0, HT, pitch_prs, T);
+                        for (int i = 0; i < HT; i++) bf[nxt][i] = lds_frag(T[i] + ao_next);
+                    }
+                    // ---- this part's MFMAs (the wave's last tile, when it is padding, behind a wave-uniform branch) ----
 #pragma unroll
-                for (int i = 0; i < HT; i++) bfA[i] = lds_frag(T[i] + ao_next);
-                if (ks == KS - 1) tap_rows(next_tap, HT, MTW, pitch_prs, T);
+                    for (int i = 0; i < HT; i++) {
+                        const int t = p * HT + i;
+                        if (t == MTW - 1) continue;
 #pragma unroll
-                for (int i = 0; i < HT - 1; i++)
+                        for (int nt = 0; nt < NTW; nt++)
+                            acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[cur][i], acc[nt][t], 0, 0, 0);
+                    }
+                    // the reads first: a fragment is then consumed >= 12 MFMAs (192 cycles; NTW = 2: 6) after its read was issued
+                    __builtin_amdgcn_sched_group_barrier(SG_DS_READ, p + 1 == NP - 1 ? HT - 1 : HT, 0);
+                    __builtin_amdgcn_sched_group_barrier(SG_MFMA, (last_part ? HT - 1 : HT) * NTW, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (last_part && !skip_last_tile) {
 #pragma unroll
-                    for (int nt = 0; nt < NTW; nt++)
-                        acc[nt][HT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[i], acc[nt][HT + i], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_DS_READ, HT, 0);
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, (HT - 1) * NTW, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!skip_last_tile) {
-#pragma unroll
-                    for (int nt = 0; nt < NTW; nt++)
-                        acc[nt][MTW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bfB[HT - 1], acc[nt][MTW - 1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int nt = 0; nt < NTW; nt++)
+                            acc[nt][MTW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf[cur][HT - 1], acc[nt][MTW - 1], 0, 0, 0);
+                    }
+                    if (last_part) __builtin_amdgcn_sched_barrier(0);
+                });
                 // this stage's fragments have been issued to the MFMAs: refill it
                 if (!stage_done) {
                 } else if (wstep < KPC - PF) {  // (compile time) with the weights of k-step g + PF
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++) wreg[stage][nt] = wp[(size_t)(g + PF) * 256 + (wo * NTW + nt) * 64];
-                } else {  // last PF k-steps: pieces 4 jj .. 4 jj + 3 of the next image chunk / the residual
+                } else {  // last PF k-steps: pieces NTW jj .. NTW jj + NTW - 1 of the next image chunk / the residual
                     const int jj = wstep - (KPC - PF);
-                    static_assert(NTW == 4 && PF == 3, "12 pieces = PF stages x NTW registers");
 #pragma unroll
                     for (int nt = 0; nt < NTW; nt++)
-                        wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po_of(jj * 4 + nt), tsoff, 0));
+                        wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po_of(jj * NTW + nt), tsoff, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (stage_done) g++;
@@ -654,8 +669,8 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
 #endif
 }
 
-__global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) { board_conv_body<false>(a); }
-__global__ __launch_bounds__(256, 2) void kz_board_conv_split16(BoardConvDev a) { board_conv_body<true>(a); }
+__global__ __launch_bounds__(256, 2) void kz_board_conv_f16(BoardConvDev a) { board_conv_body<false, KZ_BC_NTW, 12 / KZ_BC_NTW>(a); }
+__global__ __launch_bounds__(256, 2) void kz_board_conv_split16(BoardConvDev a) { board_conv_body<true, 4, 3>(a); }
 
 }  // namespace
 
@@ -723,7 +738,7 @@ void board_conv_pack_weights(const float *oihw, int cout, int cin, uint16_t *dst
 
 // ---- split arithmetic: tensors of [pixels][C / 32][hi 32 | lo 32] f16 rows, 32-channel chunks ----
 bool board_conv_split_supported(int h, int w, int cin, int cout) {
-    return NTW == 4 && cin == cout && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 && geometry(h, w).bpw >= 1;
+    return cin == cout && cout % OCW == 0 && w <= 32 && h <= 32 && w >= 2 && h >= 2 && geometry(h, w).bpw >= 1;
 }
 
 size_t board_conv_split_weight_elems(int cin, int cout) { return (size_t)2 * 9 * cin * cout; }
