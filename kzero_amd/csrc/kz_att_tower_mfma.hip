@@ -182,8 +182,12 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // LayerNorm(D) without parameters over the features of every token (attention.py:80-81), X in registers: this wave's NTD
-// feature tiles of all tokens.  One pass (sum and sum of squares in f32), one exchange between the waves: ln_partial writes
-// this wave's sums, the caller synchronises, ln_finish normalises X and writes its f16 copy into X16 (NOT synchronised).
+// feature tiles of all tokens.  One exchange between the waves, and no cancellation: a wave reduces its OWN D / 8 features
+// of a token in two passes over its registers (sum, then the squared deviations from its own mean), the waves exchange
+// (sum, M2) and ln_finish combines them exactly (Chan et al.: M2 = sum_w M2_w + n sum_w (mean_w - mean)^2).  (Rounds 5's
+// E[x^2] - mean^2 in one pass lost digits when a token's mean was large against its spread — a trained embedding with a
+// common offset in front of the first layer — while the exact-f32 instance is held to 1e-4.)  ln_partial writes this wave's
+// pair, the caller synchronises, ln_finish normalises X and writes its f16 copy into X16 (NOT synchronised).
 template <int NTD, int TT>
 __device__ __forceinline__ void ln_partial(const f32x4 (&X)[NTD][TT], float *red, int wave, int fr, int kq) {
 #pragma unroll
@@ -192,11 +196,16 @@ __device__ __forceinline__ void ln_partial(const f32x4 (&X)[NTD][TT], float *red
 #pragma unroll
         for (int t = 0; t < NTD; t++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                s += X[t][tt][j];
-                q = fmaf(X[t][tt][j], X[t][tt][j], q);
-            }
+            for (int j = 0; j < 4; j++) s += X[t][tt][j];
         s = group_sum(s);
+        const float mw = __fmul_rn(s, 1.0f / (NTD * 16));  // this wave's mean over its NTD * 16 features of the token
+#pragma unroll
+        for (int t = 0; t < NTD; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float d = __fsub_rn(X[t][tt][j], mw);
+                q = fmaf(d, d, q);
+            }
         q = group_sum(q);
         if (kq == 0) {
             red[(16 * tt + fr) * A16_WAVES + wave] = s;
@@ -206,21 +215,34 @@ __device__ __forceinline__ void ln_partial(const f32x4 (&X)[NTD][TT], float *red
 }
 template <class O, int D, int NTD, int TT, int LDX>
 __device__ __forceinline__ void ln_finish(f32x4 (&X)[NTD][TT], const float *red, typename O::E *X16, int wave, int fr, int kq, float eps) {
+    static_assert(A16_WAVES == 8 && NTD * 16 * A16_WAVES == D, "eight waves share a token's D features evenly");
 #pragma unroll
     for (int tt = 0; tt < TT; tt++) {
         const f32x4 *ps = reinterpret_cast<const f32x4 *>(red + (16 * tt + fr) * A16_WAVES);
         const f32x4 *pq = reinterpret_cast<const f32x4 *>(red + TT * 16 * A16_WAVES + (16 * tt + fr) * A16_WAVES);
         const f32x4 s0 = ps[0], s1 = ps[1], q0 = pq[0], q1 = pq[1];
         const float sum = ((s0[0] + s0[1]) + (s0[2] + s0[3])) + ((s1[0] + s1[1]) + (s1[2] + s1[3]));
-        const float sq = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
-        const float mean = sum * (1.0f / D);
-        const float var = fmaxf(sq * (1.0f / D) - mean * mean, 0.0f);
-        const float inv = __builtin_amdgcn_rsqf(var + eps);
-        const float shift = -mean * inv;
+        const float mean = __fmul_rn(sum, 1.0f / D);
+        float m2 = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+        float between = 0.0f;  // sum over the waves of (mean_w - mean)^2
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const float d0 = fmaf(s0[w], 1.0f / (NTD * 16), -mean), d1 = fmaf(s1[w], 1.0f / (NTD * 16), -mean);
+            between = fmaf(d0, d0, between);
+            between = fmaf(d1, d1, between);
+        }
+        m2 = fmaf(between, (float)(NTD * 16), m2);
+        const float inv = __builtin_amdgcn_rsqf(fmaf(m2, 1.0f / D, eps));  // biased variance M2 / D
+        const float shift = __fmul_rn(-mean, inv);
 #pragma unroll
         for (int t = 0; t < NTD; t++) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) X[t][tt][j] = fmaf(X[t][tt][j], inv, shift);
+            for (int j = 0; j < 4; j++) {
+                X[t][tt][j] = fmaf(X[t][tt][j], inv, shift);
+                // the f16 copy is the rounding of THIS f32 value in every instance: without the barrier the compiler may fold
+                // fma + conversion into one v_fma_mix (a single rounding) in one instance and not in another
+                asm volatile("" : "+v"(X[t][tt][j]));
+            }
             *reinterpret_cast<typename O::E4 *>(X16 + (16 * tt + fr) * LDX + (wave * NTD + t) * 16 + 4 * kq) = O::cvt4(X[t][tt]);
         }
     }

@@ -1361,6 +1361,29 @@ def test_attention_tower_against_the_oracle(dev, game, depth, d_model, att, head
             assert np.array_equal(s3, s2[:37]) and np.array_equal(p3, p2[:37])
 
 
+def test_attention_tower_layernorm_with_a_large_common_offset(dev):
+    """The exact-f32 AttentionTower is held to 1e-4.  Its first LayerNorm normalises expand(x) + embedding unnormalised; a
+    trained embedding may carry a common offset far above the tokens' spread, where a one-pass variance (E[x^2] - mean^2 in
+    f32) cancels: offset 60 against a spread of ~1 loses four digits.  The kernels combine per-wave (sum, M2) pairs instead
+    (advisor, round 5); this case makes the offset real — on the matrix-core tower and on the vector-ALU one."""
+    from kzero_amd.model_file import write_model
+    for att, path in (((8, 16, 16, 256), "attention_tower_f32"), ((8, 16, 16, 512), "attention_tower_f32_valu")):
+        blob = synth.random_model("chess", 2, 256, "attention", seed=31, attention=att)
+        meta, tensors = read_model(blob)
+        tensors = {k: np.array(v) for k, v in tensors.items()}
+        tensors["common.embedding"] = (tensors["common.embedding"] + np.float32(60.0)).astype(np.float32)
+        blob = write_model(meta, tensors)
+        net = O.OracleNet(blob)
+        bits, scalars_in = synth.random_boards("chess", 9, seed=37)
+        x = O.encode_input_full(bits, scalars_in, net.n_scalar, net.n_bool, net.h, net.w)
+        s_or, p_or = net.forward(x, threads=8)
+        eng = capi.Engine(capi.Model(blob=blob), dev, 16, capi.KZ_DTYPE_F32)
+        assert eng.tower_path == path
+        s, p = eng.eval_packed(bits, scalars_in)
+        assert_f32(s, s_or, f"{path}: scalars with an embedding offset of 60")
+        assert_f32(p, p_or, f"{path}: policy with an embedding offset of 60")
+
+
 @pytest.mark.parametrize("dtype", [capi.KZ_DTYPE_F16, capi.KZ_DTYPE_F32])
 def test_attention_network_full_size_default_shim_entry(dev, dtype):
     """The network python/main/supervised_main_alpha.py:69-77 builds — AttentionTower(8, 21, 16, 256, 8, 16, 16, 256) under the
