@@ -94,6 +94,9 @@ __device__ __forceinline__ h16x8 lds_frag(int addr) {
 }
 
 constexpr int SG_MFMA = 0x8, SG_DS_READ = 0x100;
+#ifndef KZ_BC_DIAG
+#define KZ_BC_DIAG 0  // diagnostic builds only (wrong results): 1 = no output-tile writes in the epilogue, 2 = no read-back of the
+#endif                // output tile, 4 = no halo clear, 8 = no residual reads — to attribute SQ_LDS_BANK_CONFLICT by phase
 #ifndef KZ_BC_STORE_AUX
 #define KZ_BC_STORE_AUX 0  // cache policy bits of the output stores (diagnostic builds: 2 = nt)
 #endif
@@ -304,7 +307,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // its left halo row and the five of its right one (with skew 0 the next line's left halo)
     {
         const int nhb = a.line16 + 5 * (a.pitch + 1) + 10 * a.h;  // halo slots per board and plane
-        for (int id = tid; id < 2 * a.bpw * nhb; id += 256) {
+        for (int id = tid; id < ((KZ_BC_DIAG & 4) ? 0 : 2 * a.bpw * nhb); id += 256) {
             const int pb = (int)__umulhi((unsigned)id, a.inv_nhb), k = id - pb * nhb;  // id / nhb (plane-major, then board)
             const int pl = pb >= a.bpw ? 1 : 0, b = pb - pl * a.bpw;
             int slot16;
@@ -611,7 +614,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
             for (int nt = 0; nt < NTW; nt++)
 #pragma unroll
                 for (int i = 0; i < MTW; i++)
-                    rres[nt][i] = *reinterpret_cast<const h16x4 *>(lds + ((wr * MTW + i) * 16 + fr) * ORS + ((wo * NTW + nt) * 16 + kq * 4) * 2);
+                    rres[nt][i] = (KZ_BC_DIAG & 8) ? h16x4{} : *reinterpret_cast<const h16x4 *>(lds + ((wr * MTW + i) * 16 + fr) * ORS + ((wo * NTW + nt) * 16 + kq * 4) * 2);
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
@@ -636,14 +639,15 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                     asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo01) : "v"(r01), "v"(v[1]));
                     asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo23) : "v"(r23), "v"(v[2]));
                     asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo23) : "v"(r23), "v"(v[3]));
-                    *reinterpret_cast<uint2 *>(slot) = make_uint2(lo01, lo23);
+                    if (!(KZ_BC_DIAG & 1)) *reinterpret_cast<uint2 *>(slot) = make_uint2(lo01, lo23);
                 } else {
                     if constexpr (with_residual) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) v[j] += (float)rres[nt][i][j];  // added in f32, AFTER the ReLU
                     }
                     if constexpr (post) v = v * ps + pt;
-                    *reinterpret_cast<h16x4 *>(slot) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                    if (!(KZ_BC_DIAG & 1)) *reinterpret_cast<h16x4 *>(slot) = h16x4{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                    else asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
                 }
             }
         }
@@ -661,7 +665,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 12; i++)  // a padding row's store is out of range and dropped
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
+        __builtin_amdgcn_raw_buffer_store_b128((KZ_BC_DIAG & 2) ? u32x4{} : *reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
                                                nquarter * OCW * 2, KZ_BC_STORE_AUX);
     KZ_STAMP(20);
 #ifdef KZ_BC_REALTIME
