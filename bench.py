@@ -7,18 +7,21 @@ own `real` counter (rust/kz-selfplay/src/server/server_alphazero.rs:113-115, col
 round-robin over `--engines` executor engines per GPU (the reference's gpu_threads_per_device, rust/Readme.md:51), each
 with its own HIP stream(s).
 
-One JSON line on rank 0 carries
-  * `value`: the K timed steps with the packed boards already resident in HBM and the outputs left in HBM (the
-    measurement contract: inputs resident when the timed region starts).  The K-step region is timed `--repeats` times
-    (default 7), each bracketed by barrier + device sync on both sides; `value` is the MEDIAN region, `value_min` /
-    `value_max` the slowest and fastest, `ms_per_step` x `steps` = the median region;
-  * `value_host_boundary` (= `pcie_inclusive.value`): the same K steps, the same number of regions, through the
-    host-pointer boundary the reference's `evaluate_batch` has (cudnn.rs:55-87: host boards in, host results out):
-    kz_engine_submit_packed -> kz_engine_wait_view, pinned staging, H2D of 136 B and D2H of 7,540 B per evaluation inside
-    the timed region — THE number to hold against the reference's `real` evals/s; the contract keeps it out of `value`;
-  * `roofline` for the dominant kernel, HIP events on the engines' own streams over the timed region;
-  * `others` (N=1 only): the other single-GPU BASELINE configs as ~1 s sub-records — A1 Ataxx 8x128 f32 B=256, the G8
-    network Go-19 40x256 f16 B=512, and the chess network through the <=1e-4-parity path (f32split16);
+ONE JSON line of at most 4 KB on rank 0 (kzero_amd/benchline.py: fixed key set; round 5's 27 KB line was not parsed by the
+driver) and the full record of everything measured in bench_full.json beside it (tools/show_bench.py prints it):
+  * `value`: the K timed steps THROUGH THE BOUNDARY A CALLER HAS — host boards + move lists in, decoded values + legal-move
+    probabilities out (kz_engine_submit_packed_decoded -> kz_engine_wait_decoded: what kzero_amd/rust/hip.rs runs by
+    default, replacing cudnn.rs:55-87 + common.rs:16-100), H2D of 284 B and D2H of 160 B per chess evaluation inside the
+    timed region.  The K-step region is timed `--repeats` times (default 7), each bracketed by barrier + device sync on both
+    sides; `value` is the MEDIAN region, `value_min` / `value_max` the slowest and fastest, `ms_per_step` x `steps` = the
+    median region;
+  * `value_device_resident`: the same K steps with the packed boards already in HBM and the raw outputs left in HBM — what
+    `value` was in rounds 1-5 (1.00-1.015 x `value`; no caller of the Network trait can obtain it); `--boundary resident` makes
+    it `value` for kernel A/B runs.  `value_host_boundary_raw`: host boards in, the raw 7.5 KB of policy rows out;
+  * `roofline` for the dominant kernel, following `value`: HIP events on the engines' own streams over the timed region;
+  * `others` (N=1 only): the other single-GPU BASELINE configs as `[workload, dtype, evals/s, frac]` tuples from ~1 s
+    sub-records through the same boundary — A1 Ataxx 8x128 f32 B=256 (and at parity), the G8 network Go-19 40x256 B=512 in
+    f16 and at parity, and the chess network through the <=1e-4-parity path (f32split16) = `value_parity_default`;
   * `cpu_baseline` (N=1 only): the oracle on this box's host cores, bounded sample.
 
 Multi-GPU: the path shards by game -> device with no collective (each device has its own job channel,
