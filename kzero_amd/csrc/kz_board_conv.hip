@@ -398,6 +398,15 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
         static_assert(MTW % HT == 0 && NP % 2 == 0, "parts alternate between two fragment buffers; part 0 is always buffer 0");
         int T[MTW];
         h16x8 bf[2][HT] = {};
+#ifndef KZ_BC_EARLY_W
+#define KZ_BC_EARLY_W 1  // (0: the A/B build without the early weight step)
+#endif
+        // The ring's registers carry the next chunk's image pieces over the chunk boundary, so the next chunk's FIRST weight
+        // step could only be requested behind the boundary's barriers and the first k-step then waited a whole L2 round trip
+        // for it.  f16 instance (16 spare registers; the split instance has none): that one step is requested two k-steps
+        // before the boundary into registers of its own and handed to the ring at the boundary.
+        constexpr bool EARLY = !SPLIT && KZ_BC_EARLY_W;
+        uint4 early[EARLY ? NTW : 1];
         int pitch_prs = a.line16 * 16;  // bytes from a line to the next
         asm volatile("" : "+s"(pitch_prs));
         tap_rows(0, 0, MTW, pitch_prs, T);
@@ -469,6 +478,13 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
                     for (int nt = 0; nt < NTW; nt++)
                         wreg[stage][nt] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, po_of(jj * NTW + nt), tsoff, 0));
                 }
+                if constexpr (EARLY) {
+                    if (wstep == KPC - 2) {  // (compile time) k-step g + 2 = the next chunk's first (the last chunk: a harmless reload)
+                        const int ge = last_chunk ? g : g + 2;
+#pragma unroll
+                        for (int nt = 0; nt < NTW; nt++) early[nt] = wp[(size_t)ge * 256 + (wo * NTW + nt) * 64];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (stage_done) g++;
             }
@@ -490,7 +506,10 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
 #pragma unroll
             for (int st = 0; st < PF; st++)
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++) wreg[st][nt] = wp[(size_t)(g + st) * 256 + (wo * NTW + nt) * 64];
+                for (int nt = 0; nt < NTW; nt++) {
+                    if (EARLY && st == 0) wreg[0][nt] = early[nt];
+                    else wreg[st][nt] = wp[(size_t)(g + st) * 256 + (wo * NTW + nt) * 64];
+                }
             KZ_STAMP(7 + (chunk & 3) * 4);
         }
     }
