@@ -195,8 +195,8 @@ int kz_engine_kernel_time(kz_engine *engine, const char *prefix, double *total_m
  *                           choice for ONE engine at batch <= 256)
  *   KZ_KEEP_ACTIVATIONS=1   with KZ_FORCE_GENERIC=1: keep every layer's output for kz_engine_read_activation
  * The kernel organisations that were measured and rejected (four boards per workgroup, two Go boards per workgroup,
- * 32x32x16 tiles, hipGraph replay, ablation knobs) are NOT in this library: `KZ_EXPERIMENTS=1 kzero_amd/csrc/build.sh`
- * builds them into a separate libkzhip_exp.so for tests/test_gpu_experiments.py and tools/.
+ * 32x32x16 tiles, hipGraph replay, ablation knobs) are NOT in this library nor in its source directory: `experiments/build.sh`
+ * builds them (experiments/csrc/) into a separate experiments/libkzhip_exp.so for tests/test_gpu_experiments.py.
  *
  * Name of the path the engine chose; DESIGN.md 5.0 has the table (shape x arithmetic -> path, launches per batch, measured
  * rate), printed from kz_model_plan by tools/gen_path_table.py and held to the built library by tests/test_path_table.py.
