@@ -206,10 +206,12 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     // the same row offset — the planes are a multiple of 256 B apart for the fragment reads — and every group took two
     // cycles: ~3e6 of the 5.8e6 SQ_LDS_BANK_CONFLICT cycles of a Go launch.  A group is now pieces 0..3 of rows r and r + 4
     // (4 x 80 B = 64 mod 128: the other half of the bank row; 4 x 144 B likewise in the epilogue's output tile), the next
-    // group the same rows' pieces 4..7: lane bits (0,1) = piece low bits, 2 = row bit 2, 3 = the plane, (4,5) = row bits
-    // (0,1), the wave = row bits (3,4).  A wave's load or store still covers the same eight whole 128-byte rows.
-    const int piece = SPLIT ? (tid & 7) : ((tid & 3) | ((tid >> 1) & 4));
-    const int trow = SPLIT ? (tid >> 3) : (((tid >> 4) & 3) | (tid & 4) | ((tid >> 6) << 3));
+    // group the same rows' pieces 4..7: lane bits (0,1) = piece low bits, 2 = row bit 2, (3,4) = row bits (0,1), 5 = the
+    // plane, the wave = row bits (3,4).  (The plane on bit 5, not 3: the four 16-lane groups of the epilogue's ds_read_b128
+    // read-back then meet half as many occupied slots of the output tile.)  A wave's load or store still covers the same
+    // eight whole 128-byte rows.
+    const int piece = SPLIT ? (tid & 7) : ((tid & 3) | ((tid >> 3) & 4));
+    const int trow = SPLIT ? (tid >> 3) : (((tid >> 3) & 3) | (tid & 4) | ((tid >> 6) << 3));
     // f16: pieces 0..3 = channels [0, 32) -> plane 0, 4..7 -> plane 1.  SPLIT: pieces 0..3 = the hi halves of channel
     // pieces c = 0..3, 4..7 their lo halves: channel piece c lives in plane c & 1 at 16 (c >> 1), lo 32 bytes behind hi —
     // lane groups kq and kq + 1 then read the two planes at the same row offset, like the f16 instance
@@ -614,9 +616,17 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     __syncthreads();  // every wave is done with the last chunk's fragments
     KZ_STAMP(18);
     const int out_lds = trow * ORS + piece * 16;  // + i * 32 * ORS
+    // The output tile keeps the two 8-byte halves of every 16-byte piece SWAPPED in the rows whose bit 3 is set: a lane's four
+    // channels are 8 bytes, a ds_write_b64 / ds_read_b64 group is the 16 rows of a tile at one channel offset, and at a
+    // 144-byte row stride rows r and r + 8 share a bank — with the swap they take the two halves of the slot instead (the
+    // 2-way conflicts of the epilogue's 24 writes and 24 residual reads per lane are gone).  For the lanes of the MFMA layout
+    // that is kq ^ (fr >> 3), a constant; for the coalesced 16-byte side (residual in, rows out) the row's bit 3 is the
+    // wave's bit 0: waves 1 and 3 swap the halves of what they stage and of what they store.
+    const bool swap_halves = wave & 1;
+    auto halves = [&](uint4 v) __attribute__((always_inline)) { return swap_halves ? make_uint4(v.z, v.w, v.x, v.y) : v; };
     if (with_res) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = wreg[i / NTW][i % NTW];
+        for (int i = 0; i < 12; i++) *reinterpret_cast<uint4 *>(lds + out_lds + i * 32 * ORS) = halves(wreg[i / NTW][i % NTW]);
         KZ_STAMP(23);
         __syncthreads();
     }
@@ -627,13 +637,14 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     auto finish = [&](auto RES, auto POST) __attribute__((always_inline)) {
         constexpr bool with_residual = decltype(RES)::value, post = decltype(POST)::value;
         const float floor_ = a.relu ? 0.0f : -__builtin_inff();
+        const int kqs = kq ^ (fr >> 3);  // where this lane's four channels sit in the output tile (halves swapped in rows 8..15 of a tile)
         h16x4 rres[NTW][MTW];
         if constexpr (with_residual) {
 #pragma unroll
             for (int nt = 0; nt < NTW; nt++)
 #pragma unroll
                 for (int i = 0; i < MTW; i++)
-                    rres[nt][i] = (KZ_BC_DIAG & 8) ? h16x4{} : *reinterpret_cast<const h16x4 *>(lds + ((wr * MTW + i) * 16 + fr) * ORS + ((wo * NTW + nt) * 16 + kq * 4) * 2);
+                    rres[nt][i] = (KZ_BC_DIAG & 8) ? h16x4{} : *reinterpret_cast<const h16x4 *>(lds + ((wr * MTW + i) * 16 + fr) * ORS + ((wo * NTW + nt) * 16 + kqs * 4) * 2);
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
@@ -645,7 +656,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
             }
 #pragma unroll
             for (int i = 0; i < MTW; i++) {
-                unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + ocl * 2;  // owned by exactly this lane
+                unsigned char *slot = lds + ((wr * MTW + i) * 16 + fr) * ORS + ((wo * NTW + nt) * 16 + kqs * 4) * 2;  // owned by exactly this lane
                 f32x4 v = acc[nt][i];
 #pragma unroll
                 for (int j = 0; j < 4; j++) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(floor_));  // [relu] (one instruction: no compare mask, no canonicalising copy)
@@ -684,7 +695,7 @@ __device__ __forceinline__ void board_conv_body(const BoardConvDev &a) {
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 12; i++)  // a padding row's store is out of range and dropped
-        __builtin_amdgcn_raw_buffer_store_b128((KZ_BC_DIAG & 2) ? u32x4{} : *reinterpret_cast<const u32x4 *>(lds + out_lds + i * 32 * ORS), yrsrc, po[i],
+        __builtin_amdgcn_raw_buffer_store_b128((KZ_BC_DIAG & 2) ? u32x4{} : __builtin_bit_cast(u32x4, halves(*reinterpret_cast<const uint4 *>(lds + out_lds + i * 32 * ORS))), yrsrc, po[i],
                                                nquarter * OCW * 2, KZ_BC_STORE_AUX);
     KZ_STAMP(20);
 #ifdef KZ_BC_REALTIME
